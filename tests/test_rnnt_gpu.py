@@ -1,0 +1,192 @@
+"""Parity of the HIP RNN-T loss (through the C-ABI) against the CPU oracle.
+
+Tolerance (BASELINE.json north_star): loss and gradient within 1e-4 relative
+in fp32.  Costs are compared with rtol 1e-5; gradients (values in [-1,1]) with
+atol 1e-5 + rtol 1e-4 -- tighter than the bar.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from test_oracle_rnnt import KAT_COST, KAT_GRAD, KAT_LOGITS
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def run_hip(logits, targets, llens, tlens, blank=0, clamp=-1.0, reduction="none", grad_out=None, inplace=False):
+    import wenet_celoss_amd as w
+    x = torch.tensor(logits, device=DEV, requires_grad=True)
+    xin = x.clone() if inplace else x          # a non-leaf so that in-place gradient is legal
+    y = torch.tensor(targets, dtype=torch.int32, device=DEV).reshape(x.shape[0], -1)
+    ll = torch.tensor(llens, dtype=torch.int32, device=DEV)
+    tl = torch.tensor(tlens, dtype=torch.int32, device=DEV)
+    loss = w.rnnt_loss(xin, y, ll, tl, blank=blank, clamp=clamp, reduction=reduction, inplace_grad=inplace)
+    if grad_out is None:
+        loss.sum().backward()
+    else:
+        loss.backward(torch.tensor(grad_out, device=DEV, dtype=torch.float32))
+    return loss.detach().cpu().numpy(), x.grad.cpu().numpy()
+
+
+def make_case(rng, B, T, U, V, scale=1.5, full=False):
+    logits = (rng.normal(size=(B, T, U + 1, V)) * scale).astype(np.float32)
+    targets = rng.integers(1, V, size=(B, U)).astype(np.int32) if U > 0 else np.zeros((B, 0), np.int32)
+    if full:
+        llens = np.full(B, T, np.int32); tlens = np.full(B, U, np.int32)
+    else:
+        llens = np.concatenate([[T], rng.integers(1, T + 1, size=B - 1)]).astype(np.int32)
+        tlens = rng.integers(0, U + 1, size=B).astype(np.int32)
+        tlens[rng.integers(0, B)] = U
+    return logits, targets, llens, tlens
+
+
+def check(logits, targets, llens, tlens, blank=0, clamp=-1.0):
+    costs, grad = run_hip(logits, targets, llens, tlens, blank=blank, clamp=clamp)
+    oc, og = oracle.rnnt_loss_f64(logits, targets, llens, tlens, blank=blank, clamp=clamp)
+    np.testing.assert_allclose(costs, oc, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(grad, og, rtol=1e-4, atol=1e-5)
+    for b in range(logits.shape[0]):                      # padding is exactly zero
+        assert not grad[b, llens[b]:].any()
+        assert not grad[b, :, tlens[b] + 1:].any()
+    return costs, grad
+
+
+def test_public_known_answer():
+    costs, grad = run_hip(KAT_LOGITS, np.array([[1, 2]]), [2], [2])
+    assert abs(costs[0] - KAT_COST) < 1e-5
+    np.testing.assert_allclose(grad, KAT_GRAD, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,T,U,V", [
+    (1, 1, 0, 2),          # single cell
+    (2, 5, 0, 7),          # no labels: blank-only path
+    (3, 7, 3, 5),          # V < 4: scalar head/tail only
+    (4, 20, 9, 33),        # V % 4 != 0: every row has a different 16-B phase
+    (3, 33, 17, 128),
+    (2, 70, 64, 40),       # U1 = 65 -> K = 2 label columns per lane
+    (2, 40, 150, 36),      # U1 = 151 -> K = 3 (the BASELINE shape's width)
+    (2, 12, 200, 20),      # K = 4
+    (1, 9, 300, 12),       # K = 5
+    (1, 6, 511, 8),        # K = 8, the supported maximum
+    (5, 130, 30, 64),      # more steps than the prefetch ring several times over
+])
+def test_parity_ragged(B, T, U, V):
+    rng = np.random.default_rng(B * 1000 + T * 10 + U + V)
+    check(*make_case(rng, B, T, U, V))
+
+
+def test_parity_full_lengths_and_blank_nonzero():
+    rng = np.random.default_rng(5)
+    logits, targets, llens, tlens = make_case(rng, 3, 25, 11, 48, full=True)
+    check(logits, targets, llens, tlens)
+    blank = 47
+    targets = rng.integers(0, 47, size=targets.shape).astype(np.int32)
+    check(logits, targets, llens, tlens, blank=blank)
+    # blank=-1 means "last class" (torchaudio convention)
+    c1, _ = run_hip(logits, targets, llens, tlens, blank=-1)
+    c2, _ = run_hip(logits, targets, llens, tlens, blank=47)
+    np.testing.assert_array_equal(c1, c2)
+
+
+def test_label_equal_to_blank_follows_case_chain():
+    rng = np.random.default_rng(6)
+    logits, targets, llens, tlens = make_case(rng, 2, 9, 5, 16, full=True)
+    targets[0, 2] = 0
+    targets[1, 4] = 0
+    check(logits, targets, llens, tlens)
+
+
+def test_clamp_and_large_logits():
+    rng = np.random.default_rng(8)
+    logits, targets, llens, tlens = make_case(rng, 2, 14, 6, 32, scale=6.0)
+    check(logits, targets, llens, tlens, clamp=0.05)
+    check(logits + 80.0, targets, llens, tlens)          # max-subtraction must hold
+    check(logits - 80.0, targets, llens, tlens)
+
+
+def test_reductions_and_grad_scaling():
+    rng = np.random.default_rng(9)
+    logits, targets, llens, tlens = make_case(rng, 4, 11, 5, 24)
+    oc, og = oracle.rnnt_loss_f64(logits, targets, llens, tlens)
+    for red, scale in (("mean", 1.0 / 4), ("sum", 1.0)):
+        loss, grad = run_hip(logits, targets, llens, tlens, reduction=red)
+        np.testing.assert_allclose(loss, oc.sum() * scale, rtol=1e-5)
+        np.testing.assert_allclose(grad, og * scale, rtol=1e-4, atol=1e-6)
+    go = np.array([0.5, -2.0, 0.0, 3.0], np.float32)
+    _, grad = run_hip(logits, targets, llens, tlens, grad_out=go)
+    np.testing.assert_allclose(grad, og * go[:, None, None, None], rtol=1e-4, atol=1e-5)
+
+
+def test_inplace_gradient_matches():
+    rng = np.random.default_rng(10)
+    logits, targets, llens, tlens = make_case(rng, 3, 17, 8, 40)
+    c0, g0 = run_hip(logits, targets, llens, tlens)
+    c1, g1 = run_hip(logits, targets, llens, tlens, inplace=True)
+    np.testing.assert_array_equal(c0, c1)
+    np.testing.assert_array_equal(g0, g1)
+
+
+def test_lattice_alpha_beta_match_oracle_recursion():
+    from wenet_celoss_amd.rnnt_loss import rnnt_lattice
+    rng = np.random.default_rng(12)
+    logits, targets, llens, tlens = make_case(rng, 3, 30, 70, 20)
+    x = torch.tensor(logits, device=DEV)
+    costs, alpha, beta = rnnt_lattice(x, torch.tensor(targets, device=DEV), torch.tensor(llens, device=DEV),
+                                      torch.tensor(tlens, device=DEV))
+    alpha, beta = alpha.cpu().numpy(), beta.cpu().numpy()
+    lp = torch.log_softmax(torch.tensor(logits, dtype=torch.float64), -1).numpy()
+    for b in range(3):
+        T, U = llens[b], tlens[b]
+        a = np.full((T, U + 1), -np.inf); a[0, 0] = 0
+        for t in range(T):
+            for u in range(U + 1):
+                if t: a[t, u] = np.logaddexp(a[t, u], a[t - 1, u] + lp[b, t - 1, u, 0])
+                if u: a[t, u] = np.logaddexp(a[t, u], a[t, u - 1] + lp[b, t, u - 1, targets[b, u - 1]])
+        np.testing.assert_allclose(alpha[b, :T, :U + 1], a, rtol=1e-5, atol=1e-4)
+        # cost from the forward variable agrees with the kernel's (beta-side) cost
+        assert abs(-(a[T - 1, U] + lp[b, T - 1, U, 0]) - costs[b].item()) < 1e-4 * max(1, abs(costs[b].item()))
+        assert abs(beta[b, 0, 0] + costs[b].item()) < 1e-6
+
+
+def test_argument_checks_raise_like_torchaudio():
+    import wenet_celoss_amd as w
+    x = torch.zeros(2, 4, 3, 8, device=DEV)
+    y = torch.ones(2, 2, dtype=torch.int32, device=DEV)
+    ll = torch.tensor([4, 3], dtype=torch.int32, device=DEV)
+    tl = torch.tensor([2, 1], dtype=torch.int32, device=DEV)
+    w.rnnt_loss(x, y, ll, tl, blank=0)
+    with pytest.raises(RuntimeError, match="int32"):
+        w.rnnt_loss(x, y.long(), ll, tl, blank=0)
+    with pytest.raises(RuntimeError, match="input length mismatch"):
+        w.rnnt_loss(x, y, torch.tensor([3, 3], dtype=torch.int32, device=DEV), tl, blank=0)
+    with pytest.raises(RuntimeError, match="output length mismatch"):
+        w.rnnt_loss(x, y, ll, torch.tensor([1, 1], dtype=torch.int32, device=DEV), blank=0)
+    with pytest.raises(RuntimeError, match="blank"):
+        w.rnnt_loss(x, y, ll, tl, blank=8)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        w.rnnt_loss(x.transpose(1, 2).contiguous().transpose(1, 2), y, ll, tl, blank=0)
+    with pytest.raises(ValueError):
+        w.rnnt_loss(x, y, ll, tl, blank=0, reduction="avg")
+
+
+def test_medium_shape_properties():
+    """Size-independent properties at a shape too large for the f64 oracle to be quick:
+    every gradient row sums to zero (occupancy in = occupancy out), padding is zero,
+    and the threaded f32 port agrees."""
+    import wenet_celoss_amd as w
+    torch.manual_seed(3)
+    B, T, U, V = 4, 200, 40, 1000
+    x = torch.randn(B, T, U + 1, V, device=DEV, requires_grad=True)
+    y = torch.randint(1, V, (B, U), dtype=torch.int32, device=DEV)
+    ll = torch.tensor([200, 180, 77, 150], dtype=torch.int32, device=DEV)
+    tl = torch.tensor([40, 12, 40, 33], dtype=torch.int32, device=DEV)
+    costs = w.rnnt_loss(x, y, ll, tl, blank=0, reduction="none")
+    costs.sum().backward()
+    g = x.grad
+    assert g.sum(-1).abs().max().item() < 2e-5
+    c32, g32 = oracle.rnnt_loss_f32(x.detach().cpu().numpy(), y.cpu().numpy(), ll.cpu().numpy(), tl.cpu().numpy())
+    np.testing.assert_allclose(costs.detach().cpu().numpy(), c32, rtol=2e-5)
+    np.testing.assert_allclose(g.cpu().numpy(), g32, rtol=1e-3, atol=2e-5)

@@ -1,0 +1,11 @@
+"""MI355X-native CTC / RNN-T loss and transducer decode for WeNet.
+
+Host side: thin PyTorch shims that mirror the reference's call sites
+(wenet/transducer/transducer.py, wenet/transformer/ctc.py, wenet/transducer/
+joint.py, wenet/transducer/search/*.py) and forward device pointers to
+libwr_mi355x.so (include/wr_api.h).  There is no CPU fallback.
+"""
+from . import _lib  # noqa: F401
+from .rnnt_loss import rnnt_loss, RNNTLoss  # noqa: F401
+
+__all__ = ["rnnt_loss", "RNNTLoss"]

@@ -1,0 +1,148 @@
+"""Loader for libwr_mi355x.so -- the C-ABI HIP library (include/wr_api.h).
+
+There is NO fallback: if the library cannot be built or loaded, every entry
+point of this package raises.  The host side only moves pointers; PyTorch is
+used for device memory, streams and torch.distributed.
+"""
+from __future__ import annotations
+
+import ctypes
+import glob
+import hashlib
+import os
+import subprocess
+import threading
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+_CSRC = os.path.join(_PKG, "csrc")
+_INCLUDE = os.path.join(_ROOT, "include")
+LIB_NAME = "libwr_mi355x.so"
+LIB_PATH = os.path.join(_PKG, LIB_NAME)
+_HASH_PATH = LIB_PATH + ".srchash"
+
+WR_F32, WR_F16, WR_BF16 = 0, 1, 2
+
+_lock = threading.Lock()
+_lib = None
+
+
+def _sources():
+    return sorted(glob.glob(os.path.join(_CSRC, "*.hip")) + glob.glob(os.path.join(_CSRC, "*.cpp")))
+
+
+def _source_hash() -> str:
+    h = hashlib.sha1()
+    files = _sources() + sorted(glob.glob(os.path.join(_CSRC, "*.hpp"))) + sorted(glob.glob(os.path.join(_INCLUDE, "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH) or not os.path.exists(_HASH_PATH):
+        return True
+    with open(_HASH_PATH) as f:
+        return f.read().strip() != _source_hash()
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into wenet-celoss_amd/libwr_mi355x.so
+    (hipcc cross-compiles without a GPU)."""
+    if not force and not is_stale():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    build_dir = os.path.join(_PKG, "build")
+    os.makedirs(build_dir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + _INCLUDE, "-I" + _CSRC,
+             "-Wall", "-Wno-unused-function"]
+    procs = []
+    for src in _sources():
+        obj = os.path.join(build_dir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        procs.append((src, subprocess.Popen([hipcc] + flags + ["-c", src, "-o", obj],
+                                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        if verbose and out.strip():
+            print(out)
+    tmp = LIB_PATH + ".tmp"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs,
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc link failed:\n" + r.stdout + r.stderr)
+    os.replace(tmp, LIB_PATH)
+    with open(_HASH_PATH, "w") as f:
+        f.write(_source_hash())
+    return LIB_PATH
+
+
+# name -> (restype, argtypes); must list every symbol include/wr_api.h declares.
+_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+SIGNATURES = {
+    "wr_api_version": (_i, []),
+    "wr_last_error": (ctypes.c_char_p, []),
+    "wr_rnnt_workspace_bytes": (_sz, [_i, _i, _i]),
+    "wr_rnnt_loss_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "wr_rnnt_loss_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    "wr_rnnt_export_lattice": (_i, [_vp, _sz, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+}
+
+
+def load():
+    """Return the loaded library (building it first if the sources changed)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        import torch  # noqa: F401  -- makes torch's HIP runtime the one resident in the process
+        try:
+            path = build()
+        except Exception as e:  # no silent fallback
+            raise RuntimeError(f"wenet_celoss_amd: cannot build {LIB_NAME}: {e}") from e
+        try:
+            lib = ctypes.CDLL(path)
+        except OSError as e:
+            raise RuntimeError(f"wenet_celoss_amd: cannot load {path}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.wr_api_version() != 1:
+            raise RuntimeError("wenet_celoss_amd: libwr_mi355x.so API version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().wr_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what or 'libwr_mi355x'} failed ({rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream(device=None):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def dtype_code(dt) -> int:
+    import torch
+    if dt == torch.float32:
+        return WR_F32
+    if dt == torch.float16:
+        return WR_F16
+    if dt == torch.bfloat16:
+        return WR_BF16
+    raise RuntimeError(f"unsupported dtype {dt}")

@@ -1,0 +1,528 @@
+// RNN-T loss + gradient for MI355X (gfx950), replacing the
+// torchaudio.functional.rnnt_loss call sites of the reference
+// (wenet/transducer/transducer.py:142-147 and :296-301).  See include/wr_api.h.
+//
+// Three device passes over a batch of variable-length utterances packed into
+// one grid (mathematics: SURVEY.md App. A.1):
+//
+//   pass 1  rnnt_lse_kernel    one wave per lattice cell (b,t,u): streams the
+//           V logits of the cell once (16-B loads, online max/sum), writes
+//           denom(t,u) and the two log-probs the lattice needs
+//           (skip = blank, emit = label) into a *diagonal-skewed* array.
+//           HBM-bound: 4*V bytes read per cell.
+//   pass 2  rnnt_sweep_kernel  one wave per (utterance, direction).  Lane l owns
+//           K = ceil(U1max/64) adjacent label columns; at step s it works on
+//           frame t = s - l, so the cross-lane dependency alpha(t,u-1) /
+//           beta(t,u+1) is exactly the neighbour lane's value from the
+//           previous step: one DPP wave shift, no LDS, no barrier.  Because
+//           pass 1 stored log-probs skewed by the same rule, step s reads one
+//           contiguous row.  Latency-bound (T + 63 dependent steps), ~0.1 ms.
+//   pass 3  rnnt_grad_kernel   one wave per cell again: re-reads the V logits,
+//           writes grad = g_b * (exp(logit + alpha + beta + cost - denom) with
+//           the blank / label corrections), zero in the padded region.
+//           HBM-bound: 4*V read + 4*V written per cell.
+//
+// Algorithmic traffic: 3 * 4 * V bytes per valid cell (+ 4*V per padded cell).
+#include "wr_common.hpp"
+
+namespace wr {
+namespace {
+
+struct RnntWs {
+    int K;            // label columns per lane in the sweep
+    int S;            // number of skewed diagonals per utterance
+    size_t lp_off, alpha_off, beta_off, denom_off, ll_off, cost_off, total;
+};
+
+__host__ __device__ inline int rnnt_cols_per_lane(int U1max) { return (U1max + kWave - 1) / kWave; }
+
+inline RnntWs rnnt_ws_layout(int B, int Tmax, int U1max)
+{
+    RnntWs w;
+    w.K = rnnt_cols_per_lane(U1max);
+    w.S = Tmax + (U1max - 1) / w.K;
+    const size_t diag = (size_t)B * w.S * U1max;
+    size_t off = 0;
+    w.lp_off = off;    off = align_up(off + diag * sizeof(float2), 256);
+    w.alpha_off = off; off = align_up(off + diag * sizeof(float), 256);
+    w.beta_off = off;  off = align_up(off + diag * sizeof(float), 256);
+    w.denom_off = off; off = align_up(off + (size_t)B * Tmax * U1max * sizeof(float), 256);
+    w.ll_off = off;    off = align_up(off + (size_t)B * sizeof(float), 256);
+    w.cost_off = off;  off = align_up(off + (size_t)B * sizeof(float), 256);
+    w.total = off;
+    return w;
+}
+
+// ------------------------------------------------------------------ pass 1 --
+// Per-lane online (max, sum) in the log2 domain over one row of V floats.
+struct RowStat {
+    float m;   // running max of x*log2e
+    float s;   // running sum of 2^(x*log2e - m)
+};
+
+__device__ __forceinline__ void stat_add4(RowStat &st, const f32x4 v)
+{
+    const float y0 = v.x * kLog2e, y1 = v.y * kLog2e, y2 = v.z * kLog2e, y3 = v.w * kLog2e;
+    const float cm = fmaxf(fmaxf(y0, y1), fmaxf(y2, y3));
+    const float nm = fmaxf(st.m, cm);
+    st.s = st.s * fast_exp2(st.m - nm) + (fast_exp2(y0 - nm) + fast_exp2(y1 - nm)) +
+           (fast_exp2(y2 - nm) + fast_exp2(y3 - nm));
+    st.m = nm;
+}
+
+__device__ __forceinline__ void stat_add1(RowStat &st, const float x)
+{
+    const float y = x * kLog2e;
+    const float nm = fmaxf(st.m, y);
+    st.s = st.s * fast_exp2(st.m - nm) + fast_exp2(y - nm);
+    st.m = nm;
+}
+
+// Natural-log log-sum-exp of row[0..V) computed by one wave.
+__device__ __forceinline__ float wave_row_lse(const float *__restrict__ row, int V, int lane)
+{
+    RowStat st{-3.0e38f, 0.f};
+    // 16-byte aligned body with scalar head/tail so that any V and any base work.
+    const int head = (int)((4 - ((reinterpret_cast<uintptr_t>(row) >> 2) & 3)) & 3);
+    const int h = head < V ? head : V;
+    const int n4 = (V - h) >> 2;
+    const int tail = V - h - 4 * n4;
+    if (lane < h) stat_add1(st, row[lane]);
+    if (lane < tail) stat_add1(st, row[h + 4 * n4 + lane]);
+    const f32x4 *__restrict__ body = reinterpret_cast<const f32x4 *>(row + h);
+    int i = lane;
+    for (; i + 3 * kWave < n4; i += 4 * kWave) {
+        const f32x4 a = __builtin_nontemporal_load(body + i);
+        const f32x4 b = __builtin_nontemporal_load(body + i + kWave);
+        const f32x4 c = __builtin_nontemporal_load(body + i + 2 * kWave);
+        const f32x4 d = __builtin_nontemporal_load(body + i + 3 * kWave);
+        stat_add4(st, a); stat_add4(st, b); stat_add4(st, c); stat_add4(st, d);
+    }
+    for (; i < n4; i += kWave) stat_add4(st, __builtin_nontemporal_load(body + i));
+    const float M = wave_max(st.m);
+    const float s = wave_sum(st.s * fast_exp2(st.m - M));
+    return (M + fast_log2(s)) * kLn2;
+}
+
+__global__ __launch_bounds__(256) void rnnt_lse_kernel(
+    const float *__restrict__ logits, const int32_t *__restrict__ targets,
+    const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens,
+    int B, int Tmax, int U1max, int V, int blank, int K, int S,
+    float2 *__restrict__ lp_skew, float *__restrict__ denom)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int waves_per_block = blockDim.x >> 6;
+    const long nrows = (long)B * Tmax * U1max;
+    const long stride = (long)gridDim.x * waves_per_block;
+    const int cells = Tmax * U1max;
+    for (long r = (long)blockIdx.x * waves_per_block + wid; r < nrows; r += stride) {
+        const int b = (int)(r / cells);
+        const int c = (int)(r - (long)b * cells);
+        const int t = c / U1max;
+        const int u = c - t * U1max;
+        const int T = llens[b], U = tlens[b];
+        if (t >= T || u > U) continue;
+        const float *row = logits + (size_t)r * V;
+        const float d = wave_row_lse(row, V, lane);
+        if (lane == 0) {
+            const float xb = row[blank];
+            float em = 0.f;
+            if (u < U) {
+                const int lab = targets[(size_t)b * (U1max - 1) + u];
+                em = row[lab] - d;
+            }
+            denom[r] = d;
+            const int s = t + u / K;
+            lp_skew[((size_t)b * S + s) * U1max + u] = make_float2(xb - d, em);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ pass 2 --
+// One wave per (utterance, direction).  K label columns per lane.
+template <int K, int PF>
+__global__ __launch_bounds__(64) void rnnt_sweep_kernel(
+    const float2 *__restrict__ lp_skew, const int32_t *__restrict__ llens,
+    const int32_t *__restrict__ tlens, int Tmax, int U1max, int S,
+    float *__restrict__ alpha_skew, float *__restrict__ beta_skew,
+    float *__restrict__ ll_out, float *__restrict__ cost_ws, float *__restrict__ costs_out)
+{
+    const int b = blockIdx.x;
+    const bool backward = blockIdx.y != 0;
+    const int lane = threadIdx.x;
+    int T = llens[b], U = tlens[b];
+    T = T < 0 ? 0 : (T > Tmax ? Tmax : T);
+    U = U < 0 ? 0 : (U > U1max - 1 ? U1max - 1 : U);
+    const float2 *__restrict__ lp = lp_skew + (size_t)b * S * U1max;
+    float *__restrict__ out = (backward ? beta_skew : alpha_skew) + (size_t)b * S * U1max;
+    const int u0 = lane * K;
+    const int nsteps = (T > 0) ? T + U / K : 0;   // diagonals that hold a valid cell
+
+    if (nsteps == 0) {
+        if (lane == 0) {
+            if (backward) { cost_ws[b] = 0.f; costs_out[b] = 0.f; } else ll_out[b] = 0.f;
+        }
+        return;
+    }
+
+    auto load_row = [&](int s, float2 (&dst)[K]) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int u = u0 + j;
+            const int t = s - lane;
+            const bool ok = (s >= 0) & (s < nsteps) & (t >= 0) & (t < T) & (u <= U);
+            dst[j] = ok ? lp[(size_t)s * U1max + u] : make_float2(0.f, 0.f);
+        }
+    };
+
+    float2 ring[PF][K];
+    float st[K];      // alpha(t-1, u_j)  /  beta(t+1, u_j)
+    float skp[K];     // forward only: skip(t-1, u_j)
+#pragma unroll
+    for (int j = 0; j < K; ++j) { st[j] = kNegInf; skp[j] = 0.f; }
+    float send = kNegInf;
+
+    if (!backward) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) load_row(i, ring[i]);
+        for (int base = 0; base < nsteps; base += PF) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int s = base + i;
+                float2 cur[K];
+#pragma unroll
+                for (int j = 0; j < K; ++j) cur[j] = ring[i][j];
+                load_row(s + PF, ring[i]);
+                if (s < nsteps) {
+                    const int t = s - lane;
+                    const bool active = (t >= 0) & (t < T);
+                    const float left_in = lane_shift_up(send, kNegInf);
+                    float nw[K];
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        const int u = u0 + j;
+                        const float top = (t >= 1) ? st[j] + skp[j] : kNegInf;
+                        float left = (j == 0) ? left_in : nw[j > 0 ? j - 1 : 0] + cur[j > 0 ? j - 1 : 0].y;
+                        left = (u >= 1) ? left : kNegInf;
+                        float v = log_add_exp(top, left);
+                        v = (t == 0 && u == 0) ? 0.f : v;
+                        v = (active && u <= U) ? v : kNegInf;
+                        nw[j] = v;
+                    }
+                    send = nw[K - 1] + cur[K - 1].y;
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        const int u = u0 + j;
+                        if (active && u <= U) {
+                            out[(size_t)s * U1max + u] = nw[j];
+                            if (t == T - 1 && u == U) ll_out[b] = nw[j] + cur[j].x;
+                        }
+                        st[j] = nw[j];
+                        skp[j] = cur[j].x;
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) load_row(nsteps - 1 - i, ring[i]);
+        for (int base = 0; base < nsteps; base += PF) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int s = nsteps - 1 - (base + i);
+                float2 cur[K];
+#pragma unroll
+                for (int j = 0; j < K; ++j) cur[j] = ring[i][j];
+                load_row(s - PF, ring[i]);
+                if (s >= 0) {
+                    const int t = s - lane;
+                    const bool active = (t >= 0) & (t < T);
+                    const float right_in = lane_shift_down(send, kNegInf);
+                    float nw[K];
+#pragma unroll
+                    for (int j = K - 1; j >= 0; --j) {
+                        const int u = u0 + j;
+                        const float down = (t < T - 1) ? st[j] + cur[j].x : kNegInf;
+                        float right = (j == K - 1) ? right_in : nw[j < K - 1 ? j + 1 : K - 1];
+                        right = (u < U) ? right + cur[j].y : kNegInf;
+                        float v = log_add_exp(down, right);
+                        v = (t == T - 1 && u == U) ? cur[j].x : v;
+                        v = (active && u <= U) ? v : kNegInf;
+                        nw[j] = v;
+                    }
+                    send = nw[0];
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        const int u = u0 + j;
+                        if (active && u <= U) {
+                            out[(size_t)s * U1max + u] = nw[j];
+                            if (t == 0 && u == 0) { cost_ws[b] = -nw[j]; costs_out[b] = -nw[j]; }
+                        }
+                        st[j] = nw[j];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ pass 3 --
+__global__ __launch_bounds__(256) void rnnt_grad_kernel(
+    const float *logits, const int32_t *__restrict__ targets,
+    const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens,
+    int B, int Tmax, int U1max, int V, int blank, float clamp, int K, int S,
+    const float *__restrict__ alpha_skew, const float *__restrict__ beta_skew,
+    const float *__restrict__ denom, const float *__restrict__ cost_ws,
+    const float *__restrict__ grad_costs, float *grads)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int waves_per_block = blockDim.x >> 6;
+    const long nrows = (long)B * Tmax * U1max;
+    const long stride = (long)gridDim.x * waves_per_block;
+    const int cells = Tmax * U1max;
+    for (long r = (long)blockIdx.x * waves_per_block + wid; r < nrows; r += stride) {
+        const int b = (int)(r / cells);
+        const int c = (int)(r - (long)b * cells);
+        const int t = c / U1max;
+        const int u = c - t * U1max;
+        const int T = llens[b], U = tlens[b];
+        const float *row = logits + (size_t)r * V;
+        float *grow = grads + (size_t)r * V;
+
+        const int head = (int)((4 - ((reinterpret_cast<uintptr_t>(row) >> 2) & 3)) & 3);
+        const int h = head < V ? head : V;
+        const int n4 = (V - h) >> 2;
+        const int tail = V - h - 4 * n4;
+        const f32x4 *body = reinterpret_cast<const f32x4 *>(row + h);
+        f32x4 *gbody = reinterpret_cast<f32x4 *>(grow + h);
+
+        if (t >= T || u > U) {          // padded cell: gradient is exactly zero
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            if (lane < h) grow[lane] = 0.f;
+            if (lane < tail) grow[h + 4 * n4 + lane] = 0.f;
+            for (int i = lane; i < n4; i += kWave) __builtin_nontemporal_store(z, gbody + i);
+            continue;
+        }
+
+        const size_t dbase = (size_t)b * S * U1max;
+        const int s = t + u / K;
+        const float al = alpha_skew[dbase + (size_t)s * U1max + u];
+        const float be = beta_skew[dbase + (size_t)s * U1max + u];
+        const float cost = cost_ws[b];
+        const float go = grad_costs ? grad_costs[b] : 1.f;
+        const float cm = al + cost - denom[r];      // g = logit + cm
+        const float c2 = (cm + be) * kLog2e;
+
+        // special entries (SURVEY.md App. A.1 case chain; first match wins)
+        bool blank_special = false;
+        float blank_sub = 0.f;                      // exponent (natural log) of the subtracted term, minus logit
+        if (t == T - 1 && u == U) { blank_special = true; blank_sub = cm; }
+        else if (t < T - 1) {
+            blank_special = true;
+            blank_sub = cm + beta_skew[dbase + (size_t)(s + 1) * U1max + u];
+        }
+        int lab = -1;
+        float lab_sub = 0.f;
+        if (u < U) {
+            lab = targets[(size_t)b * (U1max - 1) + u];
+            if (lab == blank && blank_special) lab = -1;
+            else lab_sub = cm + beta_skew[dbase + (size_t)(t + (u + 1) / K) * U1max + (u + 1)];
+        }
+        const int blk = blank_special ? blank : -1;
+
+        auto fix = [&](float val, float x, int v) -> float {
+            // val = exp(x + cm + be) already; subtract the case-chain term.
+            if (v == blk) val -= fast_exp2((x + blank_sub) * kLog2e);
+            else if (v == lab) val -= fast_exp2((x + lab_sub) * kLog2e);
+            return val;
+        };
+        auto finish = [&](float val) -> float {
+            if (clamp > 0.f) val = fminf(fmaxf(val, -clamp), clamp);
+            return val * go;
+        };
+
+        if (lane < h) {
+            const float x = row[lane];
+            grow[lane] = finish(fix(fast_exp2(fmaf(x, kLog2e, c2)), x, lane));
+        }
+        if (lane < tail) {
+            const int v = h + 4 * n4 + lane;
+            const float x = row[v];
+            grow[v] = finish(fix(fast_exp2(fmaf(x, kLog2e, c2)), x, v));
+        }
+        // body index i covers elements v = h + 4*i .. h + 4*i + 3
+        const int iblk = (blk >= h) ? ((blk - h) >> 2) : -1;
+        const int ilab = (lab >= h) ? ((lab - h) >> 2) : -1;
+        auto do4 = [&](int i, const f32x4 x) {
+            f32x4 g;
+            g.x = fast_exp2(fmaf(x.x, kLog2e, c2));
+            g.y = fast_exp2(fmaf(x.y, kLog2e, c2));
+            g.z = fast_exp2(fmaf(x.z, kLog2e, c2));
+            g.w = fast_exp2(fmaf(x.w, kLog2e, c2));
+            if (i == iblk || i == ilab) {
+                const int v0 = h + 4 * i;
+                g.x = fix(g.x, x.x, v0);
+                g.y = fix(g.y, x.y, v0 + 1);
+                g.z = fix(g.z, x.z, v0 + 2);
+                g.w = fix(g.w, x.w, v0 + 3);
+            }
+            g.x = finish(g.x); g.y = finish(g.y); g.z = finish(g.z); g.w = finish(g.w);
+            __builtin_nontemporal_store(g, gbody + i);
+        };
+        int i = lane;
+        for (; i + 3 * kWave < n4; i += 4 * kWave) {
+            const f32x4 a = __builtin_nontemporal_load(body + i);
+            const f32x4 bq = __builtin_nontemporal_load(body + i + kWave);
+            const f32x4 cq = __builtin_nontemporal_load(body + i + 2 * kWave);
+            const f32x4 dq = __builtin_nontemporal_load(body + i + 3 * kWave);
+            do4(i, a); do4(i + kWave, bq); do4(i + 2 * kWave, cq); do4(i + 3 * kWave, dq);
+        }
+        for (; i < n4; i += kWave) do4(i, __builtin_nontemporal_load(body + i));
+    }
+}
+
+// ----------------------------------------------------- diagnostics export --
+__global__ void rnnt_export_kernel(const float *__restrict__ alpha_skew, const float *__restrict__ beta_skew,
+                                   const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens,
+                                   int B, int Tmax, int U1max, int K, int S,
+                                   float *__restrict__ alpha, float *__restrict__ beta)
+{
+    const long n = (long)B * Tmax * U1max;
+    for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long)gridDim.x * blockDim.x) {
+        const int cells = Tmax * U1max;
+        const int b = (int)(r / cells);
+        const int c = (int)(r - (long)b * cells);
+        const int t = c / U1max, u = c - t * U1max;
+        float a = 0.f, be = 0.f;
+        if (t < llens[b] && u <= tlens[b]) {
+            const size_t k = ((size_t)b * S + t + u / K) * U1max + u;
+            a = alpha_skew[k];
+            be = beta_skew[k];
+        }
+        alpha[r] = a;
+        beta[r] = be;
+    }
+}
+
+int check_shape(int B, int Tmax, int U1max, int V, int blank)
+{
+    WR_REQUIRE(B > 0 && Tmax > 0 && U1max > 0 && V > 0, WR_EINVAL,
+               "rnnt: B, Tmax, U1max, V must be positive (got %d,%d,%d,%d)", B, Tmax, U1max, V);
+    WR_REQUIRE(blank >= 0 && blank < V, WR_EINVAL, "rnnt: blank %d out of range [0,%d)", blank, V);
+    WR_REQUIRE(rnnt_cols_per_lane(U1max) <= 8, WR_EUNSUPPORTED,
+               "rnnt: U1max=%d exceeds the sweep kernel's limit of 512 label columns", U1max);
+    WR_REQUIRE((long)B * Tmax * U1max < (1L << 31), WR_EUNSUPPORTED, "rnnt: more than 2^31 lattice cells");
+    return WR_OK;
+}
+
+int stream_grid(long nrows)
+{
+    // HBM-streaming grid: enough 4-wave blocks to fill 256 CUs at 8 blocks/CU, grid-stride beyond.
+    long blocks = (nrows + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+template <int K>
+void launch_sweep(const RnntWs &w, char *ws, const int32_t *llens, const int32_t *tlens, int B, int Tmax,
+                  int U1max, float *costs, hipStream_t st)
+{
+    constexpr int PF = (K <= 2) ? 8 : (K <= 4 ? 6 : 4);
+    hipLaunchKernelGGL((rnnt_sweep_kernel<K, PF>), dim3(B, 2), dim3(64), 0, st,
+                       reinterpret_cast<const float2 *>(ws + w.lp_off), llens, tlens, Tmax, U1max, w.S,
+                       reinterpret_cast<float *>(ws + w.alpha_off), reinterpret_cast<float *>(ws + w.beta_off),
+                       reinterpret_cast<float *>(ws + w.ll_off), reinterpret_cast<float *>(ws + w.cost_off), costs);
+}
+
+}  // namespace
+}  // namespace wr
+
+using namespace wr;
+
+extern "C" size_t wr_rnnt_workspace_bytes(int B, int Tmax, int U1max)
+{
+    if (B <= 0 || Tmax <= 0 || U1max <= 0) return 0;
+    return rnnt_ws_layout(B, Tmax, U1max).total;
+}
+
+extern "C" int wr_rnnt_loss_fwd(const void *logits_d, int dtype, const int32_t *targets_d,
+                                const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B, int Tmax,
+                                int U1max, int V, int blank, float *costs_d, void *workspace_d,
+                                size_t workspace_bytes, void *stream)
+{
+    if (int rc = check_shape(B, Tmax, U1max, V, blank)) return rc;
+    WR_REQUIRE(logits_d && logit_lengths_d && target_lengths_d && costs_d && workspace_d, WR_EINVAL,
+               "rnnt_loss_fwd: null pointer argument");
+    WR_REQUIRE(targets_d || U1max == 1, WR_EINVAL, "rnnt_loss_fwd: targets is null");
+    WR_REQUIRE(dtype == WR_F32, WR_EUNSUPPORTED, "rnnt_loss_fwd: dtype %d not supported yet (fp32 only)", dtype);
+    const RnntWs w = rnnt_ws_layout(B, Tmax, U1max);
+    WR_REQUIRE(workspace_bytes >= w.total, WR_EWORKSPACE, "rnnt_loss_fwd: workspace %zu < required %zu",
+               workspace_bytes, w.total);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char *ws = static_cast<char *>(workspace_d);
+    const long nrows = (long)B * Tmax * U1max;
+    hipLaunchKernelGGL(rnnt_lse_kernel, dim3(stream_grid(nrows)), dim3(256), 0, st,
+                       static_cast<const float *>(logits_d), targets_d, logit_lengths_d, target_lengths_d, B, Tmax,
+                       U1max, V, blank, w.K, w.S, reinterpret_cast<float2 *>(ws + w.lp_off),
+                       reinterpret_cast<float *>(ws + w.denom_off));
+    WR_CHECK_LAUNCH("rnnt_lse_kernel");
+    switch (w.K) {
+        case 1: launch_sweep<1>(w, ws, logit_lengths_d, target_lengths_d, B, Tmax, U1max, costs_d, st); break;
+        case 2: launch_sweep<2>(w, ws, logit_lengths_d, target_lengths_d, B, Tmax, U1max, costs_d, st); break;
+        case 3: launch_sweep<3>(w, ws, logit_lengths_d, target_lengths_d, B, Tmax, U1max, costs_d, st); break;
+        case 4: launch_sweep<4>(w, ws, logit_lengths_d, target_lengths_d, B, Tmax, U1max, costs_d, st); break;
+        case 5: launch_sweep<5>(w, ws, logit_lengths_d, target_lengths_d, B, Tmax, U1max, costs_d, st); break;
+        case 6: launch_sweep<6>(w, ws, logit_lengths_d, target_lengths_d, B, Tmax, U1max, costs_d, st); break;
+        case 7: launch_sweep<7>(w, ws, logit_lengths_d, target_lengths_d, B, Tmax, U1max, costs_d, st); break;
+        default: launch_sweep<8>(w, ws, logit_lengths_d, target_lengths_d, B, Tmax, U1max, costs_d, st); break;
+    }
+    WR_CHECK_LAUNCH("rnnt_sweep_kernel");
+    return WR_OK;
+}
+
+extern "C" int wr_rnnt_loss_bwd(const void *logits_d, int dtype, const int32_t *targets_d,
+                                const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B, int Tmax,
+                                int U1max, int V, int blank, float clamp, const float *grad_costs_d, void *grads_d,
+                                const void *workspace_d, size_t workspace_bytes, void *stream)
+{
+    if (int rc = check_shape(B, Tmax, U1max, V, blank)) return rc;
+    WR_REQUIRE(logits_d && logit_lengths_d && target_lengths_d && grads_d && workspace_d, WR_EINVAL,
+               "rnnt_loss_bwd: null pointer argument");
+    WR_REQUIRE(targets_d || U1max == 1, WR_EINVAL, "rnnt_loss_bwd: targets is null");
+    WR_REQUIRE(dtype == WR_F32, WR_EUNSUPPORTED, "rnnt_loss_bwd: dtype %d not supported yet (fp32 only)", dtype);
+    const RnntWs w = rnnt_ws_layout(B, Tmax, U1max);
+    WR_REQUIRE(workspace_bytes >= w.total, WR_EWORKSPACE, "rnnt_loss_bwd: workspace %zu < required %zu",
+               workspace_bytes, w.total);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const char *ws = static_cast<const char *>(workspace_d);
+    const long nrows = (long)B * Tmax * U1max;
+    hipLaunchKernelGGL(rnnt_grad_kernel, dim3(stream_grid(nrows)), dim3(256), 0, st,
+                       static_cast<const float *>(logits_d), targets_d, logit_lengths_d, target_lengths_d, B, Tmax,
+                       U1max, V, blank, clamp, w.K, w.S, reinterpret_cast<const float *>(ws + w.alpha_off),
+                       reinterpret_cast<const float *>(ws + w.beta_off),
+                       reinterpret_cast<const float *>(ws + w.denom_off),
+                       reinterpret_cast<const float *>(ws + w.cost_off), grad_costs_d, static_cast<float *>(grads_d));
+    WR_CHECK_LAUNCH("rnnt_grad_kernel");
+    return WR_OK;
+}
+
+extern "C" int wr_rnnt_export_lattice(const void *workspace_d, size_t workspace_bytes,
+                                      const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B,
+                                      int Tmax, int U1max, float *alpha_d, float *beta_d, void *stream)
+{
+    if (int rc = check_shape(B, Tmax, U1max, 1, 0)) return rc;
+    WR_REQUIRE(workspace_d && alpha_d && beta_d && logit_lengths_d && target_lengths_d, WR_EINVAL,
+               "rnnt_export_lattice: null pointer argument");
+    const RnntWs w = rnnt_ws_layout(B, Tmax, U1max);
+    WR_REQUIRE(workspace_bytes >= w.total, WR_EWORKSPACE, "rnnt_export_lattice: workspace too small");
+    const char *ws = static_cast<const char *>(workspace_d);
+    hipLaunchKernelGGL(rnnt_export_kernel, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float *>(ws + w.alpha_off),
+                       reinterpret_cast<const float *>(ws + w.beta_off), logit_lengths_d, target_lengths_d, B, Tmax,
+                       U1max, w.K, w.S, alpha_d, beta_d);
+    WR_CHECK_LAUNCH("rnnt_export_kernel");
+    return WR_OK;
+}

@@ -1,0 +1,87 @@
+// Shared device/host helpers for libwr_mi355x (gfx950 only; wave = 64 lanes).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "wr_api.h"
+
+namespace wr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kWave = 64;
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr float kNegInf = -__builtin_huge_valf();
+
+// ---- host-side error reporting -------------------------------------------
+void set_error(const char *fmt, ...);
+
+#define WR_REQUIRE(cond, code, ...)          \
+    do {                                     \
+        if (!(cond)) {                       \
+            ::wr::set_error(__VA_ARGS__);    \
+            return (code);                   \
+        }                                    \
+    } while (0)
+
+#define WR_CHECK_LAUNCH(what)                                                       \
+    do {                                                                            \
+        hipError_t e_ = hipGetLastError();                                          \
+        if (e_ != hipSuccess) {                                                     \
+            ::wr::set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e_)); \
+            return WR_ELAUNCH;                                                      \
+        }                                                                           \
+    } while (0)
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- device helpers ---------------------------------------------------------
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+
+// log(exp(a)+exp(b)) in the natural-log domain; -inf safe.
+__device__ __forceinline__ float log_add_exp(float a, float b)
+{
+    const float m = fmaxf(a, b);
+    const float d = -fabsf(a - b);                 // NaN when both are -inf
+    const float r = m + kLn2 * fast_log2(1.0f + fast_exp2(d * kLog2e));
+    return (m == kNegInf) ? kNegInf : r;
+}
+
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+// Shift a value one lane up (lane l receives lane l-1; lane 0 receives `fill`).
+// gfx9 DPP wave_shr:1 -- one VALU op, no LDS crossbar round trip.
+__device__ __forceinline__ float lane_shift_up(float v, float fill)
+{
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v),
+                                           0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+
+// Lane l receives lane l+1; lane 63 receives `fill`.  (DPP wave_shl:1)
+__device__ __forceinline__ float lane_shift_down(float v, float fill)
+{
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v),
+                                           0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+
+}  // namespace wr
