@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py -- RNN-T loss + gradient throughput on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of synthetic joiner
+logits already resident in HBM: wr_rnnt_loss_fwd (row log-sum-exp + alpha/beta
+sweeps -> costs) followed by wr_rnnt_loss_bwd (gradient w.r.t. the logits with
+reduction="mean" folded in), through the C-ABI of libwr_mi355x.so.
+
+Workload at N=1: BASELINE.json configs[1] -- B=32, T=1000, U=150, V=5000, fp32,
+full-length utterances.  N>1: every rank runs the same per-GPU batch on its own
+shard of utterances (weak scaling; the loss has no data-path collective,
+SURVEY.md section 8e); value = utterances of all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     -- for the dominant kernel (rnnt_grad_kernel: 2/3 of the bytes),
+                  algorithmic bytes per launch / its mean duration measured with
+                  HIP events on the launch stream inside the timed region;
+  cpu_baseline -- the threaded fp32 CPU port (oracle/rnnt_baseline.c, "port")
+                  timed on this box's host cores on a bounded sample of the same
+                  (T,U,V) utterances (N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--B", type=int, default=32)
+    ap.add_argument("--T", type=int, default=1000)
+    ap.add_argument("--U", type=int, default=150)
+    ap.add_argument("--V", type=int, default=5000)
+    ap.add_argument("--ragged", action="store_true", help="T_b~U{T/2..T}, U_b~U{U/3..U} (maxima pinned)")
+    ap.add_argument("--inplace", action="store_true", help="write the gradient over the logits storage")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="utterances timed on the CPU (-1: auto, 0: skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time budget for the baseline")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path in the product)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # RCCL; used only for the barrier / max-reduce of timings
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from wenet_celoss_amd import _lib
+    lib = _lib.load()
+
+    B, T, U, V = args.B, args.T, args.U, args.V
+    U1 = U + 1
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(20260 + rank)
+    logits = torch.empty(B, T, U1, V, dtype=torch.float32, device=dev)
+    for b in range(B):                       # per-utterance fill: no 96 GB temporary
+        logits[b].normal_(generator=gen)
+    targets = torch.randint(1, V, (B, U), dtype=torch.int32, device=dev, generator=gen)
+    if args.ragged:
+        cpu_gen = torch.Generator().manual_seed(20260 + rank)
+        tl = torch.randint(T // 2, T + 1, (B,), generator=cpu_gen)
+        ul = torch.randint(max(U // 3, 1), U + 1, (B,), generator=cpu_gen)
+        tl[0], ul[0] = T, U
+        order = torch.argsort(tl, descending=True)      # processor.py:704 sorts by feats length
+        tl, ul = tl[order], ul[order]
+        ul[ul.argmax()] = U
+    else:
+        tl = torch.full((B,), T)
+        ul = torch.full((B,), U)
+    llens = tl.to(torch.int32).to(dev)
+    tlens = ul.to(torch.int32).to(dev)
+    valid_cells = int((tl * (ul + 1)).sum())
+    pad_cells = B * T * U1 - valid_cells
+
+    inplace = args.inplace
+    grads = None
+    if not inplace:
+        try:
+            grads = torch.empty_like(logits)
+        except torch.OutOfMemoryError:
+            inplace = True
+    if inplace:
+        grads = logits
+    ws_bytes = lib.wr_rnnt_workspace_bytes(B, T, U1)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    costs = torch.empty(B, dtype=torch.float32, device=dev)
+    gcosts = torch.full((B,), 1.0 / B, dtype=torch.float32, device=dev)     # reduction="mean"
+    stream = _lib.current_stream(dev)
+    P = _lib.ptr
+
+    def fwd():
+        _lib.check(lib.wr_rnnt_loss_fwd(P(logits), 0, P(targets), P(llens), P(tlens), B, T, U1, V, 0, P(costs),
+                                        P(ws), ws_bytes, stream), "fwd")
+
+    def bwd():
+        _lib.check(lib.wr_rnnt_loss_bwd(P(logits), 0, P(targets), P(llens), P(tlens), B, T, U1, V, 0, -1.0,
+                                        P(gcosts), P(grads), P(ws), ws_bytes, stream), "bwd")
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        fwd(); bwd()
+    torch.cuda.synchronize()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        fwd()
+        ev[k][1].record()
+        bwd()
+        ev[k][2].record()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
+    bwd_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = B * world * args.steps / elapsed
+
+    # algorithmic bytes: 4*V per valid cell per pass; pass 3 also zero-fills padded cells
+    bytes_fwd = 4.0 * V * valid_cells
+    bytes_bwd = 2 * 4.0 * V * valid_cells + 4.0 * V * pad_cells
+    grad_gbs = bytes_bwd / (bwd_ms * 1e-3) / 1e9
+    lse_gbs = bytes_fwd / (fwd_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "utterances/sec RNN-T loss+grad (B=32,T=1000,U=150,V=5000)",
+        "value": round(value, 3),
+        "unit": "utterances/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"rnnt_loss+grad B={B} T={T} U={U} V={V} fp32 "
+                               f"{'ragged' if args.ragged else 'full-length'} logits resident in HBM"
+                               f"{' (gradient written in place)' if inplace else ''}",
+                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world} (utterance shards, no collective)"},
+        "roofline": {"bound": "hbm", "kernel": "rnnt_grad_kernel", "achieved": round(grad_gbs, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(grad_gbs / HBM_PEAK_GBS, 4),
+                     "traffic": None,
+                     "bytes_per_launch": bytes_bwd, "avg_ms": round(bwd_ms, 4),
+                     "other": {"rnnt_lse+sweep": {"achieved": round(lse_gbs, 1), "avg_ms": round(fwd_ms, 4),
+                                                  "bytes_per_launch": bytes_fwd}},
+                     "whole_step_GBps": round((bytes_fwd + bytes_bwd) / (ms_per_step * 1e-3) / 1e9, 1)},
+    }
+
+    if rank == 0 and world == 1 and args.cpu_sample != 0:
+        out["cpu_baseline"] = cpu_baseline(args, logits if not inplace else None, targets, llens, tlens, costs, gen, dev)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def host_cores() -> int:
+    """CPU threads this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]) + 0.5)))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, int(q / int(f.read()) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def cpu_baseline(args, logits, targets, llens, tlens, gpu_costs, gen, dev):
+    """Time the threaded fp32 CPU port on a bounded sample of the same workload."""
+    import numpy as np
+    import oracle
+    B, T, U, V = args.B, args.T, args.U, args.V
+    cores = host_cores()
+    per_utt_gb = T * (U + 1) * V * 4 / 1e9
+    bs = args.cpu_sample
+    if bs < 0:
+        try:
+            avail = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 1e9
+        except (ValueError, OSError):
+            avail = 32.0
+        bs = int(max(1, min(B, min(avail, 200.0) * 0.4 // (2 * per_utt_gb), 4)))
+    if logits is None:      # in-place run destroyed the logits: regenerate the sample
+        logits = torch.empty(bs, T, U + 1, V, dtype=torch.float32, device=dev)
+        logits.normal_(generator=gen)
+    x = logits[:bs].cpu().numpy()
+    y = targets[:bs].cpu().numpy()
+    ll = llens[:bs].cpu().numpy().copy()
+    tl = tlens[:bs].cpu().numpy().copy()
+    ll[0], tl[0] = T, U               # keep the maxima pinned for the sliced batch
+    g = np.empty_like(x)
+    t0 = time.perf_counter()
+    c, _ = oracle.rnnt_loss_f32(x, y, ll, tl, nthreads=cores, out_grad=g)     # warm-up (page faults, thread pool)
+    warm = time.perf_counter() - t0
+    reps = int(max(1, min(5, args.cpu_seconds // max(warm, 1e-3))))
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        c, _ = oracle.rnnt_loss_f32(x, y, ll, tl, nthreads=cores, out_grad=g)
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    res = {"value": round(bs / med, 3), "unit": "utterances/s", "cores": cores, "kind": "port",
+           "sample": f"{bs} of {B} utterances at the same (T={T},U={U},V={V}), fp32, loss+grad, "
+                     f"median of {reps} runs after 1 warm-up; oracle/rnnt_baseline.c with {cores} OpenMP threads "
+                     f"(torchaudio is not installed on this image)"}
+    try:
+        gc = gpu_costs[:bs].cpu().numpy()
+        same_lens = bool((llens[:bs].cpu().numpy() == ll).all() and (tlens[:bs].cpu().numpy() == tl).all())
+        if same_lens:
+            res["max_rel_cost_diff_vs_gpu"] = float(np.max(np.abs(gc - c) / np.maximum(1.0, np.abs(c))))
+    except Exception:   # the check is informational
+        pass
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -44,11 +44,11 @@ inline RnntWs rnnt_ws_layout(int B, int Tmax, int U1max)
     const size_t diag = (size_t)B * w.S * U1max;
     size_t off = 0;
     w.lp_off = off;    off = align_up(off + diag * sizeof(float2), 256);
-    w.alpha_off = off; off = align_up(off + diag * sizeof(float), 256);
-    w.beta_off = off;  off = align_up(off + diag * sizeof(float), 256);
+    w.alpha_off = off; off = align_up(off + diag * sizeof(double), 256);
+    w.beta_off = off;  off = align_up(off + diag * sizeof(double), 256);
     w.denom_off = off; off = align_up(off + (size_t)B * Tmax * U1max * sizeof(float), 256);
-    w.ll_off = off;    off = align_up(off + (size_t)B * sizeof(float), 256);
-    w.cost_off = off;  off = align_up(off + (size_t)B * sizeof(float), 256);
+    w.ll_off = off;    off = align_up(off + (size_t)B * sizeof(double), 256);
+    w.cost_off = off;  off = align_up(off + (size_t)B * sizeof(double), 256);
     w.total = off;
     return w;
 }
@@ -141,13 +141,41 @@ __global__ __launch_bounds__(256) void rnnt_lse_kernel(
 
 // ------------------------------------------------------------------ pass 2 --
 // One wave per (utterance, direction).  K label columns per lane.
+//
+// Precision: alpha/beta reach magnitudes ~ (T+U)*log(V) (1e4 at the BASELINE
+// shape), where an fp32 ulp is 1e-3.  The lattice state is therefore carried in
+// fp64 (adds, max) while the transcendental part log1p(exp(-|a-b|)) in [0, ln 2]
+// is evaluated in fp32: absolute error ~1e-7 per step instead of ~5e-4.
+__device__ __forceinline__ double log_add_exp_d(double a, double b)
+{
+    const double m = fmax(a, b);
+    const float d = (float)(-fabs(a - b));          // NaN when both are -inf
+    const float r = kLn2 * fast_log2(1.0f + fast_exp2(d * kLog2e));
+    return (m == (double)kNegInf) ? (double)kNegInf : m + (double)r;
+}
+
+__device__ __forceinline__ double lane_shift_up_d(double v, double fill)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double lane_shift_down_d(double v, double fill)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 template <int K, int PF>
 __global__ __launch_bounds__(64) void rnnt_sweep_kernel(
     const float2 *__restrict__ lp_skew, const int32_t *__restrict__ llens,
     const int32_t *__restrict__ tlens, int Tmax, int U1max, int S,
-    float *__restrict__ alpha_skew, float *__restrict__ beta_skew,
-    float *__restrict__ ll_out, float *__restrict__ cost_ws, float *__restrict__ costs_out)
+    double *__restrict__ alpha_skew, double *__restrict__ beta_skew,
+    double *__restrict__ ll_out, double *__restrict__ cost_ws, float *__restrict__ costs_out)
 {
+    constexpr double NEG = (double)kNegInf;
     const int b = blockIdx.x;
     const bool backward = blockIdx.y != 0;
     const int lane = threadIdx.x;
@@ -155,13 +183,13 @@ __global__ __launch_bounds__(64) void rnnt_sweep_kernel(
     T = T < 0 ? 0 : (T > Tmax ? Tmax : T);
     U = U < 0 ? 0 : (U > U1max - 1 ? U1max - 1 : U);
     const float2 *__restrict__ lp = lp_skew + (size_t)b * S * U1max;
-    float *__restrict__ out = (backward ? beta_skew : alpha_skew) + (size_t)b * S * U1max;
+    double *__restrict__ out = (backward ? beta_skew : alpha_skew) + (size_t)b * S * U1max;
     const int u0 = lane * K;
     const int nsteps = (T > 0) ? T + U / K : 0;   // diagonals that hold a valid cell
 
     if (nsteps == 0) {
         if (lane == 0) {
-            if (backward) { cost_ws[b] = 0.f; costs_out[b] = 0.f; } else ll_out[b] = 0.f;
+            if (backward) { cost_ws[b] = 0.0; costs_out[b] = 0.f; } else ll_out[b] = 0.0;
         }
         return;
     }
@@ -177,11 +205,11 @@ __global__ __launch_bounds__(64) void rnnt_sweep_kernel(
     };
 
     float2 ring[PF][K];
-    float st[K];      // alpha(t-1, u_j)  /  beta(t+1, u_j)
+    double st[K];     // alpha(t-1, u_j)  /  beta(t+1, u_j)
     float skp[K];     // forward only: skip(t-1, u_j)
 #pragma unroll
-    for (int j = 0; j < K; ++j) { st[j] = kNegInf; skp[j] = 0.f; }
-    float send = kNegInf;
+    for (int j = 0; j < K; ++j) { st[j] = NEG; skp[j] = 0.f; }
+    double send = NEG;
 
     if (!backward) {
 #pragma unroll
@@ -197,26 +225,26 @@ __global__ __launch_bounds__(64) void rnnt_sweep_kernel(
                 if (s < nsteps) {
                     const int t = s - lane;
                     const bool active = (t >= 0) & (t < T);
-                    const float left_in = lane_shift_up(send, kNegInf);
-                    float nw[K];
+                    const double left_in = lane_shift_up_d(send, NEG);
+                    double nw[K];
 #pragma unroll
                     for (int j = 0; j < K; ++j) {
                         const int u = u0 + j;
-                        const float top = (t >= 1) ? st[j] + skp[j] : kNegInf;
-                        float left = (j == 0) ? left_in : nw[j > 0 ? j - 1 : 0] + cur[j > 0 ? j - 1 : 0].y;
-                        left = (u >= 1) ? left : kNegInf;
-                        float v = log_add_exp(top, left);
-                        v = (t == 0 && u == 0) ? 0.f : v;
-                        v = (active && u <= U) ? v : kNegInf;
+                        const double top = (t >= 1) ? st[j] + (double)skp[j] : NEG;
+                        double left = (j == 0) ? left_in : nw[j > 0 ? j - 1 : 0] + (double)cur[j > 0 ? j - 1 : 0].y;
+                        left = (u >= 1) ? left : NEG;
+                        double v = log_add_exp_d(top, left);
+                        v = (t == 0 && u == 0) ? 0.0 : v;
+                        v = (active && u <= U) ? v : NEG;
                         nw[j] = v;
                     }
-                    send = nw[K - 1] + cur[K - 1].y;
+                    send = nw[K - 1] + (double)cur[K - 1].y;
 #pragma unroll
                     for (int j = 0; j < K; ++j) {
                         const int u = u0 + j;
                         if (active && u <= U) {
                             out[(size_t)s * U1max + u] = nw[j];
-                            if (t == T - 1 && u == U) ll_out[b] = nw[j] + cur[j].x;
+                            if (t == T - 1 && u == U) ll_out[b] = nw[j] + (double)cur[j].x;
                         }
                         st[j] = nw[j];
                         skp[j] = cur[j].x;
@@ -238,17 +266,17 @@ __global__ __launch_bounds__(64) void rnnt_sweep_kernel(
                 if (s >= 0) {
                     const int t = s - lane;
                     const bool active = (t >= 0) & (t < T);
-                    const float right_in = lane_shift_down(send, kNegInf);
-                    float nw[K];
+                    const double right_in = lane_shift_down_d(send, NEG);
+                    double nw[K];
 #pragma unroll
                     for (int j = K - 1; j >= 0; --j) {
                         const int u = u0 + j;
-                        const float down = (t < T - 1) ? st[j] + cur[j].x : kNegInf;
-                        float right = (j == K - 1) ? right_in : nw[j < K - 1 ? j + 1 : K - 1];
-                        right = (u < U) ? right + cur[j].y : kNegInf;
-                        float v = log_add_exp(down, right);
-                        v = (t == T - 1 && u == U) ? cur[j].x : v;
-                        v = (active && u <= U) ? v : kNegInf;
+                        const double down = (t < T - 1) ? st[j] + (double)cur[j].x : NEG;
+                        double right = (j == K - 1) ? right_in : nw[j < K - 1 ? j + 1 : K - 1];
+                        right = (u < U) ? right + (double)cur[j].y : NEG;
+                        double v = log_add_exp_d(down, right);
+                        v = (t == T - 1 && u == U) ? (double)cur[j].x : v;
+                        v = (active && u <= U) ? v : NEG;
                         nw[j] = v;
                     }
                     send = nw[0];
@@ -257,7 +285,7 @@ __global__ __launch_bounds__(64) void rnnt_sweep_kernel(
                         const int u = u0 + j;
                         if (active && u <= U) {
                             out[(size_t)s * U1max + u] = nw[j];
-                            if (t == 0 && u == 0) { cost_ws[b] = -nw[j]; costs_out[b] = -nw[j]; }
+                            if (t == 0 && u == 0) { cost_ws[b] = -nw[j]; costs_out[b] = (float)(-nw[j]); }
                         }
                         st[j] = nw[j];
                     }
@@ -272,8 +300,8 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(
     const float *logits, const int32_t *__restrict__ targets,
     const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens,
     int B, int Tmax, int U1max, int V, int blank, float clamp, int K, int S,
-    const float *__restrict__ alpha_skew, const float *__restrict__ beta_skew,
-    const float *__restrict__ denom, const float *__restrict__ cost_ws,
+    const double *__restrict__ alpha_skew, const double *__restrict__ beta_skew,
+    const float *__restrict__ denom, const double *__restrict__ cost_ws,
     const float *__restrict__ grad_costs, float *grads)
 {
     const int lane = threadIdx.x & (kWave - 1);
@@ -308,27 +336,29 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(
 
         const size_t dbase = (size_t)b * S * U1max;
         const int s = t + u / K;
-        const float al = alpha_skew[dbase + (size_t)s * U1max + u];
-        const float be = beta_skew[dbase + (size_t)s * U1max + u];
-        const float cost = cost_ws[b];
+        // Lattice state is fp64; the combinations below are small in magnitude
+        // (log-occupancies), so they are formed in fp64 and only then rounded.
+        const double al = alpha_skew[dbase + (size_t)s * U1max + u];
+        const double be = beta_skew[dbase + (size_t)s * U1max + u];
+        const double cost = cost_ws[b];
         const float go = grad_costs ? grad_costs[b] : 1.f;
-        const float cm = al + cost - denom[r];      // g = logit + cm
-        const float c2 = (cm + be) * kLog2e;
+        const double cmd = al + cost - (double)denom[r];      // g = logit + cm
+        const float c2 = (float)(cmd + be) * kLog2e;
 
         // special entries (SURVEY.md App. A.1 case chain; first match wins)
         bool blank_special = false;
         float blank_sub = 0.f;                      // exponent (natural log) of the subtracted term, minus logit
-        if (t == T - 1 && u == U) { blank_special = true; blank_sub = cm; }
+        if (t == T - 1 && u == U) { blank_special = true; blank_sub = (float)cmd; }
         else if (t < T - 1) {
             blank_special = true;
-            blank_sub = cm + beta_skew[dbase + (size_t)(s + 1) * U1max + u];
+            blank_sub = (float)(cmd + beta_skew[dbase + (size_t)(s + 1) * U1max + u]);
         }
         int lab = -1;
         float lab_sub = 0.f;
         if (u < U) {
             lab = targets[(size_t)b * (U1max - 1) + u];
             if (lab == blank && blank_special) lab = -1;
-            else lab_sub = cm + beta_skew[dbase + (size_t)(t + (u + 1) / K) * U1max + (u + 1)];
+            else lab_sub = (float)(cmd + beta_skew[dbase + (size_t)(t + (u + 1) / K) * U1max + (u + 1)]);
         }
         const int blk = blank_special ? blank : -1;
 
@@ -384,7 +414,7 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(
 }
 
 // ----------------------------------------------------- diagnostics export --
-__global__ void rnnt_export_kernel(const float *__restrict__ alpha_skew, const float *__restrict__ beta_skew,
+__global__ void rnnt_export_kernel(const double *__restrict__ alpha_skew, const double *__restrict__ beta_skew,
                                    const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens,
                                    int B, int Tmax, int U1max, int K, int S,
                                    float *__restrict__ alpha, float *__restrict__ beta)
@@ -398,8 +428,8 @@ __global__ void rnnt_export_kernel(const float *__restrict__ alpha_skew, const f
         float a = 0.f, be = 0.f;
         if (t < llens[b] && u <= tlens[b]) {
             const size_t k = ((size_t)b * S + t + u / K) * U1max + u;
-            a = alpha_skew[k];
-            be = beta_skew[k];
+            a = (float)alpha_skew[k];
+            be = (float)beta_skew[k];
         }
         alpha[r] = a;
         beta[r] = be;
@@ -430,11 +460,11 @@ template <int K>
 void launch_sweep(const RnntWs &w, char *ws, const int32_t *llens, const int32_t *tlens, int B, int Tmax,
                   int U1max, float *costs, hipStream_t st)
 {
-    constexpr int PF = (K <= 2) ? 8 : (K <= 4 ? 6 : 4);
+    constexpr int PF = (K <= 2) ? 8 : (K <= 4 ? 6 : 4);   // log-prob rows kept in flight ahead of the sweep
     hipLaunchKernelGGL((rnnt_sweep_kernel<K, PF>), dim3(B, 2), dim3(64), 0, st,
                        reinterpret_cast<const float2 *>(ws + w.lp_off), llens, tlens, Tmax, U1max, w.S,
-                       reinterpret_cast<float *>(ws + w.alpha_off), reinterpret_cast<float *>(ws + w.beta_off),
-                       reinterpret_cast<float *>(ws + w.ll_off), reinterpret_cast<float *>(ws + w.cost_off), costs);
+                       reinterpret_cast<double *>(ws + w.alpha_off), reinterpret_cast<double *>(ws + w.beta_off),
+                       reinterpret_cast<double *>(ws + w.ll_off), reinterpret_cast<double *>(ws + w.cost_off), costs);
 }
 
 }  // namespace
@@ -501,10 +531,10 @@ extern "C" int wr_rnnt_loss_bwd(const void *logits_d, int dtype, const int32_t *
     const long nrows = (long)B * Tmax * U1max;
     hipLaunchKernelGGL(rnnt_grad_kernel, dim3(stream_grid(nrows)), dim3(256), 0, st,
                        static_cast<const float *>(logits_d), targets_d, logit_lengths_d, target_lengths_d, B, Tmax,
-                       U1max, V, blank, clamp, w.K, w.S, reinterpret_cast<const float *>(ws + w.alpha_off),
-                       reinterpret_cast<const float *>(ws + w.beta_off),
+                       U1max, V, blank, clamp, w.K, w.S, reinterpret_cast<const double *>(ws + w.alpha_off),
+                       reinterpret_cast<const double *>(ws + w.beta_off),
                        reinterpret_cast<const float *>(ws + w.denom_off),
-                       reinterpret_cast<const float *>(ws + w.cost_off), grad_costs_d, static_cast<float *>(grads_d));
+                       reinterpret_cast<const double *>(ws + w.cost_off), grad_costs_d, static_cast<float *>(grads_d));
     WR_CHECK_LAUNCH("rnnt_grad_kernel");
     return WR_OK;
 }
@@ -520,8 +550,8 @@ extern "C" int wr_rnnt_export_lattice(const void *workspace_d, size_t workspace_
     WR_REQUIRE(workspace_bytes >= w.total, WR_EWORKSPACE, "rnnt_export_lattice: workspace too small");
     const char *ws = static_cast<const char *>(workspace_d);
     hipLaunchKernelGGL(rnnt_export_kernel, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<const float *>(ws + w.alpha_off),
-                       reinterpret_cast<const float *>(ws + w.beta_off), logit_lengths_d, target_lengths_d, B, Tmax,
+                       reinterpret_cast<const double *>(ws + w.alpha_off),
+                       reinterpret_cast<const double *>(ws + w.beta_off), logit_lengths_d, target_lengths_d, B, Tmax,
                        U1max, w.K, w.S, alpha_d, beta_d);
     WR_CHECK_LAUNCH("rnnt_export_kernel");
     return WR_OK;
