@@ -1,0 +1,180 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+
+Plain numpy restatements of the reference's transducer decoders and of the
+small modules they call, one utterance at a time, following the reference
+line by line in behaviour (not in code):
+
+  predictor step   /root/reference/wenet/transducer/predictor.py:160-200
+                   (RNNPredictor.forward_step: embed -> LSTM layers -> projection,
+                   ApplyPadding :9-15; gate order i,f,g,o as torch.nn.LSTM)
+  joiner           /root/reference/wenet/transducer/joint.py:45-70
+                   (ffn_out(tanh(enc_ffn(enc) + pred_ffn(pred))))
+  greedy search    /root/reference/wenet/transducer/search/greedy_search copy.py:6-63
+                   (the upstream core loop; semantics in SURVEY.md App. A.3)
+  prefix beam      /root/reference/wenet/transducer/search/prefix_beam_search.py:42-148
+                    with log_add from wenet/utils/common.py:268-276
+  ctc log-softmax  /root/reference/wenet/transformer/ctc.py:66-75
+
+PINNED: tests/test_oracle_decode.py replays every fixture under tests/golden/
+(greedy_core_*, prefix_beam_*, predictor_step_*, joint_ref_*), which
+tests/golden/make_golden.py produced by running the reference's own modules.
+Weights are passed as dicts of numpy arrays keyed like the reference modules'
+state_dict (embed.weight, rnn.weight_ih_l0, ..., projection.weight;
+enc_ffn/pred_ffn/ffn_out .weight/.bias; ctc_lo.weight/.bias).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+F = np.float32
+
+
+def _sigmoid(x):
+    return (1.0 / (1.0 + np.exp(-x.astype(np.float64)))).astype(F)
+
+
+def log_softmax(x):
+    x = x.astype(F)
+    m = x.max(-1, keepdims=True)
+    e = np.exp((x - m).astype(F))
+    return (x - m - np.log(e.sum(-1, keepdims=True, dtype=F))).astype(F)
+
+
+def log_add(args):
+    """wenet/utils/common.py:268-276 (Python floats = float64)."""
+    if all(a == -float("inf") for a in args):
+        return -float("inf")
+    a_max = max(args)
+    return a_max + math.log(sum(math.exp(a - a_max) for a in args))
+
+
+class Predictor:
+    """RNNPredictor step API (predictor.py:123-200).  cache = [h (L,N,H), c (L,N,H)]."""
+
+    def __init__(self, w, n_layers):
+        self.w = {k: np.asarray(v, F) for k, v in w.items()}
+        self.L = int(n_layers)
+        self.H = self.w["rnn.weight_hh_l0"].shape[1]
+
+    def init_state(self, n):
+        return [np.zeros((self.L, n, self.H), F), np.zeros((self.L, n, self.H), F)]
+
+    def forward_step(self, tokens, padding, cache):
+        """tokens (N,) int, padding (N,1) f32 (1 keeps the old state), cache -> (out (N,O), new cache)."""
+        h0, c0 = cache
+        x = self.w["embed.weight"][np.asarray(tokens, np.int64)]
+        hs, cs = [], []
+        for l in range(self.L):
+            g = (x @ self.w[f"rnn.weight_ih_l{l}"].T + self.w[f"rnn.bias_ih_l{l}"]
+                 + h0[l] @ self.w[f"rnn.weight_hh_l{l}"].T + self.w[f"rnn.bias_hh_l{l}"]).astype(F)
+            H = self.H
+            i, f, gg, o = _sigmoid(g[:, :H]), _sigmoid(g[:, H:2 * H]), np.tanh(g[:, 2 * H:3 * H]), _sigmoid(g[:, 3 * H:])
+            c = (f * c0[l] + i * gg).astype(F)
+            h = (o * np.tanh(c)).astype(F)
+            hs.append(h); cs.append(c)
+            x = h
+        out = (x @ self.w["projection.weight"].T + self.w["projection.bias"]).astype(F)
+        m, c = np.stack(hs), np.stack(cs)
+        p = np.asarray(padding, F).reshape(1, -1, 1)
+        m = p * h0 + m * (1 - p)            # ApplyPadding, predictor.py:9-15
+        c = p * c0 + c * (1 - p)
+        return out, [m.astype(F), c.astype(F)]
+
+
+class Joint:
+    """TransducerJoint.forward for step shapes (joint.py:45-70)."""
+
+    def __init__(self, w):
+        self.w = {k: np.asarray(v, F) for k, v in w.items()}
+
+    def __call__(self, enc, pred):
+        """enc (..., E), pred (..., P) broadcastable leading dims -> (..., V)."""
+        e = enc @ self.w["enc_ffn.weight"].T + self.w["enc_ffn.bias"]
+        p = pred @ self.w["pred_ffn.weight"].T + self.w["pred_ffn.bias"]
+        h = np.tanh((e + p).astype(F))
+        return (h @ self.w["ffn_out.weight"].T + self.w["ffn_out.bias"]).astype(F)
+
+    def full(self, enc, pred):
+        """(B,T,E),(B,U1,P) -> (B,T,U1,V)"""
+        e = enc @ self.w["enc_ffn.weight"].T + self.w["enc_ffn.bias"]
+        p = pred @ self.w["pred_ffn.weight"].T + self.w["pred_ffn.bias"]
+        h = np.tanh((e[:, :, None, :] + p[:, None, :, :]).astype(F))
+        return (h @ self.w["ffn_out.weight"].T + self.w["ffn_out.bias"]).astype(F)
+
+
+def greedy_search(pred: Predictor, joint: Joint, enc, T, blank=0, n_steps=64, return_margin=False):
+    """'greedy_search copy.py':14-63 for one utterance.  enc (T,E)."""
+    cache = pred.init_state(1)
+    tok = np.array([blank])
+    padding = np.zeros((1, 1), F)
+    t, hyps, prev_nblk, per_frame = 0, [], True, 0
+    out, new_cache = None, None
+    min_margin = float("inf")
+    while t < T:
+        if prev_nblk:
+            out, new_cache = pred.forward_step(tok, padding, cache)
+        lp = log_softmax(joint(enc[t][None, :], out))[0]
+        k = int(lp.argmax())
+        if return_margin:
+            srt = np.sort(lp)
+            min_margin = min(min_margin, float(srt[-1] - srt[-2]))
+        if k != blank:
+            hyps.append(k)
+            prev_nblk = True
+            per_frame += 1
+            tok = np.array([k])
+            cache = new_cache
+        if k == blank or per_frame >= n_steps:
+            if k == blank:
+                prev_nblk = False
+            t += 1
+            per_frame = 0
+    return (hyps, min_margin) if return_margin else hyps
+
+
+def ctc_log_softmax(w, enc):
+    """ctc.py:66-75: log_softmax(ctc_lo(hs)).  enc (T,E) -> (T,V)"""
+    return log_softmax(enc @ np.asarray(w["ctc_lo.weight"], F).T + np.asarray(w["ctc_lo.bias"], F))
+
+
+def prefix_beam_search(pred: Predictor, joint: Joint, ctc_w, enc, T, beam_size=5, ctc_weight=0.3,
+                       transducer_weight=0.7, blank=0):
+    """prefix_beam_search.py:42-148 for one utterance.  Returns the pruned beam as a
+    list of dicts {hyp (with the seed blank), score (float64), cache}."""
+    ctc_probs = ctc_log_softmax(ctc_w, enc[:T])
+    beam = [dict(hyp=[blank], score=0.0, cache=pred.init_state(1))]
+    for i in range(T):
+        n = len(beam)
+        toks = np.array([s["hyp"][-1] for s in beam])
+        cache = [np.concatenate([s["cache"][0] for s in beam], 1), np.concatenate([s["cache"][1] for s in beam], 1)]
+        scores = np.array([s["score"] for s in beam]).astype(F)          # fp32 tensor from Python floats (:86)
+        out, new_cache = pred.forward_step(toks, np.zeros((n, 1), F), cache)
+        logp = log_softmax(joint(np.broadcast_to(enc[i], (n, enc.shape[1])), out))
+        # (:99-101) log(tw*exp(logp) + cw*exp(ctc[i])) in fp32
+        logp = np.log((F(transducer_weight) * np.exp(logp) + F(ctc_weight) * np.exp(ctc_probs[i])[None, :]).astype(F)).astype(F)
+        order = np.argsort(-logp, axis=1, kind="stable")[:, :beam_size]   # topk: larger first, lower index on ties
+        topv = np.take_along_axis(logp, order, 1)
+        cand = (scores[:, None] + topv).astype(F)
+        beam_a = []
+        for j in range(n):
+            base = beam[j]
+            for t in range(beam_size):
+                k = int(order[j, t])
+                if k == blank:
+                    beam_a.append(dict(hyp=list(base["hyp"]), score=float(cand[j, t]), cache=base["cache"]))
+                else:
+                    beam_a.append(dict(hyp=base["hyp"] + [k], score=float(cand[j, t]),
+                                       cache=[new_cache[0][:, j:j + 1], new_cache[1][:, j:j + 1]]))
+        fusion = [beam_a[0]]
+        for s1 in beam_a[1:]:
+            for s0 in fusion:
+                if s1["hyp"] == s0["hyp"]:
+                    s0["score"] = log_add([s0["score"], s1["score"]])
+                    break
+            else:
+                fusion.append(s1)
+        fusion.sort(key=lambda s: s["score"], reverse=True)                 # stable, like list.sort
+        beam = fusion[:beam_size]
+    return beam
