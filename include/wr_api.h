@@ -95,6 +95,37 @@ int wr_rnnt_export_lattice(const void *workspace_d, size_t workspace_bytes,
                            int B, int Tmax, int U1max,
                            float *alpha_d, float *beta_d, void *stream);
 
+/* ------------------------------------------------------------------------
+ * CTC loss + gradient with the log-softmax fused in.
+ * Replaces  ys_hat = ys_hat.log_softmax(2); loss = nn.CTCLoss(...)(ys_hat, ys_pad, hlens, ys_lens)
+ * at wenet/transformer/ctc.py:60-61 (blank = 0, zero_infinity = False).
+ *
+ * logits [B, Tmax, V] contiguous = the PRE-softmax output of ctc_lo, batch-major
+ * (no transpose needed); targets [B, Smax] int32, entries beyond
+ * target_lengths[b] are never read; lengths [B] int32.  nll[b] = -log p(y_b | x_b)
+ * per utterance (infeasible alignment -> +inf, a value, not an error);
+ * reduction ('sum' then /B in the reference, ctc.py:61-63) is the caller's and
+ * is folded into grad_nll.  grads = grad_nll[b] * d nll_b / d logits, zero for
+ * t >= input_lengths[b]; grads_d may alias logits_d.  Limits: Smax <= 255,
+ * V <= 16384.
+ * ---------------------------------------------------------------------- */
+size_t wr_ctc_workspace_bytes(int B, int Tmax, int Smax);
+
+int wr_ctc_loss_fwd(const void *logits_d, int dtype,
+                    const int32_t *targets_d, const int32_t *input_lengths_d,
+                    const int32_t *target_lengths_d,
+                    int B, int Tmax, int Smax, int V, int blank,
+                    float *nll_d /* [B] out */,
+                    void *workspace_d, size_t workspace_bytes, void *stream);
+
+int wr_ctc_loss_bwd(const void *logits_d, int dtype,
+                    const int32_t *targets_d, const int32_t *input_lengths_d,
+                    const int32_t *target_lengths_d,
+                    int B, int Tmax, int Smax, int V, int blank,
+                    const float *grad_nll_d /* [B] or NULL */,
+                    void *grads_d,
+                    const void *workspace_d, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

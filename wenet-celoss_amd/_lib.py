@@ -91,6 +91,9 @@ SIGNATURES = {
     "wr_rnnt_loss_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "wr_rnnt_loss_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "wr_rnnt_export_lattice": (_i, [_vp, _sz, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "wr_ctc_workspace_bytes": (_sz, [_i, _i, _i]),
+    "wr_ctc_loss_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "wr_ctc_loss_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
 }
 
 

@@ -1,0 +1,455 @@
+// CTC loss + gradient with the log-softmax fused in, for MI355X (gfx950).
+// Replaces `ys_hat.log_softmax(2)` + `torch.nn.CTCLoss(reduction=...)` of the
+// reference (wenet/transformer/ctc.py:57-63).  See include/wr_api.h.
+//
+// Input is the *pre-softmax* output of ctc_lo, batch-major [B, Tmax, V] (the
+// reference's transpose to (T,B,V) is only nn.CTCLoss's layout requirement).
+//
+//   pass 1  ctc_lse_kernel    one wave per frame (b,t): streams the V logits once,
+//           writes denom(b,t) and the log-probs the lattice needs --
+//           lp_blank(b,t) and lp_label(b,t,i) for the S_b labels -- (S+1 values
+//           instead of 2S+1: every even state of the extended sequence is blank).
+//   pass 2  ctc_sweep_kernel  one wave per (utterance, direction); lane l owns
+//           KS = ceil((2*Smax+1)/64) adjacent states of the extended label
+//           sequence.  alpha_t(s) depends on alpha_{t-1}(s, s-1, s-2): the two
+//           values that cross a lane boundary come from the left neighbour by
+//           DPP wave shifts (no LDS, no barrier).  State in fp64, the bounded
+//           log-sum-exp correction in fp32 (same precision argument as the
+//           RNN-T sweep).  Latency-bound: T dependent steps.
+//   pass 3  ctc_grad_kernel   one workgroup per frame: softmax row into LDS,
+//           subtract the state occupancies exp(alpha+beta+nll-lp) with LDS float
+//           atomics (repeated labels and the S+1 blank states collide), write the
+//           row out with 16-B stores.  Frames t >= T_b are zero-filled.
+//
+// Algorithmic traffic: 4*V per valid frame (pass 1) + 2*4*V per frame (pass 3).
+#include "wr_common.hpp"
+
+namespace wr {
+namespace {
+
+struct CtcWs {
+    int KS;           // extended-label states per lane
+    int SP;           // 2*Smax+1
+    size_t denom_off, lpb_off, lpl_off, alpha_off, beta_off, nll_off, total;
+};
+
+inline CtcWs ctc_ws_layout(int B, int Tmax, int Smax)
+{
+    CtcWs w;
+    w.SP = 2 * Smax + 1;
+    w.KS = (w.SP + kWave - 1) / kWave;
+    size_t off = 0;
+    const size_t frames = (size_t)B * Tmax;
+    w.denom_off = off; off = align_up(off + frames * sizeof(float), 256);
+    w.lpb_off = off;   off = align_up(off + frames * sizeof(float), 256);
+    w.lpl_off = off;   off = align_up(off + frames * (size_t)(Smax > 0 ? Smax : 1) * sizeof(float), 256);
+    w.alpha_off = off; off = align_up(off + frames * w.SP * sizeof(double), 256);
+    w.beta_off = off;  off = align_up(off + frames * w.SP * sizeof(double), 256);
+    w.nll_off = off;   off = align_up(off + (size_t)B * sizeof(double), 256);
+    w.total = off;
+    return w;
+}
+
+// ------------------------------------------------------------------ pass 1 --
+__device__ __forceinline__ float wave_row_lse_cached(const float *__restrict__ row, int V, int lane)
+{
+    // Same online (max,sum) scheme as the RNN-T pass 1, but with default-policy loads:
+    // the CTC logits (B*T*V) are re-read by the gather below and by pass 3.
+    float m = -3.0e38f, s = 0.f;
+    const int head = (int)((4 - ((reinterpret_cast<uintptr_t>(row) >> 2) & 3)) & 3);
+    const int h = head < V ? head : V;
+    const int n4 = (V - h) >> 2;
+    const int tail = V - h - 4 * n4;
+    auto add1 = [&](float x) {
+        const float y = x * kLog2e, nm = fmaxf(m, y);
+        s = s * fast_exp2(m - nm) + fast_exp2(y - nm);
+        m = nm;
+    };
+    if (lane < h) add1(row[lane]);
+    if (lane < tail) add1(row[h + 4 * n4 + lane]);
+    const f32x4 *__restrict__ body = reinterpret_cast<const f32x4 *>(row + h);
+    for (int i = lane; i < n4; i += kWave) {
+        const f32x4 v = body[i];
+        const float y0 = v.x * kLog2e, y1 = v.y * kLog2e, y2 = v.z * kLog2e, y3 = v.w * kLog2e;
+        const float nm = fmaxf(m, fmaxf(fmaxf(y0, y1), fmaxf(y2, y3)));
+        s = s * fast_exp2(m - nm) + (fast_exp2(y0 - nm) + fast_exp2(y1 - nm)) +
+            (fast_exp2(y2 - nm) + fast_exp2(y3 - nm));
+        m = nm;
+    }
+    const float M = wave_max(m);
+    const float tot = wave_sum(s * fast_exp2(m - M));
+    return (M + fast_log2(tot)) * kLn2;
+}
+
+__global__ __launch_bounds__(256) void ctc_lse_kernel(
+    const float *__restrict__ logits, const int32_t *__restrict__ targets,
+    const int32_t *__restrict__ ilens, const int32_t *__restrict__ tlens,
+    int B, int Tmax, int Smax, int V, int blank,
+    float *__restrict__ denom, float *__restrict__ lp_blank, float *__restrict__ lp_label)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wpb = blockDim.x >> 6;
+    const long nrows = (long)B * Tmax;
+    for (long r = (long)blockIdx.x * wpb + wid; r < nrows; r += (long)gridDim.x * wpb) {
+        const int b = (int)(r / Tmax);
+        const int t = (int)(r - (long)b * Tmax);
+        if (t >= ilens[b]) continue;
+        const float *row = logits + (size_t)r * V;
+        const float d = wave_row_lse_cached(row, V, lane);
+        int S = tlens[b];
+        S = S < 0 ? 0 : (S > Smax ? Smax : S);
+        if (lane == 0) {
+            denom[r] = d;
+            lp_blank[r] = row[blank] - d;
+        }
+        for (int i = lane; i < S; i += kWave) {
+            int lab = targets[(size_t)b * Smax + i];
+            lab = lab < 0 ? 0 : (lab >= V ? V - 1 : lab);
+            lp_label[(size_t)r * Smax + i] = row[lab] - d;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ pass 2 --
+__device__ __forceinline__ double lse3_d(double a, double b, double c)
+{
+    const double m = fmax(a, fmax(b, c));
+    const float ea = fast_exp2((float)(a - m) * kLog2e);
+    const float eb = fast_exp2((float)(b - m) * kLog2e);
+    const float ec = fast_exp2((float)(c - m) * kLog2e);
+    const float r = kLn2 * fast_log2(ea + eb + ec);
+    return (m == (double)kNegInf) ? (double)kNegInf : m + (double)r;
+}
+
+__device__ __forceinline__ double dpp_up_d(double v, double fill)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double dpp_down_d(double v, double fill)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// KS states per lane.  State s: even -> blank, odd -> label (s-1)/2.
+template <int KS, int PF>
+__global__ __launch_bounds__(64) void ctc_sweep_kernel(
+    const float *__restrict__ lp_blank, const float *__restrict__ lp_label,
+    const int32_t *__restrict__ targets, const int32_t *__restrict__ ilens,
+    const int32_t *__restrict__ tlens, int Tmax, int Smax, int SP,
+    double *__restrict__ alpha, double *__restrict__ beta, double *__restrict__ nll_ws,
+    float *__restrict__ nll_out)
+{
+    constexpr double NEG = (double)kNegInf;
+    const int b = blockIdx.x;
+    const bool backward = blockIdx.y != 0;
+    const int lane = threadIdx.x;
+    int T = ilens[b], S = tlens[b];
+    T = T < 0 ? 0 : (T > Tmax ? Tmax : T);
+    S = S < 0 ? 0 : (S > Smax ? Smax : S);
+    const int NS = 2 * S + 1;                 // states of this utterance
+    const int s0 = lane * KS;
+    const float *__restrict__ lpb = lp_blank + (size_t)b * Tmax;
+    const float *__restrict__ lpl = lp_label + (size_t)b * Tmax * Smax;
+    double *__restrict__ out = (backward ? beta : alpha) + (size_t)b * Tmax * SP;
+
+    if (T == 0) {
+        // no frames: feasible only for the empty target (ATen: nll = 0 if S == 0 else inf)
+        if (lane == 0 && backward) {
+            const double v = (S == 0) ? 0.0 : (double)__builtin_huge_valf();
+            nll_ws[b] = v;
+            nll_out[b] = (float)v;
+        }
+        return;
+    }
+
+    // per-state constants: the label of each owned state and whether the s-2 (fwd) / s+2 (bwd) skip is allowed
+    int lab_idx[KS];      // index into lp_label row, -1 for blank / out of range
+    bool skip_ok[KS];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+        const int s = s0 + j;
+        lab_idx[j] = -1;
+        skip_ok[j] = false;
+        if (s < NS && (s & 1)) {
+            const int i = s >> 1;
+            lab_idx[j] = i;
+            const int me = targets[(size_t)b * Smax + i];
+            if (!backward) {
+                if (i >= 1) skip_ok[j] = (me != targets[(size_t)b * Smax + i - 1]);
+            } else {
+                if (i + 1 < S) skip_ok[j] = (me != targets[(size_t)b * Smax + i + 1]);
+            }
+        }
+    }
+
+    auto load_lp = [&](int t, float (&dst)[KS]) {
+        const bool ok = (t >= 0) & (t < T);
+        const float lb = ok ? lpb[t] : 0.f;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            float v = lb;
+            if (lab_idx[j] >= 0) v = ok ? lpl[(size_t)t * Smax + lab_idx[j]] : 0.f;
+            dst[j] = v;
+        }
+    };
+
+    float ring[PF][KS];
+    double st[KS];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) st[j] = NEG;
+
+    if (!backward) {
+        // t = 0: alpha_0(0) = lp(0,blank), alpha_0(1) = lp(0,y_1)
+        float lp0[KS];
+        load_lp(0, lp0);
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const int s = s0 + j;
+            st[j] = (s < NS && s <= 1) ? (double)lp0[j] : NEG;
+            if (s < NS) out[s] = st[j];
+        }
+#pragma unroll
+        for (int i = 0; i < PF; ++i) load_lp(1 + i, ring[i]);
+        for (int base = 1; base < T; base += PF) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int t = base + i;
+                float cur[KS];
+#pragma unroll
+                for (int j = 0; j < KS; ++j) cur[j] = ring[i][j];
+                load_lp(t + PF, ring[i]);
+                if (t < T) {
+                    // neighbours' last two states of the previous frame
+                    const double l1 = dpp_up_d(st[KS - 1], NEG);                       // state s0-1
+                    const double l2 = (KS >= 2) ? dpp_up_d(st[KS >= 2 ? KS - 2 : 0], NEG)  // state s0-2
+                                                : dpp_up_d(l1, NEG);
+                    double nw[KS];
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) {
+                        const int s = s0 + j;
+                        const double a0 = st[j];
+                        const double a1 = (j >= 1) ? st[j >= 1 ? j - 1 : 0] : l1;
+                        double a2 = (j >= 2) ? st[j >= 2 ? j - 2 : 0] : (j == 1 ? l1 : l2);
+                        a2 = skip_ok[j] ? a2 : NEG;
+                        double v = lse3_d(a0, a1, a2);
+                        v = (v == NEG) ? NEG : v + (double)cur[j];
+                        nw[j] = (s < NS) ? v : NEG;
+                    }
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) {
+                        st[j] = nw[j];
+                        if (s0 + j < NS) out[(size_t)t * SP + s0 + j] = nw[j];
+                    }
+                }
+            }
+        }
+    } else {
+        float lpT[KS];
+        load_lp(T - 1, lpT);
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const int s = s0 + j;
+            st[j] = (s < NS && s >= NS - 2) ? (double)lpT[j] : NEG;
+            if (s < NS) out[(size_t)(T - 1) * SP + s] = st[j];
+        }
+#pragma unroll
+        for (int i = 0; i < PF; ++i) load_lp(T - 2 - i, ring[i]);
+        for (int base = 0; base < T - 1; base += PF) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int t = T - 2 - (base + i);
+                float cur[KS];
+#pragma unroll
+                for (int j = 0; j < KS; ++j) cur[j] = ring[i][j];
+                load_lp(t - PF, ring[i]);
+                if (t >= 0) {
+                    const double r1 = dpp_down_d(st[0], NEG);                          // state s0+KS
+                    const double r2 = (KS >= 2) ? dpp_down_d(st[KS >= 2 ? 1 : 0], NEG)    // state s0+KS+1
+                                                : dpp_down_d(r1, NEG);
+                    double nw[KS];
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) {
+                        const int s = s0 + j;
+                        const double a0 = st[j];
+                        const double a1 = (j + 1 < KS) ? st[j + 1 < KS ? j + 1 : KS - 1] : r1;
+                        double a2;
+                        if (j + 2 < KS) a2 = st[j + 2 < KS ? j + 2 : KS - 1];
+                        else if (j + 2 == KS) a2 = r1;
+                        else a2 = r2;
+                        a2 = skip_ok[j] ? a2 : NEG;
+                        double v = lse3_d(a0, a1, a2);
+                        v = (v == NEG) ? NEG : v + (double)cur[j];
+                        nw[j] = (s < NS) ? v : NEG;
+                    }
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) {
+                        st[j] = nw[j];
+                        if (s0 + j < NS) out[(size_t)t * SP + s0 + j] = nw[j];
+                    }
+                }
+            }
+        }
+        // nll = -logsumexp(beta_0(0), beta_0(1))
+        const double b0 = __shfl(st[0], 0, kWave);
+        double b1 = NEG;
+        if (NS > 1) b1 = (KS >= 2) ? __shfl(st[KS >= 2 ? 1 : 0], 0, kWave) : __shfl(st[0], 1, kWave);
+        if (lane == 0) {
+            const double ll = lse3_d(b0, b1, NEG);
+            nll_ws[b] = -ll;
+            nll_out[b] = (float)(-ll);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ pass 3 --
+__global__ __launch_bounds__(256) void ctc_grad_kernel(
+    const float *logits, const int32_t *__restrict__ targets, const int32_t *__restrict__ ilens,
+    const int32_t *__restrict__ tlens, int B, int Tmax, int Smax, int SP, int V, int blank,
+    const float *__restrict__ denom, const float *__restrict__ lp_blank, const float *__restrict__ lp_label,
+    const double *__restrict__ alpha, const double *__restrict__ beta, const double *__restrict__ nll_ws,
+    const float *__restrict__ grad_nll, float *grads)
+{
+    extern __shared__ __attribute__((aligned(16))) float srow[];   // V floats
+    const long r = blockIdx.x;
+    const int b = (int)(r / Tmax);
+    const int t = (int)(r - (long)b * Tmax);
+    const int T = ilens[b];
+    int S = tlens[b];
+    S = S < 0 ? 0 : (S > Smax ? Smax : S);
+    const float *row = logits + (size_t)r * V;
+    float *grow = grads + (size_t)r * V;
+    const int tid = threadIdx.x, nt = blockDim.x;
+
+    if (t >= T) {
+        for (int v = tid; v < V; v += nt) grow[v] = 0.f;
+        return;
+    }
+    const float go = grad_nll ? grad_nll[b] : 1.f;
+    const float d2 = denom[r] * kLog2e;
+    for (int v = tid; v < V; v += nt) srow[v] = go * fast_exp2(fmaf(row[v], kLog2e, -d2));
+    __syncthreads();
+    const double nll = nll_ws[b];
+    const int NS = 2 * S + 1;
+    const double *al = alpha + (size_t)r * SP;
+    const double *be = beta + (size_t)r * SP;
+    for (int s = tid; s < NS; s += nt) {
+        int lab = blank;
+        float lp = lp_blank[r];
+        if (s & 1) {
+            lab = targets[(size_t)b * Smax + (s >> 1)];
+            lab = lab < 0 ? 0 : (lab >= V ? V - 1 : lab);
+            lp = lp_label[(size_t)r * Smax + (s >> 1)];
+        }
+        // occupancy of state s at frame t: exp(alpha + beta - lp + nll)   (alpha and beta both include lp)
+        const float e = (float)(al[s] + be[s] + nll - (double)lp);
+        atomicAdd(&srow[lab], -go * fast_exp2(e * kLog2e));
+    }
+    __syncthreads();
+    for (int v = tid; v < V; v += nt) grow[v] = srow[v];
+}
+
+int ctc_check(int B, int Tmax, int Smax, int V, int blank)
+{
+    WR_REQUIRE(B > 0 && Tmax > 0 && Smax >= 0 && V > 0, WR_EINVAL,
+               "ctc: B, Tmax, V must be positive and Smax >= 0 (got %d,%d,%d,%d)", B, Tmax, Smax, V);
+    WR_REQUIRE(blank >= 0 && blank < V, WR_EINVAL, "ctc: blank %d out of range [0,%d)", blank, V);
+    WR_REQUIRE((2 * Smax + 1 + kWave - 1) / kWave <= 8, WR_EUNSUPPORTED,
+               "ctc: Smax=%d exceeds the sweep kernel's limit of 255 labels", Smax);
+    WR_REQUIRE((size_t)V * sizeof(float) <= 64 * 1024, WR_EUNSUPPORTED,
+               "ctc: V=%d does not fit the gradient kernel's LDS row (max 16384)", V);
+    return WR_OK;
+}
+
+template <int KS>
+void launch_ctc_sweep(const CtcWs &w, char *ws, const int32_t *targets, const int32_t *ilens, const int32_t *tlens,
+                      int B, int Tmax, int Smax, float *nll, hipStream_t st)
+{
+    constexpr int PF = (KS <= 2) ? 8 : (KS <= 5 ? 6 : 4);
+    hipLaunchKernelGGL((ctc_sweep_kernel<KS, PF>), dim3(B, 2), dim3(64), 0, st,
+                       reinterpret_cast<const float *>(ws + w.lpb_off), reinterpret_cast<const float *>(ws + w.lpl_off),
+                       targets, ilens, tlens, Tmax, Smax > 0 ? Smax : 1, w.SP,
+                       reinterpret_cast<double *>(ws + w.alpha_off), reinterpret_cast<double *>(ws + w.beta_off),
+                       reinterpret_cast<double *>(ws + w.nll_off), nll);
+}
+
+}  // namespace
+}  // namespace wr
+
+using namespace wr;
+
+extern "C" size_t wr_ctc_workspace_bytes(int B, int Tmax, int Smax)
+{
+    if (B <= 0 || Tmax <= 0 || Smax < 0) return 0;
+    return ctc_ws_layout(B, Tmax, Smax).total;
+}
+
+extern "C" int wr_ctc_loss_fwd(const void *logits_d, int dtype, const int32_t *targets_d,
+                               const int32_t *input_lengths_d, const int32_t *target_lengths_d, int B, int Tmax,
+                               int Smax, int V, int blank, float *nll_d, void *workspace_d, size_t workspace_bytes,
+                               void *stream)
+{
+    if (int rc = ctc_check(B, Tmax, Smax, V, blank)) return rc;
+    WR_REQUIRE(logits_d && input_lengths_d && target_lengths_d && nll_d && workspace_d, WR_EINVAL,
+               "ctc_loss_fwd: null pointer argument");
+    WR_REQUIRE(targets_d || Smax == 0, WR_EINVAL, "ctc_loss_fwd: targets is null");
+    WR_REQUIRE(dtype == WR_F32, WR_EUNSUPPORTED, "ctc_loss_fwd: dtype %d not supported (fp32 only)", dtype);
+    const CtcWs w = ctc_ws_layout(B, Tmax, Smax);
+    WR_REQUIRE(workspace_bytes >= w.total, WR_EWORKSPACE, "ctc_loss_fwd: workspace %zu < required %zu",
+               workspace_bytes, w.total);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char *ws = static_cast<char *>(workspace_d);
+    const long nrows = (long)B * Tmax;
+    const int SmaxA = Smax > 0 ? Smax : 1;
+    long blocks = (nrows + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(ctc_lse_kernel, dim3((int)blocks), dim3(256), 0, st, static_cast<const float *>(logits_d),
+                       targets_d, input_lengths_d, target_lengths_d, B, Tmax, SmaxA, V, blank,
+                       reinterpret_cast<float *>(ws + w.denom_off), reinterpret_cast<float *>(ws + w.lpb_off),
+                       reinterpret_cast<float *>(ws + w.lpl_off));
+    WR_CHECK_LAUNCH("ctc_lse_kernel");
+    switch (w.KS) {
+        case 1: launch_ctc_sweep<1>(w, ws, targets_d, input_lengths_d, target_lengths_d, B, Tmax, Smax, nll_d, st); break;
+        case 2: launch_ctc_sweep<2>(w, ws, targets_d, input_lengths_d, target_lengths_d, B, Tmax, Smax, nll_d, st); break;
+        case 3: launch_ctc_sweep<3>(w, ws, targets_d, input_lengths_d, target_lengths_d, B, Tmax, Smax, nll_d, st); break;
+        case 4: launch_ctc_sweep<4>(w, ws, targets_d, input_lengths_d, target_lengths_d, B, Tmax, Smax, nll_d, st); break;
+        case 5: launch_ctc_sweep<5>(w, ws, targets_d, input_lengths_d, target_lengths_d, B, Tmax, Smax, nll_d, st); break;
+        case 6: launch_ctc_sweep<6>(w, ws, targets_d, input_lengths_d, target_lengths_d, B, Tmax, Smax, nll_d, st); break;
+        case 7: launch_ctc_sweep<7>(w, ws, targets_d, input_lengths_d, target_lengths_d, B, Tmax, Smax, nll_d, st); break;
+        default: launch_ctc_sweep<8>(w, ws, targets_d, input_lengths_d, target_lengths_d, B, Tmax, Smax, nll_d, st); break;
+    }
+    WR_CHECK_LAUNCH("ctc_sweep_kernel");
+    return WR_OK;
+}
+
+extern "C" int wr_ctc_loss_bwd(const void *logits_d, int dtype, const int32_t *targets_d,
+                               const int32_t *input_lengths_d, const int32_t *target_lengths_d, int B, int Tmax,
+                               int Smax, int V, int blank, const float *grad_nll_d, void *grads_d,
+                               const void *workspace_d, size_t workspace_bytes, void *stream)
+{
+    if (int rc = ctc_check(B, Tmax, Smax, V, blank)) return rc;
+    WR_REQUIRE(logits_d && input_lengths_d && target_lengths_d && grads_d && workspace_d, WR_EINVAL,
+               "ctc_loss_bwd: null pointer argument");
+    WR_REQUIRE(targets_d || Smax == 0, WR_EINVAL, "ctc_loss_bwd: targets is null");
+    WR_REQUIRE(dtype == WR_F32, WR_EUNSUPPORTED, "ctc_loss_bwd: dtype %d not supported (fp32 only)", dtype);
+    const CtcWs w = ctc_ws_layout(B, Tmax, Smax);
+    WR_REQUIRE(workspace_bytes >= w.total, WR_EWORKSPACE, "ctc_loss_bwd: workspace %zu < required %zu",
+               workspace_bytes, w.total);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const char *ws = static_cast<const char *>(workspace_d);
+    const int SmaxA = Smax > 0 ? Smax : 1;
+    hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)((long)B * Tmax)), dim3(256), (size_t)V * sizeof(float), st,
+                       static_cast<const float *>(logits_d), targets_d, input_lengths_d, target_lengths_d, B, Tmax,
+                       SmaxA, w.SP, V, blank, reinterpret_cast<const float *>(ws + w.denom_off),
+                       reinterpret_cast<const float *>(ws + w.lpb_off), reinterpret_cast<const float *>(ws + w.lpl_off),
+                       reinterpret_cast<const double *>(ws + w.alpha_off),
+                       reinterpret_cast<const double *>(ws + w.beta_off),
+                       reinterpret_cast<const double *>(ws + w.nll_off), grad_nll_d, static_cast<float *>(grads_d));
+    WR_CHECK_LAUNCH("ctc_grad_kernel");
+    return WR_OK;
+}

@@ -1,0 +1,114 @@
+"""CTC module with the reference's interface, backed by the HIP kernels.
+
+Mirror of ``wenet/transformer/ctc.py:21-84``: same constructor arguments, same
+parameter names (``ctc_lo.weight/bias`` so reference checkpoints load), same
+``forward(hs_pad, hlens, ys_pad, ys_lens)`` result
+(``CTCLoss(reduction='sum')(log_softmax(ctc_lo(dropout(hs_pad)))) / B``), same
+``log_softmax`` / ``argmax`` helpers.  The ``ctc_lo`` projection is a plain
+library GEMM (torch.nn.Linear on rocBLAS); log-softmax, the alpha/beta lattice
+and the gradient w.r.t. the projection output are the fused HIP path
+(``wr_ctc_loss_fwd/bwd``).  Quirk kept: ``F.dropout`` is called with its default
+``training=True`` (ctc.py:57), so a non-zero ``dropout_rate`` applies in eval too.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+
+class _CTCLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets, input_lengths, target_lengths, blank):
+        if not logits.is_cuda:
+            raise RuntimeError("wenet_celoss_amd.ctc_loss: logits must live on a HIP device "
+                               "(this package has no CPU path)")
+        lib = _lib.load()
+        B, T, V = logits.shape
+        S = targets.shape[1]
+        dev = logits.device
+        ws_bytes = lib.wr_ctc_workspace_bytes(B, T, S)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        nll = torch.empty(B, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.wr_ctc_loss_fwd(_lib.ptr(logits), _lib.dtype_code(logits.dtype), _lib.ptr(targets),
+                                     _lib.ptr(input_lengths), _lib.ptr(target_lengths), B, T, S, V, blank,
+                                     _lib.ptr(nll), _lib.ptr(ws), ws_bytes, _lib.current_stream(dev))
+        _lib.check(rc, "wr_ctc_loss_fwd")
+        ctx.save_for_backward(logits, targets, input_lengths, target_lengths, ws)
+        ctx.blank = blank
+        return nll
+
+    @staticmethod
+    def backward(ctx, grad_nll):
+        logits, targets, input_lengths, target_lengths, ws = ctx.saved_tensors
+        lib = _lib.load()
+        B, T, V = logits.shape
+        S = targets.shape[1]
+        dev = logits.device
+        grads = torch.empty_like(logits)
+        g = grad_nll.to(torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            rc = lib.wr_ctc_loss_bwd(_lib.ptr(logits), _lib.dtype_code(logits.dtype), _lib.ptr(targets),
+                                     _lib.ptr(input_lengths), _lib.ptr(target_lengths), B, T, S, V, ctx.blank,
+                                     _lib.ptr(g), _lib.ptr(grads), _lib.ptr(ws), ws.numel(), _lib.current_stream(dev))
+        _lib.check(rc, "wr_ctc_loss_bwd")
+        return grads, None, None, None, None
+
+
+def ctc_loss(logits: torch.Tensor, targets: torch.Tensor, input_lengths: torch.Tensor,
+             target_lengths: torch.Tensor, blank: int = 0, reduction: str = "sum") -> torch.Tensor:
+    """Fused log-softmax + CTC loss on batch-major pre-softmax activations.
+
+    logits (B, T, V) float32; targets (B, S) any integer dtype, padded with
+    anything (``IGNORE_ID`` = -1 in the reference, processor.py:722-724);
+    lengths (B,).  reduction: 'none' | 'sum' | 'mean' (mean as torch.nn.CTCLoss:
+    nll / target_length, then batch mean).
+    """
+    if reduction not in ("none", "sum", "mean"):
+        raise ValueError(f"{reduction} is not a valid value for reduction")
+    if logits.dim() != 3:
+        raise RuntimeError("ctc_loss: logits must be (batch, time, vocab)")
+    B = logits.size(0)
+    if targets.dim() == 1:
+        raise RuntimeError("ctc_loss: concatenated 1-D targets are not supported; pass (batch, max_len)")
+    if not (input_lengths.numel() == B and target_lengths.numel() == B and targets.size(0) == B):
+        raise RuntimeError("ctc_loss: batch size mismatch between logits, targets and lengths")
+    dev = logits.device
+    tg = targets.to(device=dev, dtype=torch.int32)
+    tg = torch.where(tg < 0, torch.zeros_like(tg), tg).contiguous()
+    if tg.size(1) == 0:
+        tg = torch.zeros(B, 1, dtype=torch.int32, device=dev)
+    il = input_lengths.to(device=dev, dtype=torch.int32).contiguous()
+    tl = target_lengths.to(device=dev, dtype=torch.int32).contiguous()
+    nll = _CTCLossFn.apply(logits.contiguous(), tg, il, tl, int(blank))
+    if reduction == "sum":
+        return nll.sum()
+    if reduction == "mean":
+        return (nll / tl.clamp(min=1).to(nll.dtype)).mean()
+    return nll
+
+
+class CTC(torch.nn.Module):
+    """CTC module (wenet/transformer/ctc.py:21-84)."""
+
+    def __init__(self, odim: int, encoder_output_size: int, dropout_rate: float = 0.0, reduce: bool = True):
+        super().__init__()
+        eprojs = encoder_output_size
+        self.dropout_rate = dropout_rate
+        self.ctc_lo = torch.nn.Linear(eprojs, odim)
+        self.reduction_type = "sum" if reduce else "none"
+
+    def forward(self, hs_pad: torch.Tensor, hlens: torch.Tensor, ys_pad: torch.Tensor,
+                ys_lens: torch.Tensor) -> torch.Tensor:
+        """hs_pad (B, Tmax, D), hlens (B), ys_pad (B, Lmax) padded with -1, ys_lens (B)."""
+        ys_hat = self.ctc_lo(F.dropout(hs_pad, p=self.dropout_rate))      # (B, T, V); ctc.py:57
+        loss = ctc_loss(ys_hat, ys_pad, hlens, ys_lens, blank=0, reduction=self.reduction_type)
+        return loss / ys_hat.size(0)                                        # batch-size average; ctc.py:63
+
+    def log_softmax(self, hs_pad: torch.Tensor) -> torch.Tensor:
+        return F.log_softmax(self.ctc_lo(hs_pad), dim=2)
+
+    def argmax(self, hs_pad: torch.Tensor) -> torch.Tensor:
+        return torch.argmax(self.ctc_lo(hs_pad), dim=2)
