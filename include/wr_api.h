@@ -126,6 +126,39 @@ int wr_ctc_loss_bwd(const void *logits_d, int dtype,
                     void *grads_d,
                     const void *workspace_d, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Transducer joint network (the one dense contraction on the path).
+ * Replaces TransducerJoint.forward, wenet/transducer/joint.py:45-70, from the
+ * point where the two pre-join projections exist:
+ *   ep = enc_ffn(enc) [B, T, J],  pp = pred_ffn(pred) [B, U1, J]   (joint.py:55-58)
+ *   out[b,t,u,:] = ffn_out(tanh(ep[b,t,:] + pp[b,u,:]))             (joint.py:60-69)
+ * w_out [V, J] and b_out [V] are ffn_out.weight / .bias in nn.Linear layout.
+ * fp32 throughout (exact-fp32 MFMA).  J a multiple of 4, at most 512.
+ * The activation tensor tanh(ep+pp) [B,T,U1,J] is never written to HBM in the
+ * forward pass.  If both length arrays are given, 64-cell tiles that lie wholly
+ * in the padded region (t >= T_b or u > U_b) are skipped and `out` is left
+ * untouched there -- the RNN-T loss never reads those cells.
+ *
+ * wr_joint_bwd_dz: dz[b,t,u,:] = (gout[b,t,u,:] @ w_out) * (1 - tanh(ep+pp)^2),
+ * zero in padded cells when lengths are given; h_d (optional, [B,T,U1,J])
+ * receives tanh(ep+pp) for the weight-gradient GEMM (dW = gout^T h), which --
+ * like d ep = sum_u dz and d pp = sum_t dz -- is a plain library reduction/GEMM
+ * on the host side.
+ * ---------------------------------------------------------------------- */
+size_t wr_joint_workspace_bytes(int J, int V);
+
+int wr_joint_fwd(const float *ep_d, const float *pp_d, const float *w_out_d, const float *b_out_d,
+                 const int32_t *logit_lengths_d /* nullable */, const int32_t *target_lengths_d /* nullable */,
+                 int B, int T, int U1, int J, int V,
+                 float *out_d /* [B,T,U1,V] */,
+                 void *workspace_d, size_t workspace_bytes, void *stream);
+
+int wr_joint_bwd_dz(const float *gout_d /* [B,T,U1,V] */, const float *ep_d, const float *pp_d,
+                    const float *w_out_d,
+                    const int32_t *logit_lengths_d /* nullable */, const int32_t *target_lengths_d /* nullable */,
+                    int B, int T, int U1, int J, int V,
+                    float *dz_d /* [B,T,U1,J] */, float *h_d /* [B,T,U1,J] or NULL */, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

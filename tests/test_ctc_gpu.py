@@ -83,13 +83,13 @@ def test_vs_torch_ctcloss_cpu_medium():
     rng = np.random.default_rng(2)
     logits, targets, ilens, tlens = make(rng, 8, 300, 60, 500, repeat=True)
     nll, grad = run_hip(logits, targets, ilens, tlens)
-    x = torch.tensor(logits, requires_grad=True)
+    x = torch.tensor(logits, dtype=torch.float64, requires_grad=True)   # ATen's own fp32 lattice is too noisy to check against
     lp = x.transpose(0, 1).log_softmax(2)
     ref = torch.nn.CTCLoss(reduction="none")(lp, torch.tensor(np.where(targets < 0, 0, targets)),
                                              torch.tensor(ilens.astype(np.int64)), torch.tensor(tlens.astype(np.int64)))
     ref.sum().backward()
     np.testing.assert_allclose(nll, ref.detach().numpy(), rtol=1e-5)
-    np.testing.assert_allclose(grad, x.grad.numpy(), rtol=1e-3, atol=2e-5)   # fp32 ATen lattice on the other side
+    np.testing.assert_allclose(grad, x.grad.numpy(), rtol=1e-4, atol=1e-5)
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "ctc_ref_*.npz"))))
@@ -111,7 +111,7 @@ def test_module_matches_reference_fixture(path):
         np.testing.assert_allclose(ctc.ctc_lo.bias.grad.cpu().numpy(), d["grad_b"], rtol=1e-4, atol=1e-4)
     else:
         assert np.isinf(loss.item())
-    np.testing.assert_allclose(ctc.log_softmax(hs.detach()).cpu().numpy(), d["log_softmax"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ctc.log_softmax(hs.detach()).detach().cpu().numpy(), d["log_softmax"], rtol=1e-5, atol=1e-5)
     assert (ctc.argmax(hs.detach()).cpu().numpy() == d["argmax"]).all()
 
 

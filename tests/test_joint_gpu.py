@@ -1,0 +1,114 @@
+"""Parity of the fused MFMA joiner (wr_joint_fwd / wr_joint_bwd_dz) with the
+fixtures produced by the reference's TransducerJoint (tests/golden/joint_ref_*.npz)
+and with a float64 torch evaluation of the same formula at larger shapes.
+Tolerance 1e-4 relative (north-star bar); exact-fp32 MFMA keeps us well inside."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def ref64(enc, pred, sd, gout=None):
+    """float64 torch evaluation of joint.py:55-69 (+ autograd)."""
+    t = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in sd.items()}
+    e = torch.tensor(enc, dtype=torch.float64, requires_grad=True)
+    p = torch.tensor(pred, dtype=torch.float64, requires_grad=True)
+    ep = e @ t["enc_ffn.weight"].T + t["enc_ffn.bias"]
+    pp = p @ t["pred_ffn.weight"].T + t["pred_ffn.bias"]
+    out = torch.tanh(ep[:, :, None] + pp[:, None]) @ t["ffn_out.weight"].T + t["ffn_out.bias"]
+    grads = None
+    if gout is not None:
+        out.backward(torch.tensor(gout, dtype=torch.float64))
+        grads = dict(enc=e.grad.numpy(), pred=p.grad.numpy(), **{k: v.grad.numpy() for k, v in t.items()})
+    return out.detach().numpy(), grads
+
+
+def build(sd, V, E, P, J):
+    import wenet_celoss_amd as w
+    m = w.TransducerJoint(V, E, P, J).to(DEV)
+    m.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
+    return m
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "joint_ref_*.npz"))))
+def test_matches_reference_fixture(path):
+    d = np.load(path)
+    sd = {k[2:]: d[k] for k in d.files if k.startswith("w_")}
+    V, J = sd["ffn_out.weight"].shape
+    E, P = sd["enc_ffn.weight"].shape[1], sd["pred_ffn.weight"].shape[1]
+    m = build(sd, V, E, P, J)
+    enc = torch.tensor(d["enc"], device=DEV, requires_grad=True)
+    pred = torch.tensor(d["pred"], device=DEV, requires_grad=True)
+    out = m(enc, pred)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), d["out"], rtol=1e-4, atol=1e-5)
+    out.backward(torch.tensor(d["gout"], device=DEV))
+    np.testing.assert_allclose(enc.grad.cpu().numpy(), d["grad_enc"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(pred.grad.cpu().numpy(), d["grad_pred"], rtol=1e-4, atol=1e-4)
+    for name, p in m.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), d["g_" + name], rtol=1e-4, atol=1e-4, err_msg=name)
+
+
+@pytest.mark.parametrize("B,T,U1,E,P,J,V", [
+    (2, 9, 5, 32, 24, 128, 300),      # V not a multiple of 256, one MFMA column tile per wave in backward
+    (1, 70, 3, 16, 16, 256, 1000),    # M = 210: a partial last 64-cell tile
+    (3, 11, 7, 64, 64, 512, 517),     # the shipped join_dim; V odd -> scalar dY staging path
+    (2, 13, 4, 8, 8, 36, 64),         # J not a multiple of 8/128 (zero-padded k depth)
+])
+def test_parity_float64(B, T, U1, E, P, J, V):
+    g = torch.Generator().manual_seed(B * 100 + T + J + V)
+    import wenet_celoss_amd as w
+    m = w.TransducerJoint(V, E, P, J)
+    sd = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+    m = m.to(DEV)
+    enc = torch.randn(B, T, E, generator=g); pred = torch.randn(B, U1, P, generator=g)
+    gout = torch.randn(B, T, U1, V, generator=g)
+    ro, rg = ref64(enc.numpy(), pred.numpy(), sd, gout.numpy())
+    e = enc.to(DEV).requires_grad_(True); p = pred.to(DEV).requires_grad_(True)
+    out = m(e, p)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ro, rtol=1e-4, atol=2e-5)
+    out.backward(gout.to(DEV))
+    scale = lambda a: 1e-4 * max(1.0, float(np.abs(a).max()))
+    np.testing.assert_allclose(e.grad.cpu().numpy(), rg["enc"], rtol=1e-4, atol=scale(rg["enc"]))
+    np.testing.assert_allclose(p.grad.cpu().numpy(), rg["pred"], rtol=1e-4, atol=scale(rg["pred"]))
+    for name, prm in m.named_parameters():
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), rg[name], rtol=1e-4, atol=scale(rg[name]), err_msg=name)
+
+
+def test_lengths_skip_padding_and_feed_rnnt_loss():
+    """With lengths, cells in the padded region are not computed; the loss and all
+    gradients are unchanged because the loss never reads them."""
+    import wenet_celoss_amd as w
+    torch.manual_seed(4)
+    B, T, U, E, P, J, V = 3, 80, 70, 16, 16, 128, 64
+    m = w.TransducerJoint(V, E, P, J).to(DEV)
+    enc = torch.randn(B, T, E, device=DEV); pred = torch.randn(B, U + 1, P, device=DEV)
+    y = torch.randint(1, V, (B, U), dtype=torch.int32, device=DEV)
+    ll = torch.tensor([80, 20, 5], dtype=torch.int32, device=DEV)
+    tl = torch.tensor([10, 70, 3], dtype=torch.int32, device=DEV)
+    res = []
+    for lens in (False, True):
+        m.zero_grad()
+        e = enc.clone().requires_grad_(True); p = pred.clone().requires_grad_(True)
+        logits = m(e, p, ll, tl) if lens else m(e, p)
+        loss = w.rnnt_loss(logits, y, ll, tl, blank=0, reduction="mean")
+        loss.backward()
+        res.append((loss.item(), e.grad.clone(), p.grad.clone(), m.ffn_out.weight.grad.clone()))
+    assert res[0][0] == pytest.approx(res[1][0], rel=1e-6)
+    for a, b in zip(res[0][1:], res[1][1:]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
+
+
+def test_unsupported_configuration_raises():
+    import wenet_celoss_amd as w
+    with pytest.raises(NotImplementedError):
+        w.TransducerJoint(10, 8, 8, 8, activation="relu")
+    m = w.TransducerJoint(10, 8, 8, 516).to(DEV)
+    with pytest.raises(RuntimeError, match="join_dim"):
+        m(torch.zeros(1, 2, 8, device=DEV), torch.zeros(1, 2, 8, device=DEV))

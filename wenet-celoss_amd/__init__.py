@@ -8,5 +8,6 @@ libwr_mi355x.so (include/wr_api.h).  There is no CPU fallback.
 from . import _lib  # noqa: F401
 from .rnnt_loss import rnnt_loss, RNNTLoss  # noqa: F401
 from .ctc import CTC, ctc_loss  # noqa: F401
+from .joint import TransducerJoint, joint_logits  # noqa: F401
 
-__all__ = ["rnnt_loss", "RNNTLoss", "CTC", "ctc_loss"]
+__all__ = ["rnnt_loss", "RNNTLoss", "CTC", "ctc_loss", "TransducerJoint", "joint_logits"]

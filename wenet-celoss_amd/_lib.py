@@ -94,6 +94,9 @@ SIGNATURES = {
     "wr_ctc_workspace_bytes": (_sz, [_i, _i, _i]),
     "wr_ctc_loss_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "wr_ctc_loss_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "wr_joint_workspace_bytes": (_sz, [_i, _i]),
+    "wr_joint_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "wr_joint_bwd_dz": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
 }
 
 

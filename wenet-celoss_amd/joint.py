@@ -1,0 +1,129 @@
+"""TransducerJoint with the reference's interface, backed by the MFMA kernels.
+
+Mirror of ``wenet/transducer/joint.py:9-70``: same constructor arguments and
+parameter names (``enc_ffn``, ``pred_ffn``, ``ffn_out`` -- reference checkpoints
+load unchanged), same ``forward(enc_out, pred_out) -> (B, T, U, V)``.
+
+The two pre-join projections are plain library GEMMs on small tensors
+(torch.nn.Linear on rocBLAS).  Everything after them -- broadcast add, tanh,
+the 512 -> V contraction and its backward w.r.t. the activations -- is the
+fused HIP path (``wr_joint_fwd`` / ``wr_joint_bwd_dz``).  The weight gradient
+``dW = dY^T H`` and the two reductions of ``dZ`` over u / t are library
+GEMM / sum calls.
+
+Supported configuration: the reference's shipped one (``joint_mode='add'``,
+``activation='tanh'``, ``postjoin_linear=False``,
+conf/encoder_bias_conformer_rnnt_*.yaml:21-26).  Anything else raises -- there
+is no silent fallback.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+
+
+class _JointFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ep, pp, w, b, llens, tlens):
+        if not ep.is_cuda:
+            raise RuntimeError("wenet_celoss_amd.TransducerJoint: tensors must live on a HIP device "
+                               "(this package has no CPU path)")
+        lib = _lib.load()
+        B, T, J = ep.shape
+        U1 = pp.shape[1]
+        V = w.shape[0]
+        dev = ep.device
+        ep, pp, w, b = ep.contiguous(), pp.contiguous(), w.contiguous(), b.contiguous()
+        out = torch.empty(B, T, U1, V, dtype=torch.float32, device=dev)
+        ws_bytes = lib.wr_joint_workspace_bytes(J, V)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.wr_joint_fwd(_lib.ptr(ep), _lib.ptr(pp), _lib.ptr(w), _lib.ptr(b), _lib.ptr(llens),
+                                  _lib.ptr(tlens), B, T, U1, J, V, _lib.ptr(out), _lib.ptr(ws), ws_bytes,
+                                  _lib.current_stream(dev))
+        _lib.check(rc, "wr_joint_fwd")
+        ctx.save_for_backward(ep, pp, w, llens, tlens)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        ep, pp, w, llens, tlens = ctx.saved_tensors
+        lib = _lib.load()
+        B, T, J = ep.shape
+        U1 = pp.shape[1]
+        V = w.shape[0]
+        dev = ep.device
+        gout = gout.contiguous()
+        dz = torch.empty(B, T, U1, J, dtype=torch.float32, device=dev)
+        need_w = ctx.needs_input_grad[2]
+        h = torch.empty_like(dz) if need_w else None
+        with torch.cuda.device(dev):
+            rc = lib.wr_joint_bwd_dz(_lib.ptr(gout), _lib.ptr(ep), _lib.ptr(pp), _lib.ptr(w), _lib.ptr(llens),
+                                     _lib.ptr(tlens), B, T, U1, J, V, _lib.ptr(dz), _lib.ptr(h),
+                                     _lib.current_stream(dev))
+        _lib.check(rc, "wr_joint_bwd_dz")
+        d_ep = dz.sum(dim=2)
+        d_pp = dz.sum(dim=1)
+        g2 = gout.view(-1, V)
+        if llens is not None:
+            # padded cells were skipped in forward: their incoming gradient must not leak into dW / db
+            tt = torch.arange(T, device=dev)[None, :, None] < llens[:, None, None]
+            uu = torch.arange(U1, device=dev)[None, None, :] <= tlens[:, None, None]
+            mask = (tt & uu).view(-1, 1)
+            g2 = torch.where(mask, g2, torch.zeros((), device=dev))
+        d_w = g2.t().mm(h.view(-1, J)) if need_w else None            # plain library GEMM (rocBLAS)
+        d_b = g2.sum(0) if ctx.needs_input_grad[3] else None
+        return d_ep, d_pp, d_w, d_b, None, None
+
+
+def joint_logits(ep: torch.Tensor, pp: torch.Tensor, w_out: torch.Tensor, b_out: torch.Tensor,
+                 logit_lengths: Optional[torch.Tensor] = None,
+                 target_lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ffn_out(tanh(ep[:, :, None] + pp[:, None])) -> (B, T, U1, V).  With lengths, cells in the
+    padded region are left unwritten (they are never read by the RNN-T loss)."""
+    if (logit_lengths is None) != (target_lengths is None):
+        raise RuntimeError("joint_logits: pass both length tensors or neither")
+    if logit_lengths is not None:
+        logit_lengths = logit_lengths.to(device=ep.device, dtype=torch.int32).contiguous()
+        target_lengths = target_lengths.to(device=ep.device, dtype=torch.int32).contiguous()
+    return _JointFn.apply(ep, pp, w_out, b_out, logit_lengths, target_lengths)
+
+
+class TransducerJoint(nn.Module):
+    """wenet/transducer/joint.py:9-70."""
+
+    def __init__(self, voca_size: int, enc_output_size: int, pred_output_size: int, join_dim: int,
+                 prejoin_linear: bool = True, postjoin_linear: bool = False, joint_mode: str = "add",
+                 activation: str = "tanh"):
+        assert joint_mode in ["add"]
+        super().__init__()
+        if activation != "tanh" or postjoin_linear:
+            raise NotImplementedError("wenet_celoss_amd.TransducerJoint implements the shipped configuration "
+                                      "(activation='tanh', postjoin_linear=False); got "
+                                      f"activation={activation!r}, postjoin_linear={postjoin_linear}")
+        self.prejoin_linear = prejoin_linear
+        self.postjoin_linear = postjoin_linear
+        self.joint_mode = joint_mode
+        if not self.prejoin_linear and not self.postjoin_linear:
+            assert enc_output_size == pred_output_size == join_dim
+        self.enc_ffn: Optional[nn.Linear] = None
+        self.pred_ffn: Optional[nn.Linear] = None
+        if self.prejoin_linear:
+            self.enc_ffn = nn.Linear(enc_output_size, join_dim)
+            self.pred_ffn = nn.Linear(pred_output_size, join_dim)
+        self.post_ffn: Optional[nn.Linear] = None
+        self.ffn_out = nn.Linear(join_dim, voca_size)
+
+    def forward(self, enc_out: torch.Tensor, pred_out: torch.Tensor,
+                logit_lengths: Optional[torch.Tensor] = None,
+                target_lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """enc_out (B, T, E), pred_out (B, U, P) -> (B, T, U, V).  The optional lengths are an
+        extension (skip cells the loss never reads); the reference call passes none."""
+        if self.prejoin_linear and self.enc_ffn is not None and self.pred_ffn is not None:
+            enc_out = self.enc_ffn(enc_out)
+            pred_out = self.pred_ffn(pred_out)
+        return joint_logits(enc_out, pred_out, self.ffn_out.weight, self.ffn_out.bias, logit_lengths, target_lengths)
