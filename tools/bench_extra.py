@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Secondary measurements (SURVEY.md 8d "Secondary"): joiner TFLOP/s, CTC loss+grad utt/s.
+Not the headline metric (bench.py is); prints one JSON line per measurement."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def timeit(fn, steps, warmup=1):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in ev)
+    return ts[len(ts) // 2]
+
+
+def bench_joint(args):
+    from wenet_celoss_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    B, T, U1, J, V = args.B, args.T, args.U + 1, 512, args.V
+    ep = torch.randn(B, T, J, device=dev); pp = torch.randn(B, U1, J, device=dev)
+    w = torch.randn(V, J, device=dev) * 0.05; b = torch.randn(V, device=dev)
+    out = torch.empty(B, T, U1, V, device=dev)
+    ws_bytes = lib.wr_joint_workspace_bytes(J, V)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    st = _lib.current_stream(dev); P = _lib.ptr
+    f = lambda: _lib.check(lib.wr_joint_fwd(P(ep), P(pp), P(w), P(b), None, None, B, T, U1, J, V, P(out), P(ws), ws_bytes, st))
+    ms = timeit(f, args.steps)
+    flops = 2.0 * B * T * U1 * J * V
+    print(json.dumps({"what": "joint_fwd", "shape": [B, T, U1, J, V], "ms": round(ms, 3),
+                      "TFLOPs": round(flops / ms / 1e9, 2), "peak_f32_mfma": 157.3,
+                      "frac": round(flops / ms / 1e9 / 157.3, 4)}), flush=True)
+    dz = torch.empty(B, T, U1, J, device=dev); h = torch.empty_like(dz)
+    g = lambda: _lib.check(lib.wr_joint_bwd_dz(P(out), P(ep), P(pp), P(w), None, None, B, T, U1, J, V, P(dz), P(h), st))
+    ms = timeit(g, args.steps)
+    print(json.dumps({"what": "joint_bwd_dz", "shape": [B, T, U1, J, V], "ms": round(ms, 3),
+                      "TFLOPs": round(flops / ms / 1e9, 2), "frac": round(flops / ms / 1e9 / 157.3, 4)}), flush=True)
+    if args.dw:
+        g2 = out.view(-1, V)
+        k = lambda: g2.t().mm(h.view(-1, J))
+        ms = timeit(k, max(1, args.steps // 2))
+        print(json.dumps({"what": "joint_dW_rocblas", "ms": round(ms, 3), "TFLOPs": round(flops / ms / 1e9, 2)}), flush=True)
+
+
+def bench_ctc(args):
+    import wenet_celoss_amd as wc
+    from wenet_celoss_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    B, T, S, V = 32, 1000, 150, 5000
+    x = torch.randn(B, T, V, device=dev)
+    y = torch.randint(1, V, (B, S), dtype=torch.int32, device=dev)
+    il = torch.full((B,), T, dtype=torch.int32, device=dev); tl = torch.full((B,), S, dtype=torch.int32, device=dev)
+    ws_bytes = lib.wr_ctc_workspace_bytes(B, T, S)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    nll = torch.empty(B, device=dev); g = torch.empty_like(x); go = torch.full((B,), 1.0 / B, device=dev)
+    st = _lib.current_stream(dev); P = _lib.ptr
+
+    def step():
+        _lib.check(lib.wr_ctc_loss_fwd(P(x), 0, P(y), P(il), P(tl), B, T, S, V, 0, P(nll), P(ws), ws_bytes, st))
+        _lib.check(lib.wr_ctc_loss_bwd(P(x), 0, P(y), P(il), P(tl), B, T, S, V, 0, P(go), P(g), P(ws), ws_bytes, st))
+    ms = timeit(step, 20, warmup=3)
+    # CPU reference, exactly the reference's call (ctc.py:60-61), on the host cores
+    import time
+    xc = x.cpu().requires_grad_(True)
+    torch.set_num_threads(min(os.cpu_count(), 16))
+    t0 = time.perf_counter()
+    for _ in range(3):
+        lp = xc.transpose(0, 1).log_softmax(2)
+        l = torch.nn.CTCLoss(reduction="sum")(lp, y.cpu().long(), il.cpu().long(), tl.cpu().long()) / B
+        l.backward()
+    cpu_ms = (time.perf_counter() - t0) / 3 * 1e3
+    print(json.dumps({"what": "ctc_loss+grad", "shape": [B, T, S, V], "ms": round(ms, 4), "utt_per_s": round(B / ms * 1e3, 1),
+                      "GBps_algorithmic(3*4*T*B*V)": round(3 * 4.0 * T * B * V / ms / 1e6, 1),
+                      "steps_per_s": round(T / ms * 1e3), "cpu_torch_ctcloss_ms": round(cpu_ms, 1),
+                      "cpu_utt_per_s": round(B / cpu_ms * 1e3, 1), "cpu_threads": torch.get_num_threads()}), flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["joint", "ctc"])
+    ap.add_argument("--B", type=int, default=32)
+    ap.add_argument("--T", type=int, default=1000)
+    ap.add_argument("--U", type=int, default=150)
+    ap.add_argument("--V", type=int, default=5000)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--dw", action="store_true")
+    a = ap.parse_args()
+    {"joint": bench_joint, "ctc": bench_ctc}[a.what](a)
