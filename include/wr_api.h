@@ -159,6 +159,83 @@ int wr_joint_bwd_dz(const float *gout_d /* [B,T,U1,V] */, const float *ep_d, con
                     int B, int T, int U1, int J, int V,
                     float *dz_d /* [B,T,U1,J] */, float *h_d /* [B,T,U1,J] or NULL */, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Transducer decoding: batched greedy search, batched prefix beam search and
+ * the predictor step API, with every per-step operation on the device.
+ *
+ * Replaces
+ *   greedy  wenet/transducer/search/greedy_search copy.py:6-63 -- the upstream core loop behind
+ *           Transducer.greedy_search (wenet/transducer/transducer.py:515-598)
+ *   beam    PrefixBeamSearch.prefix_beam_search, wenet/transducer/search/prefix_beam_search.py:42-148
+ *           (called from Transducer.beam_search, transducer.py:332-377)
+ *   step    RNNPredictor.forward_step, wenet/transducer/predictor.py:160-200, and the joiner for
+ *           step shapes (joint.py:45-70), i.e. forward_predictor_step / forward_joint_step
+ *           (transducer.py:613-629)
+ *
+ * Weights are passed in the reference modules' own (nn.Linear / nn.LSTM / nn.Embedding) layouts;
+ * wr_decoder_create re-lays them out k-major once into the caller's workspace.
+ * The decoder handle owns no device memory; it holds the launch configuration, the captured
+ * hipGraphs of the micro-steps and an internal work stream that is ordered against the caller's
+ * stream with events (no device-wide synchronisation).  wr_greedy_search synchronises its own work
+ * stream once every 16 micro-steps to test the "lanes still decoding" word (the reference
+ * synchronises on every step); wr_prefix_beam_search and wr_predictor_step never do.
+ * Limits: lanes <= 128, vocabulary <= 16384, LSTM layers <= 4, beam <= 16, layer widths <= 1024.
+ * ---------------------------------------------------------------------- */
+#define WR_MAX_LSTM_LAYERS 4
+
+typedef struct wr_transducer_weights {
+    int32_t vocab_size;   /* V */
+    int32_t enc_dim;      /* E: encoder output size */
+    int32_t pred_dim;     /* P: predictor output size (RNNPredictor.projection out) */
+    int32_t embed_dim;    /* D */
+    int32_t hidden;       /* H: LSTM hidden size */
+    int32_t n_layers;     /* L */
+    int32_t join_dim;     /* J */
+    int32_t reserved;
+    const float *embed;                        /* predictor.embed.weight       [V, D] */
+    const float *w_ih[WR_MAX_LSTM_LAYERS];     /* predictor.rnn.weight_ih_l{k} [4H, D or H], gate order i,f,g,o */
+    const float *w_hh[WR_MAX_LSTM_LAYERS];     /* predictor.rnn.weight_hh_l{k} [4H, H] */
+    const float *b_ih[WR_MAX_LSTM_LAYERS];     /* predictor.rnn.bias_ih_l{k}   [4H] */
+    const float *b_hh[WR_MAX_LSTM_LAYERS];     /* predictor.rnn.bias_hh_l{k}   [4H] */
+    const float *proj_w, *proj_b;              /* predictor.projection         [P, H], [P] */
+    const float *enc_ffn_w, *enc_ffn_b;        /* joint.enc_ffn                [J, E], [J] */
+    const float *pred_ffn_w, *pred_ffn_b;      /* joint.pred_ffn               [J, P], [J] */
+    const float *out_w, *out_b;                /* joint.ffn_out                [V, J], [V] */
+} wr_transducer_weights;
+
+typedef struct wr_decoder wr_decoder;
+
+size_t wr_decoder_workspace_bytes(const wr_transducer_weights *w, int max_lanes, int max_utt, int Tmax,
+                                  int max_hyp, int max_beam);
+
+/* max_lanes: streams decoded together (greedy) or utterances x beam (beam search);
+ * max_utt: utterances per call; Tmax: encoder frames; max_hyp: greedy hypothesis capacity. */
+int wr_decoder_create(const wr_transducer_weights *w, int max_lanes, int max_utt, int Tmax, int max_hyp,
+                      int max_beam, void *workspace_d, size_t workspace_bytes, void *stream,
+                      wr_decoder **out);
+int wr_decoder_destroy(wr_decoder *h);
+int wr_decoder_set_graph(wr_decoder *h, int enable /* 0: plain launches instead of hipGraph replay */);
+
+/* enc_out [N, T, E] fp32, enc_lens [N]; hyps [N, max_hyp] / hyp_lens [N] out (tokens beyond
+ * max_hyp are counted in hyp_lens but not stored).  Each lane follows the reference loop exactly:
+ * predictor stepped only after a non-blank, at most n_steps emissions per frame. */
+int wr_greedy_search(wr_decoder *h, const float *enc_out_d, const int32_t *enc_lens_d, int N, int T,
+                     int n_steps, int blank, int32_t *hyps_d, int32_t *hyp_lens_d, void *stream);
+
+/* enc_out [B, T, E], ctc_logp [B, T, V] = log_softmax(ctc_lo(enc_out)) (ctc.py:66-75).
+ * Out: hyps [B, beam, Tmax+1] (each begins with the seed blank, padded with -1), hyp_lens [B, beam],
+ * scores [B, beam] float64 (best first), n_hyps [B]. */
+int wr_prefix_beam_search(wr_decoder *h, const float *enc_out_d, const int32_t *enc_lens_d,
+                          const float *ctc_logp_d, int B, int T, int beam, float ctc_weight,
+                          float transducer_weight, int blank, int32_t *hyps_d, int32_t *hyp_lens_d,
+                          double *scores_d, int32_t *n_hyps_d, void *stream);
+
+/* One predictor step for N lanes: tokens [N], cache_h / cache_c [L, N, H] in;
+ * out [N, P], new_h / new_c [L, N, H] out (padding is applied by the caller, predictor.py:9-15). */
+int wr_predictor_step(wr_decoder *h, const int32_t *tokens_d, const float *cache_h_d,
+                      const float *cache_c_d, int N, float *out_d, float *new_h_d, float *new_c_d,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,7 +97,29 @@ SIGNATURES = {
     "wr_joint_workspace_bytes": (_sz, [_i, _i]),
     "wr_joint_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "wr_joint_bwd_dz": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "wr_decoder_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i, _i]),
+    "wr_decoder_create": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
+    "wr_decoder_destroy": (_i, [_vp]),
+    "wr_decoder_set_graph": (_i, [_vp, _i]),
+    "wr_greedy_search": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "wr_prefix_beam_search": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "wr_predictor_step": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
 }
+
+
+class TransducerWeights(ctypes.Structure):
+    """ctypes mirror of `wr_transducer_weights` (include/wr_api.h)."""
+    _MAXL = 4
+    _fields_ = [("vocab_size", ctypes.c_int32), ("enc_dim", ctypes.c_int32), ("pred_dim", ctypes.c_int32),
+                ("embed_dim", ctypes.c_int32), ("hidden", ctypes.c_int32), ("n_layers", ctypes.c_int32),
+                ("join_dim", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("embed", ctypes.c_void_p),
+                ("w_ih", ctypes.c_void_p * 4), ("w_hh", ctypes.c_void_p * 4),
+                ("b_ih", ctypes.c_void_p * 4), ("b_hh", ctypes.c_void_p * 4),
+                ("proj_w", ctypes.c_void_p), ("proj_b", ctypes.c_void_p),
+                ("enc_ffn_w", ctypes.c_void_p), ("enc_ffn_b", ctypes.c_void_p),
+                ("pred_ffn_w", ctypes.c_void_p), ("pred_ffn_b", ctypes.c_void_p),
+                ("out_w", ctypes.c_void_p), ("out_b", ctypes.c_void_p)]
 
 
 def load():

@@ -1,0 +1,1100 @@
+// Transducer decoding on MI355X (gfx950): batched greedy search and batched
+// prefix beam search with every per-step operation on the device.
+//
+// Replaces (semantics: SURVEY.md App. A.3 / A.4)
+//   greedy   wenet/transducer/search/greedy_search copy.py:6-63  (the upstream core loop that
+//            Transducer.greedy_search dispatches to, transducer.py:515-598)
+//   beam     wenet/transducer/search/prefix_beam_search.py:42-148 (PrefixBeamSearch)
+//   step API wenet/transducer/predictor.py:160-200 (RNNPredictor.forward_step, LSTM cell x L +
+//            projection) and wenet/transducer/joint.py:45-70 for step shapes.
+//
+// The reference runs ONE utterance at a time from Python with a host<->device
+// sync on every step (.item()).  Here `lanes` (independent streams for greedy;
+// utterances x beam hypotheses for beam search) advance together, one
+// micro-step = five small kernels with all control state in device memory:
+//
+//   lstm_step_kernel (x L)  predicated per lane: embed/LSTM cell -> new cache
+//   proj_step_kernel        projection + pred_ffn; writes the joiner activation
+//                           tanh(enc_ffn(enc)[t] + pred_ffn(pred)) k-major
+//   joint_step_kernel       logits[lane, :] = ffn_out(activation): exact-fp32 MFMA
+//                           (32x32x2), lanes x 32 vocabulary columns per workgroup,
+//                           K split over the 4 waves, operands read k-major
+//                           straight from L2 (weights are pre-transposed once)
+//   greedy_update_kernel    log-softmax + argmax (first index on ties) + the
+//                           frame/emission state machine + cache commit
+//   beam_topk_kernel /      log-softmax, CTC mixture, top-k in LDS; per-utterance
+//   beam_update_kernel      expansion, prefix fusion (float64 log_add), stable prune
+//
+// Micro-steps are replayed from a hipGraph (captured once per decoder handle) so
+// the host only checks a "lanes still active" word every few dozen steps.
+#include "wr_common.hpp"
+
+#include <math.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+namespace wr {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMaxLayers = WR_MAX_LSTM_LAYERS;
+constexpr int kLG = 8;            // lanes per workgroup in the LSTM step
+constexpr int kMaxBeam = 16;
+constexpr int kStepsPerGraph = 16;
+
+struct Dims {
+    int V, E, P, D, H, L, J;      // vocab, encoder dim, predictor out dim, embed dim, hidden, layers, join dim
+    int Jp, Vp;                   // J padded to 8, V padded to 256 (k-major joiner weight)
+    int NL, NLp;                  // lanes, lanes padded to 32
+};
+
+// Device-resident decoder state; all pointers are carved from the caller's workspace.
+struct DevState {
+    Dims d;
+    // transposed (k-major) weights
+    const float *embed;
+    float *wt_ih[kMaxLayers], *wt_hh[kMaxLayers], *bsum[kMaxLayers];
+    float *proj_wt, *predffn_wt, *encffn_wt, *out_wt;
+    const float *proj_b, *predffn_b, *encffn_b, *out_b;
+    // per-call inputs
+    const float *enc;             // [n_utt, T, E]
+    const int32_t *enc_lens;      // [n_utt]
+    const float *ctc_logp;        // [n_utt, T, V] (beam only)
+    int n_utt, T, lanes_per_utt, n_lanes;
+    // lane state
+    float *ep_all;                // [n_utt, T, J]
+    int32_t *token, *lane_t, *noblk, *need_pred, *lane_active;
+    float *cache_h, *cache_c;     // [L, NL, H] committed state
+    float *new_h, *new_c;         // [L, NL, H] output of the last predictor step
+    float *pred_out;              // [NL, P]  projected predictor output (step API)
+    float *pp;                    // [NL, J]
+    float *ht;                    // [Jp, NLp]  joiner activation, k-major
+    float *logits;                // [NL, V]
+    int32_t *active_count;        // lanes still decoding
+    // greedy outputs / params
+    int32_t *hyps;                // [NL, max_hyp]
+    int32_t *hyp_lens;
+    int max_hyp, n_steps, blank;
+    // beam state
+    int beam;
+    float ctc_weight, tr_weight;
+    float *topv;                  // [NL, beam]
+    int32_t *topi;
+    float *alt_h, *alt_c;         // second committed-cache buffer (beam reorders hypotheses)
+    int32_t *cache_sel;           // [n_utt] which committed buffer is current (0/1)
+    int32_t *bhyps;               // [2, n_utt, beam, Lmax]
+    int32_t *bhyp_lens;           // [2, n_utt, beam]
+    double *bscores;              // [n_utt, beam]
+    int32_t *n_hyps;              // [n_utt]
+    int32_t *frame;               // [n_utt]
+    int32_t *hyp_sel;             // [n_utt]
+    int Lmax;
+};
+
+// ----------------------------------------------------------------- setup --
+// src [R][C] row-major -> dst [C][Rp] (zero padded columns R..Rp-1 and rows C..Cp-1)
+__global__ void transpose_pad_kernel(const float *__restrict__ src, int R, int C, int Rp, int Cp, float *__restrict__ dst)
+{
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? src[(size_t)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < Cp && r < Rp) dst[(size_t)c * Rp + r] = tile[tx][i];
+    }
+}
+
+__global__ void add_bias_kernel(const float *a, const float *b, int n, float *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+
+// ep_all[row, :] = enc[row, :] @ enc_ffn^T + b     (rows = n_utt * T)
+__global__ __launch_bounds__(256) void ep_all_kernel(DevState *s)
+{
+    extern __shared__ float xs[];              // [8][E]
+    const Dims &d = s->d;
+    const long rows = (long)s->n_utt * s->T;
+    const long r0 = (long)blockIdx.x * 8;
+    for (int i = threadIdx.x; i < 8 * d.E; i += blockDim.x) {
+        const long r = r0 + i / d.E;
+        xs[i] = (r < rows) ? s->enc[(size_t)r * d.E + i % d.E] : 0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < d.J; j += blockDim.x) {
+        float acc[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+        for (int k = 0; k < d.E; ++k) {
+            const float w = s->encffn_wt[(size_t)k * d.J + j];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] = fmaf(w, xs[r * d.E + k], acc[r]);
+        }
+        const float b = s->encffn_b[j];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (r0 + r < rows) s->ep_all[(size_t)(r0 + r) * d.J + j] = acc[r] + b;
+    }
+}
+
+// --------------------------------------------------------- predictor step --
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// grid (ceil(H/32), ceil(n_lanes/kLG)), 128 threads: thread r -> gate r/32, hidden unit blockIdx.x*32 + r%32
+__global__ __launch_bounds__(128) void lstm_step_kernel(DevState *s, int layer)
+{
+    extern __shared__ float sm[];
+    const Dims &d = s->d;
+    const int in_dim = (layer == 0) ? d.D : d.H;
+    float *xh = sm;                               // [kLG][in_dim + H]
+    float *gates = sm + kLG * (in_dim + d.H);     // [kLG][128]
+    const int n0 = blockIdx.y * kLG;
+    const int tid = threadIdx.x;
+    const int NLH = d.NL * d.H;
+
+    int need_any = 0;
+    for (int g = 0; g < kLG; ++g) {
+        const int n = n0 + g;
+        if (n < s->n_lanes && s->lane_active[n] && s->need_pred[n]) need_any = 1;
+    }
+    if (!need_any) return;
+
+    for (int g = 0; g < kLG; ++g) {
+        const int n = n0 + g;
+        const bool on = (n < s->n_lanes) && s->lane_active[n] && s->need_pred[n];
+        const float *x = nullptr;
+        if (on) x = (layer == 0) ? s->embed + (size_t)s->token[n] * d.D
+                                 : s->new_h + (size_t)(layer - 1) * NLH + (size_t)n * d.H;
+        const float *h = on ? s->cache_h + (size_t)layer * NLH + (size_t)n * d.H : nullptr;
+        for (int k = tid; k < in_dim; k += 128) xh[g * (in_dim + d.H) + k] = on ? x[k] : 0.f;
+        for (int k = tid; k < d.H; k += 128) xh[g * (in_dim + d.H) + in_dim + k] = on ? h[k] : 0.f;
+    }
+    __syncthreads();
+    const int gate = tid >> 5, unit = blockIdx.x * 32 + (tid & 31);
+    const int row = gate * d.H + unit;
+    const int G4 = 4 * d.H;
+    float acc[kLG];
+#pragma unroll
+    for (int g = 0; g < kLG; ++g) acc[g] = 0.f;
+    if (unit < d.H) {
+        const float *wi = s->wt_ih[layer] + row;
+        for (int k = 0; k < in_dim; ++k) {
+            const float w = wi[(size_t)k * G4];
+#pragma unroll
+            for (int g = 0; g < kLG; ++g) acc[g] = fmaf(w, xh[g * (in_dim + d.H) + k], acc[g]);
+        }
+        const float *wh = s->wt_hh[layer] + row;
+        for (int k = 0; k < d.H; ++k) {
+            const float w = wh[(size_t)k * G4];
+#pragma unroll
+            for (int g = 0; g < kLG; ++g) acc[g] = fmaf(w, xh[g * (in_dim + d.H) + in_dim + k], acc[g]);
+        }
+        const float b = s->bsum[layer][row];
+#pragma unroll
+        for (int g = 0; g < kLG; ++g) gates[g * 128 + tid] = acc[g] + b;
+    }
+    __syncthreads();
+    for (int w = tid; w < kLG * 32; w += 128) {
+        const int g = w >> 5, u = w & 31;
+        const int n = n0 + g, un = blockIdx.x * 32 + u;
+        if (n >= s->n_lanes || un >= d.H) continue;
+        if (!(s->lane_active[n] && s->need_pred[n])) continue;
+        const float ig = sigmoidf_(gates[g * 128 + u]);
+        const float fg = sigmoidf_(gates[g * 128 + 32 + u]);
+        const float gg = tanhf(gates[g * 128 + 64 + u]);
+        const float og = sigmoidf_(gates[g * 128 + 96 + u]);
+        const size_t o = (size_t)layer * NLH + (size_t)n * d.H + un;
+        const float c = fg * s->cache_c[o] + ig * gg;
+        s->new_c[o] = c;
+        s->new_h[o] = og * tanhf(c);
+    }
+}
+
+// one workgroup per lane: projection + pred_ffn (if the predictor stepped), then the joiner activation
+__global__ __launch_bounds__(256) void proj_step_kernel(DevState *s)
+{
+    extern __shared__ float sm[];                 // [H] + [P]
+    const Dims &d = s->d;
+    const int n = blockIdx.x;
+    const int tid = threadIdx.x;
+    const bool active = s->lane_active[n] != 0;
+    if (active && s->need_pred[n]) {
+        float *hv = sm, *ov = sm + d.H;
+        const float *h = s->new_h + (size_t)(d.L - 1) * d.NL * d.H + (size_t)n * d.H;
+        for (int k = tid; k < d.H; k += 256) hv[k] = h[k];
+        __syncthreads();
+        for (int p = tid; p < d.P; p += 256) {
+            float a = 0.f;
+            for (int k = 0; k < d.H; ++k) a = fmaf(s->proj_wt[(size_t)k * d.P + p], hv[k], a);
+            ov[p] = a + s->proj_b[p];
+            s->pred_out[(size_t)n * d.P + p] = ov[p];
+        }
+        __syncthreads();
+        for (int j = tid; j < d.J; j += 256) {
+            float a = 0.f;
+            for (int k = 0; k < d.P; ++k) a = fmaf(s->predffn_wt[(size_t)k * d.J + j], ov[k], a);
+            s->pp[(size_t)n * d.J + j] = a + s->predffn_b[j];
+        }
+        __syncthreads();
+    }
+    // joiner activation for this lane's current frame (zero for idle lanes so the MFMA tile stays finite)
+    const int utt = n / s->lanes_per_utt;
+    const int t = s->lane_t[n];
+    const float *ep = s->ep_all + ((size_t)utt * s->T + (t < s->T ? t : s->T - 1)) * d.J;
+    for (int j = tid; j < d.Jp; j += 256) {
+        float v = 0.f;
+        if (active && j < d.J) v = tanhf(ep[j] + s->pp[(size_t)n * d.J + j]);
+        s->ht[(size_t)j * d.NLp + n] = v;
+    }
+}
+
+// logits[lane, v] = sum_k ht[k][lane] * out_wt[k][v] + b[v]; one workgroup per 32 vocabulary columns
+template <int MT /* 32-lane tiles */>
+__global__ __launch_bounds__(256) void joint_step_kernel(DevState *s)
+{
+    __shared__ float red[4][MT][32 * 32];
+    const Dims &d = s->d;
+    const int v0 = blockIdx.x * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int kq = d.Jp / 4;                      // Jp is a multiple of 8 -> each quarter is even
+    const int kb = wave * kq;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = (f32x16){0};
+    const float *__restrict__ A = s->ht + (size_t)(kb + half) * d.NLp + l31;
+    const float *__restrict__ Bm = s->out_wt + (size_t)(kb + half) * d.Vp + v0 + l31;
+#pragma unroll 4
+    for (int k = 0; k < kq; k += 2) {
+        const float b = Bm[(size_t)k * d.Vp];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float a = A[(size_t)k * d.NLp + m * 32];
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[m], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            red[wave][m][row * 32 + l31] = acc[m][r];
+        }
+    __syncthreads();
+    for (int i = tid; i < MT * 1024; i += 256) {
+        const int m = i >> 10, rc = i & 1023;
+        const int n = m * 32 + (rc >> 5), v = v0 + (rc & 31);
+        if (n < s->n_lanes && v < d.V)
+            s->logits[(size_t)n * d.V + v] = (red[0][m][rc] + red[1][m][rc]) + (red[2][m][rc] + red[3][m][rc]) + s->out_b[v];
+    }
+}
+
+// ---------------------------------------------------------------- greedy --
+__global__ void greedy_init_kernel(DevState *s)
+{
+    const Dims &d = s->d;
+    const int n = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < d.L * d.H; i += blockDim.x) {
+        const int l = i / d.H, k = i % d.H;
+        const size_t o = (size_t)l * d.NL * d.H + (size_t)n * d.H + k;
+        s->cache_h[o] = 0.f; s->cache_c[o] = 0.f; s->new_h[o] = 0.f; s->new_c[o] = 0.f;
+    }
+    for (int j = tid; j < d.J; j += blockDim.x) s->pp[(size_t)n * d.J + j] = 0.f;
+    if (tid == 0) {
+        const int T = s->enc_lens[n] < s->T ? s->enc_lens[n] : s->T;
+        s->token[n] = s->blank;
+        s->lane_t[n] = 0;
+        s->noblk[n] = 0;
+        s->need_pred[n] = 1;
+        s->hyp_lens[n] = 0;
+        const int act = T > 0;
+        s->lane_active[n] = act;
+        if (act) atomicAdd(s->active_count, 1);
+    }
+}
+
+// block-wide argmax with "first index on ties"
+__device__ __forceinline__ void block_argmax(float &val, int &idx, float *sv, int *si)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(val, o, kWave);
+        const int oi = __shfl_xor(idx, o, kWave);
+        if (ov > val || (ov == val && oi < idx)) { val = ov; idx = oi; }
+    }
+    if (lane == 0) { sv[wave] = val; si[wave] = idx; }
+    __syncthreads();
+    const int nw = blockDim.x >> 6;
+    val = sv[0]; idx = si[0];
+    for (int w = 1; w < nw; ++w)
+        if (sv[w] > val || (sv[w] == val && si[w] < idx)) { val = sv[w]; idx = si[w]; }
+    __syncthreads();
+}
+
+__device__ __forceinline__ float block_max(float v, float *sv)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    v = wave_max(v);
+    if (lane == 0) sv[wave] = v;
+    __syncthreads();
+    float r = sv[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = fmaxf(r, sv[w]);
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ float block_sum(float v, float *sv)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    v = wave_sum(v);
+    if (lane == 0) sv[wave] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += sv[w];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void greedy_update_kernel(DevState *s)
+{
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    __shared__ int s_commit;
+    const Dims &d = s->d;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    if (!s->lane_active[n]) return;
+    const float *x = s->logits + (size_t)n * d.V;
+    // log_softmax as the reference evaluates it: (x - max) - log(sum(exp(x - max)))
+    float m = -3.0e38f;
+    for (int v = tid; v < d.V; v += 256) m = fmaxf(m, x[v]);
+    m = block_max(m, sv);
+    float sum = 0.f;
+    for (int v = tid; v < d.V; v += 256) sum += expf(x[v] - m);
+    sum = block_sum(sum, sv);
+    const float ls = logf(sum);
+    float best = -3.0e38f;
+    int bi = 0x7fffffff;
+    for (int v = tid; v < d.V; v += 256) {
+        const float lp = (x[v] - m) - ls;
+        if (lp > best) { best = lp; bi = v; }      // strided ascending scan keeps the lowest index per thread
+    }
+    block_argmax(best, bi, sv, si);
+    const int k = bi;
+    if (tid == 0) {
+        int t = s->lane_t[n], nb = s->noblk[n];
+        int commit = 0;
+        if (k != s->blank) {
+            const int len = s->hyp_lens[n];
+            if (len < s->max_hyp) s->hyps[(size_t)n * s->max_hyp + len] = k;
+            s->hyp_lens[n] = len + 1;
+            s->need_pred[n] = 1;
+            nb += 1;
+            s->token[n] = k;
+            commit = 1;
+        }
+        if (k == s->blank || nb >= s->n_steps) {
+            if (k == s->blank) s->need_pred[n] = 0;
+            t += 1;
+            nb = 0;
+        }
+        s->lane_t[n] = t;
+        s->noblk[n] = nb;
+        const int T = s->enc_lens[n] < s->T ? s->enc_lens[n] : s->T;
+        if (t >= T) {
+            s->lane_active[n] = 0;
+            atomicSub(s->active_count, 1);
+        }
+        s_commit = commit;
+    }
+    __syncthreads();
+    if (s_commit) {                                // cache = new_cache (greedy_search copy.py:52)
+        for (int i = tid; i < d.L * d.H; i += 256) {
+            const int l = i / d.H, kk = i % d.H;
+            const size_t o = (size_t)l * d.NL * d.H + (size_t)n * d.H + kk;
+            s->cache_h[o] = s->new_h[o];
+            s->cache_c[o] = s->new_c[o];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ beam --
+__global__ void beam_init_kernel(DevState *s)
+{
+    const Dims &d = s->d;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int b = n / s->beam, j = n % s->beam;
+    for (int i = tid; i < d.L * d.H; i += blockDim.x) {
+        const int l = i / d.H, k = i % d.H;
+        const size_t o = (size_t)l * d.NL * d.H + (size_t)n * d.H + k;
+        s->cache_h[o] = 0.f; s->cache_c[o] = 0.f; s->alt_h[o] = 0.f; s->alt_c[o] = 0.f;
+        s->new_h[o] = 0.f; s->new_c[o] = 0.f;
+    }
+    for (int q = tid; q < d.J; q += blockDim.x) s->pp[(size_t)n * d.J + q] = 0.f;
+    if (tid == 0) {
+        const int T = s->enc_lens[b] < s->T ? s->enc_lens[b] : s->T;
+        s->token[n] = s->blank;
+        s->lane_t[n] = 0;
+        s->need_pred[n] = 1;
+        s->lane_active[n] = (j == 0 && T > 0);
+        s->bhyp_lens[(size_t)b * s->beam + j] = (j == 0) ? 1 : 0;
+        s->bhyps[((size_t)b * s->beam + j) * s->Lmax] = s->blank;
+        if (j == 0) {
+            s->n_hyps[b] = 1;
+            s->frame[b] = 0;
+            s->hyp_sel[b] = 0;
+            s->cache_sel[b] = 0;
+            s->bscores[(size_t)b * s->beam] = 0.0;
+        }
+    }
+}
+
+// per lane: log-softmax, mixture with the CTC posterior of this frame, top-`beam`
+__global__ __launch_bounds__(256) void beam_topk_kernel(DevState *s)
+{
+    extern __shared__ float lp[];                  // [V]
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const Dims &d = s->d;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    if (!s->lane_active[n]) return;
+    const int b = n / s->beam;
+    const int fr = s->frame[b];
+    const float *x = s->logits + (size_t)n * d.V;
+    const float *cp = s->ctc_logp + ((size_t)b * s->T + fr) * d.V;
+    float m = -3.0e38f;
+    for (int v = tid; v < d.V; v += 256) m = fmaxf(m, x[v]);
+    m = block_max(m, sv);
+    float sum = 0.f;
+    for (int v = tid; v < d.V; v += 256) sum += expf(x[v] - m);
+    sum = block_sum(sum, sv);
+    const float ls = logf(sum);
+    for (int v = tid; v < d.V; v += 256) {
+        const float l = (x[v] - m) - ls;
+        // prefix_beam_search.py:99-101: log(tw * exp(logp) + cw * exp(ctc[i]))
+        lp[v] = logf(s->tr_weight * expf(l) + s->ctc_weight * expf(cp[v]));
+    }
+    __syncthreads();
+    for (int k = 0; k < s->beam; ++k) {
+        float best = -__builtin_huge_valf();
+        int bi = 0x7fffffff;
+        for (int v = tid; v < d.V; v += 256) {
+            const float val = lp[v];
+            if (val > best) { best = val; bi = v; }     // ascending scan: lowest index wins ties
+        }
+        block_argmax(best, bi, sv, si);
+        if (tid == 0) {
+            s->topv[(size_t)n * s->beam + k] = best;
+            s->topi[(size_t)n * s->beam + k] = (bi < d.V) ? bi : 0;
+            if (bi >= 0 && bi < d.V) lp[bi] = -__builtin_huge_valf();   // taken
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ double log_add2(double a, double b)
+{
+    // wenet/utils/common.py:268-276 for two arguments, float64
+    const double ninf = -__builtin_huge_val();
+    if (a == ninf && b == ninf) return ninf;
+    const double mx = a > b ? a : b;
+    return mx + log(exp(a - mx) + exp(b - mx));
+}
+
+// one workgroup per utterance: expansion, prefix fusion, stable prune (prefix_beam_search.py:107-146)
+__global__ __launch_bounds__(256) void beam_update_kernel(DevState *s)
+{
+    __shared__ int c_base[kMaxBeam * kMaxBeam], c_tok[kMaxBeam * kMaxBeam], c_len[kMaxBeam * kMaxBeam];
+    __shared__ double c_score[kMaxBeam * kMaxBeam];
+    __shared__ int order[kMaxBeam * kMaxBeam];
+    __shared__ int s_nf, s_keep;
+    const Dims &d = s->d;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int beam = s->beam;
+    const int T = s->enc_lens[b] < s->T ? s->enc_lens[b] : s->T;
+    const int fr = s->frame[b];
+    if (fr >= T) return;
+    const int N = s->n_hyps[b];
+    const int sel = s->hyp_sel[b];
+    const size_t hstride = (size_t)s->n_utt * beam * s->Lmax;
+    const int32_t *hy = s->bhyps + sel * hstride + (size_t)b * beam * s->Lmax;
+    int32_t *hy2 = s->bhyps + (1 - sel) * hstride + (size_t)b * beam * s->Lmax;
+    const int32_t *hl = s->bhyp_lens + (size_t)sel * s->n_utt * beam + (size_t)b * beam;
+    int32_t *hl2 = s->bhyp_lens + (size_t)(1 - sel) * s->n_utt * beam + (size_t)b * beam;
+
+    if (tid == 0) {
+        int nf = 0;
+        for (int j = 0; j < N; ++j) {
+            const int n = b * beam + j;
+            // scores tensor is fp32 built from Python floats (:86); add in fp32 (:105); .item() -> float64 (:116)
+            const float sj = (float)s->bscores[(size_t)b * beam + j];
+            for (int t = 0; t < beam; ++t) {
+                const int tok = s->topi[(size_t)n * beam + t];
+                const double sc = (double)(sj + s->topv[(size_t)n * beam + t]);
+                const int len = hl[j] + (tok != s->blank ? 1 : 0);
+                // prefix fusion: first occurrence wins, later equal hypotheses add their score (:130-142)
+                int hit = -1;
+                for (int f = 0; f < nf && hit < 0; ++f) {
+                    if (c_len[f] != len) continue;
+                    const int bj = c_base[f], bt = c_tok[f];
+                    const int lb = hl[bj];          // base length of the fused entry
+                    bool same = true;
+                    for (int q = len - 1; q >= 0 && same; --q) {
+                        const int a = (q < hl[j]) ? hy[(size_t)j * s->Lmax + q] : tok;
+                        const int c = (q < lb) ? hy[(size_t)bj * s->Lmax + q] : bt;
+                        same = (a == c);
+                    }
+                    if (same) hit = f;
+                }
+                if (hit >= 0) c_score[hit] = log_add2(c_score[hit], sc);
+                else {
+                    c_base[nf] = j; c_tok[nf] = tok; c_len[nf] = len; c_score[nf] = sc;
+                    ++nf;
+                }
+            }
+        }
+        // stable sort by score, descending (list.sort(key=score, reverse=True) keeps fusion order on ties)
+        for (int i = 0; i < nf; ++i) order[i] = i;
+        for (int i = 1; i < nf; ++i) {
+            const int o = order[i];
+            int p = i - 1;
+            while (p >= 0 && c_score[order[p]] < c_score[o]) { order[p + 1] = order[p]; --p; }
+            order[p + 1] = o;
+        }
+        s_nf = nf;
+        s_keep = nf < beam ? nf : beam;
+    }
+    __syncthreads();
+    const int keep = s_keep;
+    const int csel = s->cache_sel[b];
+    const float *ch = csel ? s->alt_h : s->cache_h, *cc = csel ? s->alt_c : s->cache_c;
+    float *nh = csel ? s->cache_h : s->alt_h, *nc = csel ? s->cache_c : s->alt_c;
+    for (int e = 0; e < keep; ++e) {
+        const int f = order[e];
+        const int j = c_base[f], tok = c_tok[f], len = c_len[f];
+        const int lb = hl[j];
+        for (int q = tid; q < lb; q += 256) hy2[(size_t)e * s->Lmax + q] = hy[(size_t)j * s->Lmax + q];
+        const int src = b * beam + j, dst = b * beam + e;
+        // blank keeps the base hypothesis' cache, a label takes the predictor's new cache (:111-124)
+        const bool blank_ext = (tok == s->blank);
+        for (int i = tid; i < d.L * d.H; i += 256) {
+            const int l = i / d.H, k = i % d.H;
+            const size_t so = (size_t)l * d.NL * d.H + (size_t)src * d.H + k;
+            const size_t dst_o = (size_t)l * d.NL * d.H + (size_t)dst * d.H + k;
+            nh[dst_o] = blank_ext ? ch[so] : s->new_h[so];
+            nc[dst_o] = blank_ext ? cc[so] : s->new_c[so];
+        }
+        if (tid == 0) {
+            if (!blank_ext && lb < s->Lmax) hy2[(size_t)e * s->Lmax + lb] = tok;
+            hl2[e] = len;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int e = 0; e < keep; ++e) {
+            const int f = order[e];
+            s->bscores[(size_t)b * beam + e] = c_score[f];
+            const int n = b * beam + e;
+            const int tok = c_tok[f];
+            // next frame's predictor input is the last token of the hypothesis (:78-80)
+            const int j = c_base[f];
+            s->token[n] = (tok != s->blank) ? tok : hy[(size_t)j * s->Lmax + hl[j] - 1];
+        }
+        const int nfr = fr + 1;
+        for (int e = 0; e < beam; ++e) {
+            const int n = b * beam + e;
+            s->lane_active[n] = (e < keep) && (nfr < T);
+            s->lane_t[n] = nfr;
+            s->need_pred[n] = 1;
+        }
+        s->n_hyps[b] = keep;
+        s->frame[b] = nfr;
+        s->hyp_sel[b] = 1 - sel;
+        s->cache_sel[b] = 1 - csel;
+    }
+}
+
+// the LSTM step reads the committed cache through cache_h/cache_c; in beam mode the current buffer
+// alternates per utterance, so copy the current one into place before each frame's predictor step
+__global__ void beam_cache_gather_kernel(DevState *s)
+{
+    const Dims &d = s->d;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int b = n / s->beam;
+    if (!s->lane_active[n] || s->cache_sel[b] == 0) return;
+    for (int i = tid; i < d.L * d.H; i += blockDim.x) {
+        const int l = i / d.H, k = i % d.H;
+        const size_t o = (size_t)l * d.NL * d.H + (size_t)n * d.H + k;
+        s->cache_h[o] = s->alt_h[o];
+        s->cache_c[o] = s->alt_c[o];
+    }
+}
+
+__global__ void beam_cache_fix_kernel(DevState *s)
+{
+    // after the gather, the "current" buffer for every utterance is cache_h/cache_c
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < s->n_utt) s->cache_sel[b] = 0;
+}
+
+__global__ void beam_export_kernel(DevState *s, int32_t *hyps_out, int32_t *lens_out, double *scores_out, int32_t *n_out)
+{
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int beam = s->beam;
+    const int sel = s->hyp_sel[b];
+    const size_t hstride = (size_t)s->n_utt * beam * s->Lmax;
+    const int32_t *hy = s->bhyps + sel * hstride + (size_t)b * beam * s->Lmax;
+    const int32_t *hl = s->bhyp_lens + (size_t)sel * s->n_utt * beam + (size_t)b * beam;
+    const int N = s->n_hyps[b];
+    for (int i = tid; i < beam * s->Lmax; i += blockDim.x) {
+        const int e = i / s->Lmax, q = i % s->Lmax;
+        hyps_out[((size_t)b * beam + e) * s->Lmax + q] = (e < N && q < hl[e]) ? hy[(size_t)e * s->Lmax + q] : -1;
+    }
+    if (tid < beam) {
+        lens_out[(size_t)b * beam + tid] = (tid < N) ? hl[tid] : 0;
+        scores_out[(size_t)b * beam + tid] = (tid < N) ? s->bscores[(size_t)b * beam + tid] : -__builtin_huge_val();
+    }
+    if (tid == 0) n_out[b] = N;
+}
+
+}  // namespace
+}  // namespace wr
+
+using namespace wr;
+
+// ------------------------------------------------------------ host handle --
+struct wr_decoder {
+    Dims d;
+    DevState host;                // host copy of the device state block
+    DevState *dev;                // device copy (first bytes of the workspace)
+    char *ws;
+    size_t ws_bytes;
+    int max_utt, Tmax, max_hyp, max_beam;
+    int32_t *h_active;            // pinned host word
+    hipStream_t work;             // decode work runs here (graph capture is illegal on the legacy default stream)
+    hipEvent_t ev_in, ev_out;     // ordering against the caller's stream, no device-wide sync
+    hipGraphExec_t greedy_graph;
+    hipGraphExec_t beam_graph;
+    int greedy_graph_lanes, beam_graph_lanes;
+    bool use_graph;
+};
+
+namespace {
+
+struct Carver {
+    char *base;
+    size_t off;
+    template <typename T>
+    T *take(size_t n)
+    {
+        off = align_up(off, 256);
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+size_t carve(const wr_transducer_weights *w, int max_lanes, int max_utt, int Tmax, int max_hyp, int max_beam, char *base,
+             DevState *st, DevState **dev)
+{
+    Carver c{base, 0};
+    Dims d;
+    d.V = w->vocab_size; d.E = w->enc_dim; d.P = w->pred_dim; d.D = w->embed_dim; d.H = w->hidden; d.L = w->n_layers;
+    d.J = w->join_dim;
+    d.Jp = (d.J + 7) / 8 * 8;
+    d.Vp = (d.V + 255) / 256 * 256;
+    d.NL = max_lanes;
+    d.NLp = (max_lanes + 31) / 32 * 32;
+    DevState s;
+    memset(&s, 0, sizeof(s));
+    s.d = d;
+    DevState *devp = c.take<DevState>(1);
+    for (int l = 0; l < d.L; ++l) {
+        const int in_dim = l == 0 ? d.D : d.H;
+        s.wt_ih[l] = c.take<float>((size_t)in_dim * 4 * d.H);
+        s.wt_hh[l] = c.take<float>((size_t)d.H * 4 * d.H);
+        s.bsum[l] = c.take<float>((size_t)4 * d.H);
+    }
+    s.proj_wt = c.take<float>((size_t)d.H * d.P);
+    s.predffn_wt = c.take<float>((size_t)d.P * d.J);
+    s.encffn_wt = c.take<float>((size_t)d.E * d.J);
+    s.out_wt = c.take<float>((size_t)d.Jp * d.Vp);
+    s.ep_all = c.take<float>((size_t)max_utt * Tmax * d.J);
+    s.token = c.take<int32_t>(d.NL); s.lane_t = c.take<int32_t>(d.NL); s.noblk = c.take<int32_t>(d.NL);
+    s.need_pred = c.take<int32_t>(d.NL); s.lane_active = c.take<int32_t>(d.NLp);
+    const size_t cs = (size_t)d.L * d.NL * d.H;
+    s.cache_h = c.take<float>(cs); s.cache_c = c.take<float>(cs);
+    s.new_h = c.take<float>(cs); s.new_c = c.take<float>(cs);
+    s.alt_h = c.take<float>(cs); s.alt_c = c.take<float>(cs);
+    s.pred_out = c.take<float>((size_t)d.NL * d.P);
+    s.pp = c.take<float>((size_t)d.NL * d.J);
+    s.ht = c.take<float>((size_t)d.Jp * d.NLp);
+    s.logits = c.take<float>((size_t)d.NL * d.V);
+    s.active_count = c.take<int32_t>(64);
+    s.topv = c.take<float>((size_t)d.NL * kMaxBeam); s.topi = c.take<int32_t>((size_t)d.NL * kMaxBeam);
+    s.cache_sel = c.take<int32_t>(max_utt); s.n_hyps = c.take<int32_t>(max_utt); s.frame = c.take<int32_t>(max_utt);
+    s.hyp_sel = c.take<int32_t>(max_utt);
+    const int Lmax = Tmax + 1;
+    s.bhyps = c.take<int32_t>((size_t)2 * max_utt * max_beam * Lmax);
+    s.bhyp_lens = c.take<int32_t>((size_t)2 * max_utt * max_beam);
+    s.bscores = c.take<double>((size_t)max_utt * max_beam);
+    s.Lmax = Lmax;
+    s.max_hyp = max_hyp;
+    if (st) *st = s;
+    if (dev) *dev = devp;
+    return align_up(c.off, 256);
+}
+
+int check_weights(const wr_transducer_weights *w)
+{
+    WR_REQUIRE(w != nullptr, WR_EINVAL, "decoder: weights is null");
+    WR_REQUIRE(w->vocab_size > 1 && w->enc_dim > 0 && w->pred_dim > 0 && w->embed_dim > 0 && w->hidden > 0 && w->join_dim > 0,
+               WR_EINVAL, "decoder: non-positive dimension");
+    WR_REQUIRE(w->n_layers >= 1 && w->n_layers <= kMaxLayers, WR_EUNSUPPORTED, "decoder: n_layers=%d (max %d)", w->n_layers,
+               kMaxLayers);
+    WR_REQUIRE(w->join_dim <= 1024 && w->pred_dim <= 1024 && w->hidden <= 1024 && w->embed_dim <= 1024 && w->enc_dim <= 1024,
+               WR_EUNSUPPORTED, "decoder: a layer dimension exceeds 1024");
+    WR_REQUIRE(w->vocab_size * sizeof(float) <= 64 * 1024, WR_EUNSUPPORTED, "decoder: vocab_size=%d exceeds 16384",
+               w->vocab_size);
+    WR_REQUIRE(w->embed && w->proj_w && w->proj_b && w->enc_ffn_w && w->enc_ffn_b && w->pred_ffn_w && w->pred_ffn_b &&
+                   w->out_w && w->out_b, WR_EINVAL, "decoder: null weight pointer");
+    for (int l = 0; l < w->n_layers; ++l)
+        WR_REQUIRE(w->w_ih[l] && w->w_hh[l] && w->b_ih[l] && w->b_hh[l], WR_EINVAL, "decoder: null LSTM weight (layer %d)", l);
+    return WR_OK;
+}
+
+void launch_transpose(const float *src, int R, int C, int Rp, int Cp, float *dst, hipStream_t st)
+{
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3((Rp + 31) / 32, (Cp + 31) / 32), dim3(256), 0, st, src, R, C, Rp, Cp, dst);
+}
+
+void launch_predictor_and_joint(wr_decoder *h, int n_lanes, hipStream_t st)
+{
+    const Dims &d = h->d;
+    for (int l = 0; l < d.L; ++l) {
+        const int in_dim = l == 0 ? d.D : d.H;
+        const size_t lds = ((size_t)kLG * (in_dim + d.H) + kLG * 128) * sizeof(float);
+        hipLaunchKernelGGL(lstm_step_kernel, dim3((d.H + 31) / 32, (n_lanes + kLG - 1) / kLG), dim3(128), lds, st, h->dev, l);
+    }
+    hipLaunchKernelGGL(proj_step_kernel, dim3(n_lanes), dim3(256), (size_t)(d.H + d.P) * sizeof(float), st, h->dev);
+    const int mt = (n_lanes + 31) / 32;
+    const dim3 grid(d.Vp / 32);
+    switch (mt) {
+        case 1: hipLaunchKernelGGL((joint_step_kernel<1>), grid, dim3(256), 0, st, h->dev); break;
+        case 2: hipLaunchKernelGGL((joint_step_kernel<2>), grid, dim3(256), 0, st, h->dev); break;
+        case 3: hipLaunchKernelGGL((joint_step_kernel<3>), grid, dim3(256), 0, st, h->dev); break;
+        default: hipLaunchKernelGGL((joint_step_kernel<4>), grid, dim3(256), 0, st, h->dev); break;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t wr_decoder_workspace_bytes(const wr_transducer_weights *w, int max_lanes, int max_utt, int Tmax,
+                                             int max_hyp, int max_beam)
+{
+    if (!w || max_lanes <= 0 || max_utt <= 0 || Tmax <= 0) return 0;
+    return carve(w, max_lanes, max_utt, Tmax, max_hyp, max_beam > 0 ? max_beam : 1, nullptr, nullptr, nullptr);
+}
+
+extern "C" int wr_decoder_create(const wr_transducer_weights *w, int max_lanes, int max_utt, int Tmax, int max_hyp,
+                                 int max_beam, void *workspace_d, size_t workspace_bytes, void *stream, wr_decoder **out)
+{
+    if (int rc = check_weights(w)) return rc;
+    WR_REQUIRE(out && workspace_d, WR_EINVAL, "decoder_create: null pointer argument");
+    WR_REQUIRE(max_lanes > 0 && max_lanes <= 128, WR_EUNSUPPORTED, "decoder_create: max_lanes=%d (1..128)", max_lanes);
+    WR_REQUIRE(max_utt > 0 && max_utt <= max_lanes && Tmax > 0 && max_hyp >= 0, WR_EINVAL, "decoder_create: bad sizes");
+    if (max_beam <= 0) max_beam = 1;
+    WR_REQUIRE(max_beam <= kMaxBeam, WR_EUNSUPPORTED, "decoder_create: beam %d exceeds %d", max_beam, kMaxBeam);
+    const size_t need = carve(w, max_lanes, max_utt, Tmax, max_hyp, max_beam, nullptr, nullptr, nullptr);
+    WR_REQUIRE(workspace_bytes >= need, WR_EWORKSPACE, "decoder_create: workspace %zu < required %zu", workspace_bytes, need);
+    wr_decoder *h = new (std::nothrow) wr_decoder();
+    WR_REQUIRE(h != nullptr, WR_EINVAL, "decoder_create: out of host memory");
+    h->ws = static_cast<char *>(workspace_d);
+    h->ws_bytes = workspace_bytes;
+    carve(w, max_lanes, max_utt, Tmax, max_hyp, max_beam, h->ws, &h->host, &h->dev);
+    h->d = h->host.d;
+    h->max_utt = max_utt; h->Tmax = Tmax; h->max_hyp = max_hyp; h->max_beam = max_beam;
+    h->greedy_graph = nullptr; h->beam_graph = nullptr; h->greedy_graph_lanes = h->beam_graph_lanes = -1;
+    h->use_graph = true;
+    h->h_active = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void **>(&h->h_active), 64, hipHostMallocDefault) != hipSuccess) {
+        delete h;
+        set_error("decoder_create: hipHostMalloc failed");
+        return WR_ELAUNCH;
+    }
+    if (hipStreamCreateWithFlags(&h->work, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) != hipSuccess) {
+        (void)hipHostFree(h->h_active);
+        delete h;
+        set_error("decoder_create: stream/event creation failed");
+        return WR_ELAUNCH;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Dims &d = h->d;
+    DevState &s = h->host;
+    s.embed = w->embed; s.proj_b = w->proj_b; s.predffn_b = w->pred_ffn_b; s.encffn_b = w->enc_ffn_b; s.out_b = w->out_b;
+    for (int l = 0; l < d.L; ++l) {
+        const int in_dim = l == 0 ? d.D : d.H;
+        launch_transpose(w->w_ih[l], 4 * d.H, in_dim, 4 * d.H, in_dim, s.wt_ih[l], st);
+        launch_transpose(w->w_hh[l], 4 * d.H, d.H, 4 * d.H, d.H, s.wt_hh[l], st);
+        hipLaunchKernelGGL(add_bias_kernel, dim3((4 * d.H + 255) / 256), dim3(256), 0, st, w->b_ih[l], w->b_hh[l], 4 * d.H,
+                           s.bsum[l]);
+    }
+    launch_transpose(w->proj_w, d.P, d.H, d.P, d.H, s.proj_wt, st);
+    launch_transpose(w->pred_ffn_w, d.J, d.P, d.J, d.P, s.predffn_wt, st);
+    launch_transpose(w->enc_ffn_w, d.J, d.E, d.J, d.E, s.encffn_wt, st);
+    launch_transpose(w->out_w, d.V, d.J, d.Vp, d.Jp, s.out_wt, st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        (void)hipHostFree(h->h_active);
+        delete h;
+        set_error("decoder_create: weight preparation failed: %s", hipGetErrorString(e));
+        return WR_ELAUNCH;
+    }
+    *out = h;
+    return WR_OK;
+}
+
+extern "C" int wr_decoder_destroy(wr_decoder *h)
+{
+    if (!h) return WR_OK;
+    if (h->greedy_graph) (void)hipGraphExecDestroy(h->greedy_graph);
+    if (h->beam_graph) (void)hipGraphExecDestroy(h->beam_graph);
+    if (h->h_active) (void)hipHostFree(h->h_active);
+    (void)hipStreamSynchronize(h->work);
+    (void)hipEventDestroy(h->ev_in);
+    (void)hipEventDestroy(h->ev_out);
+    (void)hipStreamDestroy(h->work);
+    delete h;
+    return WR_OK;
+}
+
+extern "C" int wr_decoder_set_graph(wr_decoder *h, int enable)
+{
+    WR_REQUIRE(h != nullptr, WR_EINVAL, "decoder_set_graph: null handle");
+    h->use_graph = enable != 0;
+    return WR_OK;
+}
+
+namespace {
+
+int upload_state(wr_decoder *h, hipStream_t st)
+{
+    hipError_t e = hipMemcpyAsync(h->dev, &h->host, sizeof(DevState), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) { set_error("decoder: state upload failed: %s", hipGetErrorString(e)); return WR_ELAUNCH; }
+    return WR_OK;
+}
+
+void greedy_micro_step(wr_decoder *h, int n_lanes, hipStream_t st)
+{
+    launch_predictor_and_joint(h, n_lanes, st);
+    hipLaunchKernelGGL(greedy_update_kernel, dim3(n_lanes), dim3(256), 0, st, h->dev);
+}
+
+void beam_frame(wr_decoder *h, int n_lanes, int n_utt, hipStream_t st)
+{
+    hipLaunchKernelGGL(beam_cache_gather_kernel, dim3(n_lanes), dim3(128), 0, st, h->dev);
+    hipLaunchKernelGGL(beam_cache_fix_kernel, dim3((n_utt + 63) / 64), dim3(64), 0, st, h->dev);
+    launch_predictor_and_joint(h, n_lanes, st);
+    hipLaunchKernelGGL(beam_topk_kernel, dim3(n_lanes), dim3(256), (size_t)h->d.V * sizeof(float), st, h->dev);
+    hipLaunchKernelGGL(beam_update_kernel, dim3(n_utt), dim3(256), 0, st, h->dev);
+}
+
+// Order the decoder's work stream after everything already enqueued on the caller's stream ...
+hipStream_t enter(wr_decoder *h, hipStream_t caller)
+{
+    (void)hipEventRecord(h->ev_in, caller);
+    (void)hipStreamWaitEvent(h->work, h->ev_in, 0);
+    return h->work;
+}
+// ... and the caller's stream after the decoder's work.
+void leave(wr_decoder *h, hipStream_t caller)
+{
+    (void)hipEventRecord(h->ev_out, h->work);
+    (void)hipStreamWaitEvent(caller, h->ev_out, 0);
+}
+
+// Capture `reps` repetitions of `body` on `st` into an executable graph.
+template <typename F>
+int capture(hipStream_t st, int reps, F body, hipGraphExec_t *out)
+{
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { set_error("decoder: hipStreamBeginCapture failed: %s", hipGetErrorString(e)); return WR_ELAUNCH; }
+    for (int i = 0; i < reps; ++i) body();
+    e = hipStreamEndCapture(st, &g);
+    if (e != hipSuccess || !g) { set_error("decoder: hipStreamEndCapture failed: %s", hipGetErrorString(e)); return WR_ELAUNCH; }
+    e = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) { set_error("decoder: hipGraphInstantiate failed: %s", hipGetErrorString(e)); return WR_ELAUNCH; }
+    return WR_OK;
+}
+
+}  // namespace
+
+extern "C" int wr_greedy_search(wr_decoder *h, const float *enc_out_d, const int32_t *enc_lens_d, int N, int T, int n_steps,
+                                int blank, int32_t *hyps_d, int32_t *hyp_lens_d, void *stream)
+{
+    WR_REQUIRE(h && enc_out_d && enc_lens_d && hyps_d && hyp_lens_d, WR_EINVAL, "greedy_search: null pointer argument");
+    WR_REQUIRE(N > 0 && N <= h->d.NL && N <= h->max_utt, WR_EINVAL, "greedy_search: N=%d exceeds the decoder's capacity", N);
+    WR_REQUIRE(T > 0 && T <= h->Tmax, WR_EINVAL, "greedy_search: T=%d exceeds the decoder's Tmax=%d", T, h->Tmax);
+    WR_REQUIRE(n_steps >= 1 && blank >= 0 && blank < h->d.V, WR_EINVAL, "greedy_search: bad n_steps/blank");
+    hipStream_t caller = static_cast<hipStream_t>(stream);
+    hipStream_t st = enter(h, caller);
+    DevState &s = h->host;
+    s.enc = enc_out_d; s.enc_lens = enc_lens_d; s.ctc_logp = nullptr;
+    s.n_utt = N; s.T = T; s.lanes_per_utt = 1; s.n_lanes = N;
+    s.hyps = hyps_d; s.hyp_lens = hyp_lens_d; s.max_hyp = h->max_hyp; s.n_steps = n_steps; s.blank = blank; s.beam = 1;
+    if (int rc = upload_state(h, st)) return rc;
+    (void)hipMemsetAsync(s.active_count, 0, sizeof(int32_t), st);
+    (void)hipMemsetAsync(s.lane_active, 0, sizeof(int32_t) * h->d.NLp, st);
+    hipLaunchKernelGGL(ep_all_kernel, dim3((unsigned)(((long)N * T + 7) / 8)), dim3(256), (size_t)8 * h->d.E * sizeof(float), st,
+                       h->dev);
+    hipLaunchKernelGGL(greedy_init_kernel, dim3(N), dim3(128), 0, st, h->dev);
+    WR_CHECK_LAUNCH("greedy_init");
+    if (h->use_graph && h->greedy_graph_lanes != N) {
+        if (h->greedy_graph) { (void)hipGraphExecDestroy(h->greedy_graph); h->greedy_graph = nullptr; }
+        if (int rc = capture(st, kStepsPerGraph, [&] { greedy_micro_step(h, N, st); }, &h->greedy_graph)) return rc;
+        h->greedy_graph_lanes = N;
+    }
+    const long max_micro = (long)T * ((long)n_steps + 1) + 1;
+    for (long done = 0; done < max_micro; done += kStepsPerGraph) {
+        if (h->use_graph) {
+            hipError_t e = hipGraphLaunch(h->greedy_graph, st);
+            if (e != hipSuccess) { set_error("greedy_search: hipGraphLaunch failed: %s", hipGetErrorString(e)); return WR_ELAUNCH; }
+        } else {
+            for (int i = 0; i < kStepsPerGraph; ++i) greedy_micro_step(h, N, st);
+        }
+        // the reference synchronises on every step (.item()); we do once per kStepsPerGraph micro-steps
+        (void)hipMemcpyAsync(h->h_active, s.active_count, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { set_error("greedy_search: stream error: %s", hipGetErrorString(e)); return WR_ELAUNCH; }
+        if (*h->h_active <= 0) break;
+    }
+    leave(h, caller);
+    WR_CHECK_LAUNCH("greedy_search");
+    return WR_OK;
+}
+
+extern "C" int wr_prefix_beam_search(wr_decoder *h, const float *enc_out_d, const int32_t *enc_lens_d,
+                                     const float *ctc_logp_d, int B, int T, int beam, float ctc_weight,
+                                     float transducer_weight, int blank, int32_t *hyps_d, int32_t *hyp_lens_d,
+                                     double *scores_d, int32_t *n_hyps_d, void *stream)
+{
+    WR_REQUIRE(h && enc_out_d && enc_lens_d && ctc_logp_d && hyps_d && hyp_lens_d && scores_d && n_hyps_d, WR_EINVAL,
+               "prefix_beam_search: null pointer argument");
+    WR_REQUIRE(beam >= 1 && beam <= h->max_beam, WR_EINVAL, "prefix_beam_search: beam=%d exceeds the decoder's max %d", beam,
+               h->max_beam);
+    WR_REQUIRE(B > 0 && B <= h->max_utt && B * beam <= h->d.NL, WR_EINVAL,
+               "prefix_beam_search: B*beam=%d exceeds the decoder's capacity", B * beam);
+    WR_REQUIRE(T > 0 && T <= h->Tmax, WR_EINVAL, "prefix_beam_search: T=%d exceeds the decoder's Tmax=%d", T, h->Tmax);
+    WR_REQUIRE(blank >= 0 && blank < h->d.V, WR_EINVAL, "prefix_beam_search: bad blank");
+    hipStream_t caller = static_cast<hipStream_t>(stream);
+    hipStream_t st = enter(h, caller);
+    DevState &s = h->host;
+    s.enc = enc_out_d; s.enc_lens = enc_lens_d; s.ctc_logp = ctc_logp_d;
+    s.n_utt = B; s.T = T; s.lanes_per_utt = beam; s.n_lanes = B * beam;
+    s.beam = beam; s.ctc_weight = ctc_weight; s.tr_weight = transducer_weight; s.blank = blank;
+    s.Lmax = h->Tmax + 1;
+    if (int rc = upload_state(h, st)) return rc;
+    (void)hipMemsetAsync(s.lane_active, 0, sizeof(int32_t) * h->d.NLp, st);
+    const int NLn = B * beam;
+    hipLaunchKernelGGL(ep_all_kernel, dim3((unsigned)(((long)B * T + 7) / 8)), dim3(256), (size_t)8 * h->d.E * sizeof(float), st,
+                       h->dev);
+    hipLaunchKernelGGL(beam_init_kernel, dim3(NLn), dim3(128), 0, st, h->dev);
+    WR_CHECK_LAUNCH("beam_init");
+    const int key = NLn * 1000 + beam;
+    if (h->use_graph && h->beam_graph_lanes != key) {
+        if (h->beam_graph) { (void)hipGraphExecDestroy(h->beam_graph); h->beam_graph = nullptr; }
+        if (int rc = capture(st, kStepsPerGraph, [&] { beam_frame(h, NLn, B, st); }, &h->beam_graph)) return rc;
+        h->beam_graph_lanes = key;
+    }
+    for (int f = 0; f < T; f += kStepsPerGraph) {
+        if (h->use_graph) {
+            hipError_t e = hipGraphLaunch(h->beam_graph, st);
+            if (e != hipSuccess) { set_error("prefix_beam_search: hipGraphLaunch failed: %s", hipGetErrorString(e)); return WR_ELAUNCH; }
+        } else {
+            for (int i = 0; i < kStepsPerGraph; ++i) beam_frame(h, NLn, B, st);
+        }
+    }
+    hipLaunchKernelGGL(beam_export_kernel, dim3(B), dim3(256), 0, st, h->dev, hyps_d, hyp_lens_d, scores_d, n_hyps_d);
+    leave(h, caller);
+    WR_CHECK_LAUNCH("prefix_beam_search");
+    return WR_OK;
+}
+
+namespace {
+// [L][srcN][H] -> [L][dstN][H] for the first N lanes
+__global__ void copy_cache_kernel(const float *__restrict__ src, int srcN, float *__restrict__ dst, int dstN, int L, int N, int H)
+{
+    const long total = (long)L * N * H;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % H);
+        const int n = (int)((i / H) % N);
+        const int l = (int)(i / ((long)H * N));
+        dst[((size_t)l * dstN + n) * H + k] = src[((size_t)l * srcN + n) * H + k];
+    }
+}
+
+__global__ void step_setup_kernel(DevState *s, const int32_t *tokens, int N)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < s->d.NLp) {
+        const int on = n < N;
+        s->lane_active[n] = on;
+        if (n < s->d.NL) {
+            s->need_pred[n] = on;
+            s->lane_t[n] = 0;
+            if (on) s->token[n] = tokens[n];
+        }
+    }
+}
+
+__global__ void copy_rows_kernel(const float *__restrict__ src, float *__restrict__ dst, long n)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+}  // namespace
+
+// Single predictor step for `N` lanes through the same kernels the decoders use (step API of
+// predictor.py:160-200): tokens + cache in, projected output [N,P] and new cache [L,N,H] out.
+extern "C" int wr_predictor_step(wr_decoder *h, const int32_t *tokens_d, const float *cache_h_d, const float *cache_c_d, int N,
+                                 float *out_d, float *new_h_d, float *new_c_d, void *stream)
+{
+    WR_REQUIRE(h && tokens_d && cache_h_d && cache_c_d && out_d && new_h_d && new_c_d, WR_EINVAL,
+               "predictor_step: null pointer argument");
+    WR_REQUIRE(N > 0 && N <= h->d.NL, WR_EINVAL, "predictor_step: N=%d exceeds the decoder's capacity %d", N, h->d.NL);
+    hipStream_t caller = static_cast<hipStream_t>(stream);
+    hipStream_t st = enter(h, caller);
+    const Dims &d = h->d;
+    DevState &s = h->host;
+    s.n_utt = 1; s.T = 1; s.lanes_per_utt = d.NL; s.n_lanes = N; s.enc = nullptr; s.enc_lens = nullptr;
+    if (int rc = upload_state(h, st)) return rc;
+    (void)hipMemsetAsync(s.ep_all, 0, sizeof(float) * d.J, st);
+    hipLaunchKernelGGL(step_setup_kernel, dim3((d.NLp + 63) / 64), dim3(64), 0, st, h->dev, tokens_d, N);
+    hipLaunchKernelGGL(copy_cache_kernel, dim3(64), dim3(256), 0, st, cache_h_d, N, s.cache_h, d.NL, d.L, N, d.H);
+    hipLaunchKernelGGL(copy_cache_kernel, dim3(64), dim3(256), 0, st, cache_c_d, N, s.cache_c, d.NL, d.L, N, d.H);
+    for (int l = 0; l < d.L; ++l) {
+        const int in_dim = l == 0 ? d.D : d.H;
+        const size_t lds = ((size_t)kLG * (in_dim + d.H) + kLG * 128) * sizeof(float);
+        hipLaunchKernelGGL(lstm_step_kernel, dim3((d.H + 31) / 32, (N + kLG - 1) / kLG), dim3(128), lds, st, h->dev, l);
+    }
+    hipLaunchKernelGGL(proj_step_kernel, dim3(N), dim3(256), (size_t)(d.H + d.P) * sizeof(float), st, h->dev);
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(32), dim3(256), 0, st, s.pred_out, out_d, (long)N * d.P);
+    hipLaunchKernelGGL(copy_cache_kernel, dim3(64), dim3(256), 0, st, s.new_h, d.NL, new_h_d, N, d.L, N, d.H);
+    hipLaunchKernelGGL(copy_cache_kernel, dim3(64), dim3(256), 0, st, s.new_c, d.NL, new_c_d, N, d.L, N, d.H);
+    leave(h, caller);
+    WR_CHECK_LAUNCH("predictor_step");
+    return WR_OK;
+}

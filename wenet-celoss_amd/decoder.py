@@ -1,0 +1,169 @@
+"""Python owner of a `wr_decoder` handle (include/wr_api.h): packs the predictor /
+joiner weights in the reference modules' layouts into `wr_transducer_weights`,
+allocates the workspace through torch, and exposes greedy search, prefix beam
+search and the predictor step."""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Tuple
+
+import torch
+
+from . import _lib
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    t = t.detach()
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.float().contiguous()
+    return t
+
+
+class DeviceDecoder:
+    """One handle per (predictor, joint) pair and capacity.  Not thread-safe."""
+
+    def __init__(self, predictor, joint, max_lanes: int, max_utt: int, tmax: int, max_hyp: int = 0, max_beam: int = 1):
+        lib = _lib.load()
+        rnn = predictor.rnn
+        if not isinstance(rnn, torch.nn.LSTM):
+            raise NotImplementedError("wenet_celoss_amd decoding implements the LSTM RNNPredictor "
+                                      f"(the shipped configuration); got {type(rnn).__name__}")
+        if joint.enc_ffn is None or joint.pred_ffn is None:
+            raise NotImplementedError("wenet_celoss_amd decoding needs prejoin_linear=True (the shipped configuration)")
+        dev = joint.ffn_out.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("wenet_celoss_amd decoding: modules must live on a HIP device (this package has no CPU path)")
+        self.device = dev
+        self._keep: List[torch.Tensor] = []
+
+        def hold(t):
+            t = _f32(t)
+            self._keep.append(t)
+            return t.data_ptr()
+
+        w = _lib.TransducerWeights()
+        w.vocab_size = joint.ffn_out.weight.shape[0]
+        w.enc_dim = joint.enc_ffn.weight.shape[1]
+        w.pred_dim = predictor.projection.weight.shape[0]
+        w.embed_dim = predictor.embed.weight.shape[1]
+        w.hidden = rnn.hidden_size
+        w.n_layers = rnn.num_layers
+        w.join_dim = joint.ffn_out.weight.shape[1]
+        w.embed = hold(predictor.embed.weight)
+        if rnn.num_layers > 4:
+            raise NotImplementedError("at most 4 LSTM layers")
+        for l in range(rnn.num_layers):
+            w.w_ih[l] = hold(getattr(rnn, f"weight_ih_l{l}"))
+            w.w_hh[l] = hold(getattr(rnn, f"weight_hh_l{l}"))
+            w.b_ih[l] = hold(getattr(rnn, f"bias_ih_l{l}"))
+            w.b_hh[l] = hold(getattr(rnn, f"bias_hh_l{l}"))
+        w.proj_w, w.proj_b = hold(predictor.projection.weight), hold(predictor.projection.bias)
+        w.enc_ffn_w, w.enc_ffn_b = hold(joint.enc_ffn.weight), hold(joint.enc_ffn.bias)
+        w.pred_ffn_w, w.pred_ffn_b = hold(joint.pred_ffn.weight), hold(joint.pred_ffn.bias)
+        w.out_w, w.out_b = hold(joint.ffn_out.weight), hold(joint.ffn_out.bias)
+        self._w = w
+        self.dims = dict(V=w.vocab_size, E=w.enc_dim, P=w.pred_dim, D=w.embed_dim, H=w.hidden, L=w.n_layers, J=w.join_dim)
+        self.max_lanes, self.max_utt, self.tmax, self.max_hyp, self.max_beam = max_lanes, max_utt, tmax, max_hyp, max_beam
+        nbytes = lib.wr_decoder_workspace_bytes(ctypes.byref(w), max_lanes, max_utt, tmax, max_hyp, max_beam)
+        if nbytes == 0:
+            raise RuntimeError("wr_decoder_workspace_bytes rejected the configuration")
+        self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            rc = lib.wr_decoder_create(ctypes.byref(w), max_lanes, max_utt, tmax, max_hyp, max_beam, _lib.ptr(self._ws),
+                                       nbytes, _lib.current_stream(dev), ctypes.byref(handle))
+        _lib.check(rc, "wr_decoder_create")
+        self._h = handle
+        self._lib = lib
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self._lib.wr_decoder_destroy(h)
+            except Exception:
+                pass
+
+    def set_graph(self, enable: bool) -> None:
+        _lib.check(self._lib.wr_decoder_set_graph(self._h, int(enable)), "wr_decoder_set_graph")
+
+    def greedy(self, encoder_out: torch.Tensor, encoder_out_lens: torch.Tensor, n_steps: int = 64, blank: int = 0
+               ) -> List[List[int]]:
+        """encoder_out (N, T, E); returns one token list per stream."""
+        enc = _f32(encoder_out)
+        N, T, _ = enc.shape
+        lens = encoder_out_lens.to(device=self.device, dtype=torch.int32).reshape(-1).contiguous()
+        hyps = torch.empty(N, max(self.max_hyp, 1), dtype=torch.int32, device=self.device)
+        hl = torch.empty(N, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self._lib.wr_greedy_search(self._h, _lib.ptr(enc), _lib.ptr(lens), N, T, int(n_steps), int(blank),
+                                            _lib.ptr(hyps), _lib.ptr(hl), _lib.current_stream(self.device))
+        _lib.check(rc, "wr_greedy_search")
+        hl_c, hy_c = hl.cpu().tolist(), hyps.cpu()
+        if max(hl_c, default=0) > self.max_hyp:
+            raise RuntimeError(f"greedy search produced {max(hl_c)} tokens but the decoder was sized for {self.max_hyp}")
+        return [hy_c[i, :hl_c[i]].tolist() for i in range(N)]
+
+    def prefix_beam(self, encoder_out: torch.Tensor, encoder_out_lens: torch.Tensor, ctc_logp: torch.Tensor,
+                    beam_size: int, ctc_weight: float, transducer_weight: float, blank: int = 0
+                    ) -> List[List[Tuple[List[int], float]]]:
+        """encoder_out (B, T, E), ctc_logp (B, T, V).  Per utterance: [(hyp incl. seed blank, score)] best first."""
+        enc = _f32(encoder_out)
+        ctc = _f32(ctc_logp)
+        B, T, _ = enc.shape
+        lens = encoder_out_lens.to(device=self.device, dtype=torch.int32).reshape(-1).contiguous()
+        lmax = self.tmax + 1
+        hyps = torch.empty(B, beam_size, lmax, dtype=torch.int32, device=self.device)
+        hl = torch.empty(B, beam_size, dtype=torch.int32, device=self.device)
+        sc = torch.empty(B, beam_size, dtype=torch.float64, device=self.device)
+        nh = torch.empty(B, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self._lib.wr_prefix_beam_search(self._h, _lib.ptr(enc), _lib.ptr(lens), _lib.ptr(ctc), B, T, int(beam_size),
+                                                 float(ctc_weight), float(transducer_weight), int(blank), _lib.ptr(hyps),
+                                                 _lib.ptr(hl), _lib.ptr(sc), _lib.ptr(nh), _lib.current_stream(self.device))
+        _lib.check(rc, "wr_prefix_beam_search")
+        hyps, hl, sc, nh = hyps.cpu(), hl.cpu().tolist(), sc.cpu().tolist(), nh.cpu().tolist()
+        out = []
+        for b in range(B):
+            out.append([(hyps[b, e, :hl[b][e]].tolist(), sc[b][e]) for e in range(nh[b])])
+        return out
+
+    def predictor_step(self, tokens: torch.Tensor, cache_h: torch.Tensor, cache_c: torch.Tensor):
+        """tokens (N,), cache (L, N, H) -> out (N, P), new_h, new_c (L, N, H)."""
+        N = tokens.numel()
+        tok = tokens.to(device=self.device, dtype=torch.int32).reshape(-1).contiguous()
+        ch, cc = _f32(cache_h), _f32(cache_c)
+        out = torch.empty(N, self.dims["P"], dtype=torch.float32, device=self.device)
+        nh, nc = torch.empty_like(ch), torch.empty_like(cc)
+        with torch.cuda.device(self.device):
+            rc = self._lib.wr_predictor_step(self._h, _lib.ptr(tok), _lib.ptr(ch), _lib.ptr(cc), N, _lib.ptr(out),
+                                             _lib.ptr(nh), _lib.ptr(nc), _lib.current_stream(self.device))
+        _lib.check(rc, "wr_predictor_step")
+        return out, nh, nc
+
+
+def _weights_key(predictor, joint):
+    ps = list(predictor.parameters()) + list(joint.parameters())
+    return tuple((p.data_ptr(), p._version) for p in ps)
+
+
+class DecoderCache:
+    """Keeps a DeviceDecoder alive across calls and rebuilds it when the modules'
+    weights change or a call needs more capacity."""
+
+    def __init__(self):
+        self._dec = None
+        self._key = None
+
+    def get(self, predictor, joint, lanes: int, utts: int, tmax: int, max_hyp: int, beam: int) -> DeviceDecoder:
+        key = _weights_key(predictor, joint)
+        d = self._dec
+        same = d is not None and key == self._key
+        if not same or lanes > d.max_lanes or utts > d.max_utt or tmax > d.tmax or max_hyp > d.max_hyp or beam > d.max_beam:
+            grow = (lambda new, old: max(new, old)) if same else (lambda new, old: new)
+            caps = (grow(lanes, d.max_lanes if d else 0), grow(utts, d.max_utt if d else 0), grow(tmax, d.tmax if d else 0),
+                    grow(max_hyp, d.max_hyp if d else 0), grow(beam, d.max_beam if d else 1))
+            self._dec = None            # release the old handle before building the new one
+            self._dec = DeviceDecoder(predictor, joint, *caps)
+            self._key = key
+        return self._dec

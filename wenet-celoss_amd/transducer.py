@@ -1,0 +1,295 @@
+"""Transducer model head with the reference's interface
+(wenet/transducer/transducer.py:20-629): same constructor keywords, same
+`forward(speech, speech_lengths, text, text_lengths, context_list,
+context_lengths, hw_label)` returning the dict
+{loss, loss_att, loss_ctc, loss_rnnt, hw_loss}, same `greedy_search`,
+`beam_search`, `transducer_attention_rescoring`, `_cal_transducer_score` and
+step exports -- so wenet/bin/train.py and wenet/bin/recognize.py can drive it.
+
+What runs where
+  joiner logits      wenet_celoss_amd.TransducerJoint  (MFMA HIP kernels)
+  RNN-T loss + grad  wenet_celoss_amd.rnnt_loss        (HIP, replaces torchaudio, :142-147 / :296-301)
+  CTC loss + grad    wenet_celoss_amd.CTC              (HIP, replaces nn.CTCLoss)
+  greedy / beam      wenet_celoss_amd.search.*         (HIP decode kernels under hipGraph)
+  encoder, attention decoder, ContextBias: whatever modules the caller passes
+  (stock PyTorch-ROCm; out of scope).
+
+`context_bias` may be None (no hot words); when a ContextBias module is given it
+is called exactly where the reference calls it in `forward`.  The fork's
+hot-word greedy variants are not accelerated yet:
+`greedy_search` with a context_bias raises.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+from torch.nn.utils.rnn import pad_sequence
+
+from .common import IGNORE_ID, LabelSmoothingLoss, add_blank, add_sos_eos, end_blank, reverse_pad_list
+from .decoder import DecoderCache
+from .rnnt_loss import rnnt_loss
+from .search.greedy_search import basic_greedy_search
+from .search.prefix_beam_search import PrefixBeamSearch
+
+
+class Transducer(nn.Module):
+    """Transducer-ctc-attention hybrid Encoder-Predictor-Decoder model (transducer.py:20)."""
+
+    def __init__(self, vocab_size: int, blank: int, encoder: nn.Module, predictor: nn.Module, joint: nn.Module,
+                 attention_decoder: Optional[nn.Module] = None, ctc: Optional[nn.Module] = None,
+                 context_bias: Optional[nn.Module] = None, ctc_weight: float = 0, ignore_id: int = IGNORE_ID,
+                 reverse_weight: float = 0.0, lsm_weight: float = 0.0, length_normalized_loss: bool = False,
+                 transducer_weight: float = 1.0, attention_weight: float = 0.0, hw_weight: float = 0.4,
+                 loss_mode: str = "both") -> None:
+        assert attention_weight + ctc_weight + transducer_weight == 1.0          # transducer.py:46 (kept as is)
+        super().__init__()
+        # ASRModel part (asr_model.py:38-70): sos/eos are the last class
+        self.sos = vocab_size - 1
+        self.eos = vocab_size - 1
+        self.vocab_size = vocab_size
+        self.ignore_id = ignore_id
+        self.ctc_weight = ctc_weight
+        self.reverse_weight = reverse_weight
+        self.encoder = encoder
+        self.decoder = attention_decoder
+        self.ctc = ctc
+
+        self.blank = blank
+        self.transducer_weight = transducer_weight
+        self.attention_decoder_weight = 1 - self.transducer_weight - self.ctc_weight
+        self.context_bias = context_bias
+        self.predictor = predictor
+        self.joint = joint
+        self.bs = None
+        self.hw_weight = hw_weight
+        self.loss_mode = loss_mode
+        self.hw_criterion = nn.CrossEntropyLoss()
+        if attention_decoder is not None:
+            self.criterion_att = LabelSmoothingLoss(size=vocab_size, padding_idx=ignore_id, smoothing=lsm_weight,
+                                                    normalize_length=length_normalized_loss)
+        self._decoder_cache = DecoderCache()
+
+    # ------------------------------------------------------------- training --
+    def compute_loss(self, encoder_out: torch.Tensor, encoder_out_lens: torch.Tensor, predictor_out: torch.Tensor,
+                     text: torch.Tensor, text_lengths: torch.Tensor, skip_padding: bool = False
+                     ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The loss block of the reference forward (transducer.py:131-147): joiner -> int32 label prep -> RNN-T loss.
+        Returns (joint_out, loss_rnnt).  `skip_padding=True` (extension) lets the joiner skip lattice cells
+        that the loss never reads."""
+        rnnt_text = text.to(torch.int64)
+        rnnt_text = torch.where(rnnt_text == self.ignore_id, 0, rnnt_text).to(torch.int32)
+        rnnt_text_lengths = text_lengths.to(torch.int32)
+        encoder_out_lens = encoder_out_lens.to(torch.int32)
+        if skip_padding:
+            joint_out = self.joint(encoder_out, predictor_out, encoder_out_lens, rnnt_text_lengths)
+        else:
+            joint_out = self.joint(encoder_out, predictor_out)
+        loss = rnnt_loss(joint_out, rnnt_text.contiguous(), encoder_out_lens.contiguous(),
+                         rnnt_text_lengths.contiguous(), blank=self.blank, reduction="mean")
+        return joint_out, loss
+
+    def forward(self, speech: torch.Tensor, speech_lengths: torch.Tensor, text: torch.Tensor,
+                text_lengths: torch.Tensor, context_list: torch.Tensor = torch.IntTensor([0]),
+                context_lengths: torch.Tensor = torch.IntTensor([0]), hw_label=torch.IntTensor([0])
+                ) -> Dict[str, Optional[torch.Tensor]]:
+        """Frontend + Encoder + predictor + joint + loss (transducer.py:79-270)."""
+        assert text_lengths.dim() == 1, text_lengths.shape
+        assert (speech.shape[0] == speech_lengths.shape[0] == text.shape[0] == text_lengths.shape[0]), \
+            (speech.shape, speech_lengths.shape, text.shape, text_lengths.shape)
+        cb = self.context_bias
+        bias_hidden = cb.forward_bias_hidden(context_list, context_lengths) if cb is not None else None
+
+        encoder_out, encoder_mask = self.encoder(speech, speech_lengths)
+        encoder_out_lens = encoder_mask.squeeze(1).sum(1)
+        encoder_out_bias = None
+        if cb is not None:
+            encoder_out, encoder_out_bias = cb.forward_encoder_bias(bias_hidden, encoder_out)
+        ys_in_pad = add_blank(text, self.blank, self.ignore_id)
+        predictor_out = self.predictor(ys_in_pad)
+        predictor_out_bias = None
+        if cb is not None:
+            predictor_out, predictor_out_bias = cb.forward_predictor_bias(bias_hidden, predictor_out)
+        predictor_out_unbiased = predictor_out.clone()
+
+        _, loss_rnnt = self.compute_loss(encoder_out, encoder_out_lens, predictor_out, text, text_lengths)
+        loss = self.transducer_weight * loss_rnnt
+
+        loss_att: Optional[torch.Tensor] = None
+        if self.attention_decoder_weight != 0.0 and self.decoder is not None:
+            loss_att, _ = self._calc_att_loss(encoder_out, encoder_mask, text, text_lengths)
+        loss_ctc: Optional[torch.Tensor] = None
+        if self.ctc_weight != 0.0 and self.ctc is not None:
+            loss_ctc = self.ctc(encoder_out, encoder_out_lens, text, text_lengths)
+        if loss_ctc is not None:
+            loss = loss + self.ctc_weight * loss_ctc.sum()
+        if loss_att is not None:
+            loss = loss + self.attention_decoder_weight * loss_att.sum()
+
+        hw_loss: Optional[torch.Tensor] = None
+        if self.hw_weight != 0.0 and cb is not None:
+            if self.loss_mode == "pred":
+                hw_output = cb.forward_hw_pred(bias_hidden, predictor_out_unbiased).permute(0, 2, 1)
+                hw_label_pad = end_blank(hw_label, self.blank, self.ignore_id)[..., :-1]
+                hw_loss = self.hw_criterion(hw_output[..., :-1], hw_label_pad)
+            elif self.loss_mode == "both":
+                hw_output = cb.forward_hw_pred_both(encoder_out_bias, predictor_out_bias).permute(0, 2, 1)
+                hw_label_pad = end_blank(hw_label, self.blank, self.ignore_id)[..., :-1]
+                hw_loss = self.hw_criterion(hw_output[..., :-1], hw_label_pad)
+            else:
+                _, hw_output_dec = cb.forward_hw_pred_both_sep(encoder_out_bias, predictor_out_bias)
+                hw_label_pad = add_blank(hw_label, self.blank, self.ignore_id)
+                hw_loss = self.hw_criterion(hw_output_dec.permute(0, 2, 1), hw_label_pad)
+            loss = loss + self.hw_weight * hw_loss
+        return {"loss": loss, "loss_att": loss_att, "loss_ctc": loss_ctc, "loss_rnnt": loss_rnnt, "hw_loss": hw_loss}
+
+    def _calc_att_loss(self, encoder_out, encoder_mask, ys_pad, ys_pad_lens):
+        """asr_model.py:115-148 (attention decoder is whatever module the caller attached)."""
+        ys_in_pad, ys_out_pad = add_sos_eos(ys_pad, self.sos, self.eos, self.ignore_id)
+        ys_in_lens = ys_pad_lens + 1
+        r_ys_pad = reverse_pad_list(ys_pad, ys_pad_lens, float(self.ignore_id))
+        r_ys_in_pad, r_ys_out_pad = add_sos_eos(r_ys_pad, self.sos, self.eos, self.ignore_id)
+        decoder_out, r_decoder_out, _ = self.decoder(encoder_out, encoder_mask, ys_in_pad, ys_in_lens, r_ys_in_pad,
+                                                     self.reverse_weight)
+        loss_att = self.criterion_att(decoder_out, ys_out_pad)
+        r_loss_att = torch.tensor(0.0, device=loss_att.device)
+        if self.reverse_weight > 0.0:
+            r_loss_att = self.criterion_att(r_decoder_out, r_ys_out_pad)
+        loss_att = loss_att * (1 - self.reverse_weight) + r_loss_att * self.reverse_weight
+        pred = decoder_out.view(-1, self.vocab_size).argmax(1)
+        mask = ys_out_pad.view(-1) != self.ignore_id
+        acc = float((pred[mask] == ys_out_pad.view(-1)[mask]).sum()) / max(int(mask.sum()), 1)
+        return loss_att, acc
+
+    # -------------------------------------------------------------- decoding --
+    def init_bs(self):
+        if self.bs is None:
+            self.bs = PrefixBeamSearch(self.encoder, self.predictor, self.joint, self.ctc, self.blank)
+
+    def _cal_transducer_score(self, encoder_out: torch.Tensor, encoder_mask: torch.Tensor, hyps_lens: torch.Tensor,
+                              hyps_pad: torch.Tensor):
+        """-rnnt_loss(reduction='none') per hypothesis (transducer.py:277-302)."""
+        hyps_pad_blank = add_blank(hyps_pad, self.blank, self.ignore_id)
+        xs_in_lens = encoder_mask.squeeze(1).sum(1).int()
+        predictor_out = self.predictor(hyps_pad_blank)
+        joint_out = self.joint(encoder_out, predictor_out)
+        rnnt_text = hyps_pad.to(torch.int64)
+        rnnt_text = torch.where(rnnt_text == self.ignore_id, 0, rnnt_text).to(torch.int32)
+        loss_td = rnnt_loss(joint_out, rnnt_text.contiguous(), xs_in_lens.contiguous(), hyps_lens.int().contiguous(),
+                            blank=self.blank, reduction="none")
+        return loss_td * -1
+
+    def _cal_attn_score(self, encoder_out, encoder_mask, hyps_pad, hyps_lens):
+        """transducer.py:304-330"""
+        ori_hyps_pad = hyps_pad
+        hyps_pad, _ = add_sos_eos(hyps_pad, self.sos, self.eos, self.ignore_id)
+        hyps_lens = hyps_lens + 1
+        r_hyps_pad = reverse_pad_list(ori_hyps_pad, hyps_lens, self.ignore_id)
+        r_hyps_pad, _ = add_sos_eos(r_hyps_pad, self.sos, self.eos, self.ignore_id)
+        decoder_out, r_decoder_out, _ = self.decoder(encoder_out, encoder_mask, hyps_pad, hyps_lens, r_hyps_pad,
+                                                     self.reverse_weight)
+        decoder_out = torch.nn.functional.log_softmax(decoder_out, dim=-1).cpu().numpy()
+        r_decoder_out = torch.nn.functional.log_softmax(r_decoder_out, dim=-1).cpu().numpy()
+        return decoder_out, r_decoder_out
+
+    def beam_search(self, speech: torch.Tensor, speech_lengths: torch.Tensor, decoding_chunk_size: int = -1,
+                    beam_size: int = 5, num_decoding_left_chunks: int = -1, simulate_streaming: bool = False,
+                    ctc_weight: float = 0.3, transducer_weight: float = 0.7, **_ignored):
+        """transducer.py:332-377.  Extra keyword arguments (recognize.py:303-304 passes context_list /
+        context_lengths, which the reference signature lacks) are accepted and ignored."""
+        self.init_bs()
+        beam, _ = self.bs.prefix_beam_search(speech, speech_lengths, decoding_chunk_size, beam_size,
+                                             num_decoding_left_chunks, simulate_streaming, ctc_weight,
+                                             transducer_weight)
+        return beam[0].hyp[1:], beam[0].score
+
+    def transducer_attention_rescoring(self, speech: torch.Tensor, speech_lengths: torch.Tensor, beam_size: int,
+                                       decoding_chunk_size: int = -1, num_decoding_left_chunks: int = -1,
+                                       simulate_streaming: bool = False, reverse_weight: float = 0.0,
+                                       ctc_weight: float = 0.0, attn_weight: float = 0.0,
+                                       transducer_weight: float = 0.0, search_ctc_weight: float = 1.0,
+                                       search_transducer_weight: float = 0.0, beam_search_type: str = "transducer"):
+        """transducer.py:379-513 (transducer n-best; the CTC n-best branch needs the ASRModel CTC prefix beam
+        search)."""
+        assert speech.shape[0] == speech_lengths.shape[0]
+        assert decoding_chunk_size != 0
+        if reverse_weight > 0.0:
+            assert hasattr(self.decoder, "right_decoder")
+        device = speech.device
+        assert speech.shape[0] == 1
+        self.init_bs()
+        if beam_search_type != "transducer":
+            raise NotImplementedError("beam_search_type='ctc' is not built yet (SURVEY.md section 8f item 1)")
+        beam, encoder_out = self.bs.prefix_beam_search(speech, speech_lengths, decoding_chunk_size=decoding_chunk_size,
+                                                       beam_size=beam_size,
+                                                       num_decoding_left_chunks=num_decoding_left_chunks,
+                                                       ctc_weight=search_ctc_weight,
+                                                       transducer_weight=search_transducer_weight)
+        beam_score = [s.score for s in beam]
+        hyps = [s.hyp[1:] for s in beam]
+        assert len(hyps) == beam_size
+        hyps_pad = pad_sequence([torch.tensor(h, device=device, dtype=torch.long) for h in hyps], True, self.ignore_id)
+        hyps_lens = torch.tensor([len(h) for h in hyps], device=device, dtype=torch.long)
+        encoder_out = encoder_out.repeat(beam_size, 1, 1)
+        encoder_mask = torch.ones(beam_size, 1, encoder_out.size(1), dtype=torch.bool, device=device)
+        td_score = self._cal_transducer_score(encoder_out, encoder_mask, hyps_lens, hyps_pad)
+        decoder_out, r_decoder_out = self._cal_attn_score(encoder_out, encoder_mask, hyps_pad, hyps_lens)
+        best_score, best_index = -float("inf"), 0
+        for i, hyp in enumerate(hyps):
+            score = 0.0
+            for j, w in enumerate(hyp):
+                score += decoder_out[i][j][w]
+            score += decoder_out[i][len(hyp)][self.eos]
+            td_s = td_score[i]
+            if reverse_weight > 0:
+                r_score = 0.0
+                for j, w in enumerate(hyp):
+                    r_score += r_decoder_out[i][len(hyp) - j - 1][w]
+                r_score += r_decoder_out[i][len(hyp)][self.eos]
+                score = score * (1 - reverse_weight) + r_score * reverse_weight
+            score = score * attn_weight + beam_score[i] * ctc_weight + td_s * transducer_weight
+            if score > best_score:
+                best_score, best_index = score, i
+        return hyps[best_index], best_score
+
+    def greedy_search(self, speech: torch.Tensor, speech_lengths: torch.Tensor, decoding_chunk_size: int = -1,
+                      num_decoding_left_chunks: int = -1, simulate_streaming: bool = False, n_steps: int = 64,
+                      context_list: torch.Tensor = torch.IntTensor([0]),
+                      context_lengths: torch.Tensor = torch.IntTensor([0]), context_filter_state: str = "on",
+                      context_decoder_labels_padded: torch.Tensor = torch.IntTensor([0])):
+        """transducer.py:515-598 -> (hyps: List[List[int]], dist).  With no hot-word module the fork's
+        variants reduce to the upstream loop and `dist` (an edit distance over the hot-word gate trace) is 0."""
+        assert speech.size(0) == 1
+        assert speech.shape[0] == speech_lengths.shape[0]
+        assert decoding_chunk_size != 0
+        _ = simulate_streaming
+        if self.context_bias is not None:
+            raise NotImplementedError("greedy_search with a ContextBias module (hot-word gating / go-back, "
+                                      "greedy_search.py:34-430) is not built yet: SURVEY.md section 8f item 3")
+        encoder_out, encoder_mask = self.encoder(speech, speech_lengths, decoding_chunk_size, num_decoding_left_chunks)
+        encoder_out_lens = encoder_mask.squeeze(1).sum()
+        hyps = basic_greedy_search(self, encoder_out, encoder_out_lens, n_steps=n_steps)
+        return hyps, 0
+
+    def greedy_search_batch(self, speech: torch.Tensor, speech_lengths: torch.Tensor, decoding_chunk_size: int = -1,
+                            num_decoding_left_chunks: int = -1, n_steps: int = 64) -> List[List[int]]:
+        """Extension: N independent streams decoded together (BASELINE config 3)."""
+        encoder_out, encoder_mask = self.encoder(speech, speech_lengths, decoding_chunk_size, num_decoding_left_chunks)
+        return basic_greedy_search(self, encoder_out, encoder_mask.squeeze(1).sum(1), n_steps=n_steps)
+
+    # ----------------------------------------------------- step exports (:600-629) --
+    def forward_encoder_chunk(self, xs, offset: int, required_cache_size: int, att_cache=torch.zeros(0, 0, 0, 0),
+                              cnn_cache=torch.zeros(0, 0, 0, 0)):
+        return self.encoder.forward_chunk(xs, offset, required_cache_size, att_cache, cnn_cache)
+
+    def forward_predictor_step(self, xs: torch.Tensor, cache: List[torch.Tensor]):
+        assert len(cache) == 2
+        padding = torch.zeros(1, 1, device=xs.device)
+        return self.predictor.forward_step(xs, padding, cache)
+
+    def forward_joint_step(self, enc_out: torch.Tensor, pred_out: torch.Tensor) -> torch.Tensor:
+        return self.joint(enc_out, pred_out)
+
+    def forward_predictor_init_state(self) -> List[torch.Tensor]:
+        return self.predictor.init_state(1, device=self.joint.ffn_out.weight.device)
