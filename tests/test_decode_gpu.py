@@ -41,7 +41,7 @@ def build_modules(d, with_ctc=False):
     ctc = None
     if with_ctc:
         ctc = w.CTC(V, E).to(DEV).eval()
-        ctc.load_state_dict({k: torch.tensor(v) for k, v in sub(d, "ctc_").items()})
+        ctc.load_state_dict({k[4:]: torch.tensor(d[k]) for k in d.files if k.startswith("ctc_ctc_lo")})
     return pred, joint, ctc
 
 
@@ -149,7 +149,8 @@ def test_prefix_beam_batched_equals_single():
         assert [s.hyp for s in single] == [s.hyp for s in batch[b]]
         np.testing.assert_allclose([s.score for s in single], [s.score for s in batch[b]], rtol=1e-6)
     p = do.Predictor(sub(d, "pred_"), int(d["n_layers"])); j = do.Joint(sub(d, "joint_"))
-    ref = do.prefix_beam_search(p, j, sub(d, "ctc_"), encs[1].cpu().numpy(), T - 5, beam_size=4)
+    ref = do.prefix_beam_search(p, j, {k[4:]: d[k] for k in d.files if k.startswith("ctc_ctc_lo")},
+                                encs[1].cpu().numpy(), T - 5, beam_size=4)
     assert [s["hyp"] for s in ref] == [s.hyp for s in batch[1]]
 
 
@@ -162,8 +163,9 @@ def test_config3_shape_streams_match_oracle():
     V, E, P, J, H, L, N, T = 5000, 256, 256, 512, 256, 2, 64, 32
     pred = w.RNNPredictor(V, P, P, 0.1, H, L).to(DEV).eval()
     joint = w.TransducerJoint(V, E, P, J).to(DEV).eval()
-    with torch.no_grad():
-        joint.ffn_out.bias[0] += 2.5             # a realistic share of blanks
+    with torch.no_grad():                        # spread the logits (clear top-1/top-2 margins) and favour blank
+        joint.ffn_out.weight *= 10
+        joint.ffn_out.bias[0] += 13.0
     model = types.SimpleNamespace(blank=0, predictor=pred, joint=joint)
     enc = torch.randn(N, T, E, device=DEV)
     lens = torch.randint(8, T + 1, (N,)); lens[0] = T

@@ -85,7 +85,7 @@ class RNNPredictor(nn.Module):
         assert len(cache) == 2
         state_m, state_c = cache
         N = input.size(0)
-        if self._step_joint is None or self._step_joint.ffn_out.weight.device != self.embed.weight.device:
+        if self._step_joint is None or self._step_joint[0].ffn_out.weight.device != self.embed.weight.device:
             self._step_joint = [_StepJoint(self.projection.weight.shape[0], self.embed.weight.device)]
         dec = self._step_cache.get(self, self._step_joint[0], lanes=N, utts=1, tmax=1, max_hyp=0, beam=1)
         out, m, c = dec.predictor_step(input.reshape(-1), state_m, state_c)
