@@ -1,0 +1,130 @@
+"""End-to-end checks of wenet_celoss_amd.Transducer on the GPU with a tiny stand-in
+encoder: the forward dict and every gradient agree with an independent float64
+evaluation (torch autograd for the dense parts, CPU oracle for RNN-T / CTC), and
+the decode wrappers return the reference's shapes."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class TinyEncoder(torch.nn.Module):
+    """Linear + frame mask; returns (encoder_out, mask) like wenet encoders (encoder.py forward)."""
+
+    def __init__(self, idim, odim):
+        super().__init__()
+        self.proj = torch.nn.Linear(idim, odim)
+
+    def forward(self, xs, xs_lens, decoding_chunk_size=0, num_decoding_left_chunks=-1):
+        T = xs.size(1)
+        mask = (torch.arange(T, device=xs.device)[None, :] < xs_lens[:, None].to(xs.device)).unsqueeze(1)
+        return torch.tanh(self.proj(xs)), mask
+
+
+def build(V=23, E=12, P=10, J=16, H=14, ctc_w=0.3):
+    import wenet_celoss_amd as w
+    torch.manual_seed(1)
+    return w.Transducer(V, 0, TinyEncoder(8, E), w.RNNPredictor(V, P, P, 0.0, H, 2, dropout=0.0),
+                        w.TransducerJoint(V, E, P, J), ctc=w.CTC(V, E), ctc_weight=ctc_w, transducer_weight=1.0 - ctc_w,
+                        hw_weight=0.0).to(DEV)
+
+
+def test_forward_dict_and_gradients_match_float64():
+    m = build()
+    B, Tin, U = 3, 11, 4
+    g = torch.Generator().manual_seed(2)
+    speech = torch.randn(B, Tin, 8, generator=g).to(DEV)
+    slen = torch.tensor([11, 7, 9], dtype=torch.int32, device=DEV)
+    text = torch.tensor([[3, 5, 2, 9], [4, 4, -1, -1], [7, 1, 6, -1]], device=DEV)
+    tlen = torch.tensor([4, 2, 3], dtype=torch.int32, device=DEV)
+    out = m(speech, slen, text, tlen)
+    assert set(out.keys()) == {"loss", "loss_att", "loss_ctc", "loss_rnnt", "hw_loss"}
+    assert out["loss_att"] is None and out["hw_loss"] is None
+    out["loss"].backward()
+
+    # independent float64 evaluation
+    md = {k: v.detach().double().cpu() for k, v in m.state_dict().items()}
+    prm = {k: v.clone().requires_grad_(True) for k, v in md.items()}
+    x = speech.double().cpu()
+    enc = torch.tanh(x @ prm["encoder.proj.weight"].T + prm["encoder.proj.bias"])
+    ys_in = torch.cat([torch.zeros(B, 1, dtype=torch.long), torch.where(text.cpu() < 0, 0, text.cpu())], 1)
+    emb = prm["predictor.embed.weight"][ys_in]
+    # the LSTM cell by hand (gate order i,f,g,o)
+    hs = [torch.zeros(B, 14, dtype=torch.double) for _ in range(2)]
+    cs = [torch.zeros(B, 14, dtype=torch.double) for _ in range(2)]
+    outs = []
+    for t in range(U + 1):
+        inp = emb[:, t]
+        for l in range(2):
+            gates = inp @ prm[f"predictor.rnn.weight_ih_l{l}"].T + prm[f"predictor.rnn.bias_ih_l{l}"] + \
+                hs[l] @ prm[f"predictor.rnn.weight_hh_l{l}"].T + prm[f"predictor.rnn.bias_hh_l{l}"]
+            i, f, gg, o = gates.chunk(4, 1)
+            cs[l] = torch.sigmoid(f) * cs[l] + torch.sigmoid(i) * torch.tanh(gg)
+            hs[l] = torch.sigmoid(o) * torch.tanh(cs[l])
+            inp = hs[l]
+        outs.append(inp)
+    pred = torch.stack(outs, 1) @ prm["predictor.projection.weight"].T + prm["predictor.projection.bias"]
+    ep = enc @ prm["joint.enc_ffn.weight"].T + prm["joint.enc_ffn.bias"]
+    pp = pred @ prm["joint.pred_ffn.weight"].T + prm["joint.pred_ffn.bias"]
+    logits = torch.tanh(ep[:, :, None] + pp[:, None]) @ prm["joint.ffn_out.weight"].T + prm["joint.ffn_out.bias"]
+    ctc_logits = enc @ prm["ctc.ctc_lo.weight"].T + prm["ctc.ctc_lo.bias"]
+    # losses through the CPU oracle (values + gradients w.r.t. logits), chained into autograd
+    lnp = logits.detach().float().numpy()
+    ytxt = np.where(text.cpu().numpy() < 0, 0, text.cpu().numpy()).astype(np.int32)
+    rc, rg = oracle.rnnt_loss_f64(lnp, ytxt, slen.cpu().numpy(), tlen.cpu().numpy())
+    cn, cg = oracle.ctc_loss_f64(ctc_logits.detach().float().numpy(), ytxt, slen.cpu().numpy(), tlen.cpu().numpy())
+    loss_rnnt, loss_ctc = rc.mean(), cn.sum() / B
+    total = 0.7 * loss_rnnt + 0.3 * loss_ctc
+    assert out["loss_rnnt"].item() == pytest.approx(loss_rnnt, rel=1e-5)
+    assert out["loss_ctc"].item() == pytest.approx(loss_ctc, rel=1e-5)
+    assert out["loss"].item() == pytest.approx(total, rel=1e-5)
+    surrogate = (logits * torch.tensor(rg, dtype=torch.double) * (0.7 / B)).sum() + \
+        (ctc_logits * torch.tensor(cg, dtype=torch.double) * (0.3 / B)).sum()
+    surrogate.backward()
+    for name, p in m.named_parameters():
+        ref = prm[name].grad
+        assert ref is not None, name
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref.numpy(), rtol=2e-3, atol=2e-5, err_msg=name)
+
+
+def test_decode_wrappers_shapes_and_consistency():
+    import wenet_celoss_amd as w
+    m = build().eval()
+    with torch.no_grad():
+        m.joint.ffn_out.weight *= 6
+        m.joint.ffn_out.bias[0] += 1.0
+    speech = torch.randn(1, 40, 8, device=DEV)
+    slen = torch.tensor([40], dtype=torch.int32, device=DEV)
+    hyps, dist = m.greedy_search(speech, slen)
+    assert isinstance(hyps, list) and len(hyps) == 1 and dist == 0
+    hyp, score = m.beam_search(speech, slen, beam_size=4, context_list=None, context_lengths=None)   # extra kwargs ignored
+    assert isinstance(hyp, list) and isinstance(score, float)
+    # beam 1 with the transducer score only follows the greedy path while at most one token is emitted per frame
+    b1, _ = m.beam_search(speech, slen, beam_size=1, ctc_weight=0.0, transducer_weight=1.0)
+    g1, _ = m.greedy_search(speech, slen, n_steps=1)
+    assert b1 == g1[0]
+    # rescoring score helper: -rnnt_loss(reduction='none') per hypothesis
+    enc_out, mask = m.encoder(speech, slen)
+    hyps_pad = torch.tensor([hyp + [-1] * (max(len(hyp), 1) - len(hyp))] if hyp else [[-1]], device=DEV)
+    if hyp:
+        td = m._cal_transducer_score(enc_out, mask, torch.tensor([len(hyp)], device=DEV), hyps_pad)
+        assert td.shape == (1,) and td.item() < 0
+    # batch extension equals one-by-one
+    sp = torch.randn(3, 40, 8, device=DEV)
+    sl = torch.tensor([40, 25, 33], dtype=torch.int32, device=DEV)
+    batch = m.greedy_search_batch(sp, sl)
+    for i in range(3):
+        one, _ = m.greedy_search(sp[i:i + 1, :sl[i]], sl[i:i + 1])
+        assert one[0] == batch[i]
+    with pytest.raises(AssertionError):
+        m.greedy_search(sp, sl)                              # reference asserts batch size 1 (transducer.py:545)
+    # step exports
+    cache = m.forward_predictor_init_state()
+    o, c2 = m.forward_predictor_step(torch.zeros(1, 1, dtype=torch.long, device=DEV), cache)
+    assert o.shape == (1, 1, 10) and c2[0].shape == cache[0].shape
+    js = m.forward_joint_step(enc_out[:, :1], o)
+    assert js.shape == (1, 1, 1, 23)
