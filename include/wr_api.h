@@ -48,6 +48,11 @@ enum wr_status {
 int wr_api_version(void);
 const char *wr_last_error(void);
 
+/* Benchmarking hook: process-wide launch-shape knobs of the streaming kernels.  Results never depend
+ * on them; the defaults are the measured best.  key 0: workgroups per CU of the RNN-T row-lse pass,
+ * key 1: of the RNN-T gradient pass, key 2: non-temporal loads/stores (0/1). */
+int wr_tune_set(int key, int value);
+
 /* ------------------------------------------------------------------------
  * RNN-T loss + gradient w.r.t. the joiner logits (log-softmax fused).
  * Replaces torchaudio.functional.rnnt_loss(logits, targets, logit_lengths,

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Interleaved A/B of the RNN-T streaming kernels' launch knobs in ONE process (rule: never compare
+timings across processes).  Prints median ms of fwd (lse+sweep) and bwd (grad) per variant."""
+import itertools
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from wenet_celoss_amd import _lib  # noqa: E402
+
+lib = _lib.load()
+dev = torch.device("cuda:0")
+B, T, U, V = int(os.environ.get("B", 8)), 1000, 150, 5000
+U1 = U + 1
+logits = torch.empty(B, T, U1, V, device=dev)
+for b in range(B):
+    logits[b].normal_()
+grads = torch.empty_like(logits)
+targets = torch.randint(1, V, (B, U), dtype=torch.int32, device=dev)
+ll = torch.full((B,), T, dtype=torch.int32, device=dev); tl = torch.full((B,), U, dtype=torch.int32, device=dev)
+wsb = lib.wr_rnnt_workspace_bytes(B, T, U1); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+costs = torch.empty(B, device=dev); gc = torch.full((B,), 1.0 / B, device=dev)
+st = _lib.current_stream(dev); P = _lib.ptr
+fwd = lambda: _lib.check(lib.wr_rnnt_loss_fwd(P(logits), 0, P(targets), P(ll), P(tl), B, T, U1, V, 0, P(costs), P(ws), wsb, st))
+bwd = lambda: _lib.check(lib.wr_rnnt_loss_bwd(P(logits), 0, P(targets), P(ll), P(tl), B, T, U1, V, 0, -1.0, P(gc), P(grads), P(ws), wsb, st))
+
+variants = [dict(lse=l, grad=g, nt=n) for n in (1, 0) for l, g in ((8, 7), (8, 8), (6, 6), (4, 4), (12, 12), (16, 16), (5, 5), (7, 7))]
+res = {i: ([], []) for i in range(len(variants))}
+for rnd in range(int(os.environ.get("ROUNDS", 5))):
+    for i, v in enumerate(variants):
+        lib.wr_tune_set(0, v["lse"]); lib.wr_tune_set(1, v["grad"]); lib.wr_tune_set(2, v["nt"])
+        fwd(); bwd(); torch.cuda.synchronize()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record(); fwd(); e[1].record(); bwd(); e[2].record(); torch.cuda.synchronize()
+        res[i][0].append(e[0].elapsed_time(e[1])); res[i][1].append(e[1].elapsed_time(e[2]))
+med = lambda a: sorted(a)[len(a) // 2]
+for i, v in enumerate(variants):
+    f, b = med(res[i][0]), med(res[i][1])
+    print(json.dumps(dict(v, fwd_ms=round(f, 3), bwd_ms=round(b, 3), fwd_GBs=round(4.0 * V * B * T * U1 / f / 1e6),
+                          bwd_GBs=round(8.0 * V * B * T * U1 / b / 1e6))))

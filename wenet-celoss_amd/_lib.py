@@ -87,6 +87,7 @@ _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_
 SIGNATURES = {
     "wr_api_version": (_i, []),
     "wr_last_error": (ctypes.c_char_p, []),
+    "wr_tune_set": (_i, [_i, _i]),
     "wr_rnnt_workspace_bytes": (_sz, [_i, _i, _i]),
     "wr_rnnt_loss_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "wr_rnnt_loss_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),

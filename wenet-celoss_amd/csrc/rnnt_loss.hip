@@ -29,8 +29,8 @@ namespace wr {
 namespace {
 
 struct RnntWs {
-    int K;            // label columns per lane in the sweep
-    int S;            // number of skewed diagonals per utterance
+    int K;            // label columns per lane in the sweep (lane l owns u = l, l+64, ...)
+    int S;            // number of anti-diagonals per utterance
     size_t lp_off, alpha_off, beta_off, denom_off, ll_off, cost_off, total;
 };
 
@@ -40,7 +40,7 @@ inline RnntWs rnnt_ws_layout(int B, int Tmax, int U1max)
 {
     RnntWs w;
     w.K = rnnt_cols_per_lane(U1max);
-    w.S = Tmax + (U1max - 1) / w.K;
+    w.S = Tmax + U1max - 1;          // anti-diagonals s = t + u
     const size_t diag = (size_t)B * w.S * U1max;
     size_t off = 0;
     w.lp_off = off;    off = align_up(off + diag * sizeof(float2), 256);
@@ -78,7 +78,21 @@ __device__ __forceinline__ void stat_add1(RowStat &st, const float x)
     st.m = nm;
 }
 
+template <bool NT>
+__device__ __forceinline__ f32x4 ld4(const f32x4 *p)
+{
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st4(f32x4 v, f32x4 *p)
+{
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
 // Natural-log log-sum-exp of row[0..V) computed by one wave.
+template <bool NT>
 __device__ __forceinline__ float wave_row_lse(const float *__restrict__ row, int V, int lane)
 {
     RowStat st{-3.0e38f, 0.f};
@@ -92,18 +106,19 @@ __device__ __forceinline__ float wave_row_lse(const float *__restrict__ row, int
     const f32x4 *__restrict__ body = reinterpret_cast<const f32x4 *>(row + h);
     int i = lane;
     for (; i + 3 * kWave < n4; i += 4 * kWave) {
-        const f32x4 a = __builtin_nontemporal_load(body + i);
-        const f32x4 b = __builtin_nontemporal_load(body + i + kWave);
-        const f32x4 c = __builtin_nontemporal_load(body + i + 2 * kWave);
-        const f32x4 d = __builtin_nontemporal_load(body + i + 3 * kWave);
+        const f32x4 a = ld4<NT>(body + i);
+        const f32x4 b = ld4<NT>(body + i + kWave);
+        const f32x4 c = ld4<NT>(body + i + 2 * kWave);
+        const f32x4 d = ld4<NT>(body + i + 3 * kWave);
         stat_add4(st, a); stat_add4(st, b); stat_add4(st, c); stat_add4(st, d);
     }
-    for (; i < n4; i += kWave) stat_add4(st, __builtin_nontemporal_load(body + i));
+    for (; i < n4; i += kWave) stat_add4(st, ld4<NT>(body + i));
     const float M = wave_max(st.m);
     const float s = wave_sum(st.s * fast_exp2(st.m - M));
     return (M + fast_log2(s)) * kLn2;
 }
 
+template <bool NT>
 __global__ __launch_bounds__(256) void rnnt_lse_kernel(
     const float *__restrict__ logits, const int32_t *__restrict__ targets,
     const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens,
@@ -124,7 +139,7 @@ __global__ __launch_bounds__(256) void rnnt_lse_kernel(
         const int T = llens[b], U = tlens[b];
         if (t >= T || u > U) continue;
         const float *row = logits + (size_t)r * V;
-        const float d = wave_row_lse(row, V, lane);
+        const float d = wave_row_lse<NT>(row, V, lane);
         if (lane == 0) {
             const float xb = row[blank];
             float em = 0.f;
@@ -133,7 +148,7 @@ __global__ __launch_bounds__(256) void rnnt_lse_kernel(
                 em = row[lab] - d;
             }
             denom[r] = d;
-            const int s = t + u / K;
+            const int s = t + u;
             lp_skew[((size_t)b * S + s) * U1max + u] = make_float2(xb - d, em);
         }
     }
@@ -154,20 +169,27 @@ __device__ __forceinline__ double log_add_exp_d(double a, double b)
     return (m == (double)kNegInf) ? (double)kNegInf : m + (double)r;
 }
 
-__device__ __forceinline__ double lane_shift_up_d(double v, double fill)
+// Rotate a double by one lane: lane l receives lane l-1 (lane 0 receives lane 63).  gfx9 DPP wave_ror:1.
+__device__ __forceinline__ double lane_rotate_up_d(double v)
 {
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), 0x138, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), 0x138, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x13C, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x13C, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ double lane_shift_down_d(double v, double fill)
+// Lane l receives lane l+1 (lane 63 receives lane 0).  DPP wave_rol:1.
+__device__ __forceinline__ double lane_rotate_down_d(double v)
 {
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), 0x130, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), 0x130, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x134, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x134, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 
+// One wave per (utterance, direction).  Lane l owns the K label columns u_j = l + 64 j and at step s
+// works on the cells (t = s - u_j, u_j) of anti-diagonal s: the K cells of a lane are independent of
+// each other (K-way ILP), and what a cell needs from diagonal s -/+ 1 is its own previous value and the
+// previous value of the neighbouring lane (lane 63 wraps to lane 0's next column block) -- one DPP
+// wave rotate per owned column, no LDS, no barrier.
 template <int K, int PF>
 __global__ __launch_bounds__(64) void rnnt_sweep_kernel(
     const float2 *__restrict__ lp_skew, const int32_t *__restrict__ llens,
@@ -184,8 +206,7 @@ __global__ __launch_bounds__(64) void rnnt_sweep_kernel(
     U = U < 0 ? 0 : (U > U1max - 1 ? U1max - 1 : U);
     const float2 *__restrict__ lp = lp_skew + (size_t)b * S * U1max;
     double *__restrict__ out = (backward ? beta_skew : alpha_skew) + (size_t)b * S * U1max;
-    const int u0 = lane * K;
-    const int nsteps = (T > 0) ? T + U / K : 0;   // diagonals that hold a valid cell
+    const int nsteps = (T > 0) ? T + U : 0;       // anti-diagonals that hold a valid cell
 
     if (nsteps == 0) {
         if (lane == 0) {
@@ -197,19 +218,19 @@ __global__ __launch_bounds__(64) void rnnt_sweep_kernel(
     auto load_row = [&](int s, float2 (&dst)[K]) {
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const int u = u0 + j;
-            const int t = s - lane;
+            const int u = lane + kWave * j;
+            const int t = s - u;
             const bool ok = (s >= 0) & (s < nsteps) & (t >= 0) & (t < T) & (u <= U);
             dst[j] = ok ? lp[(size_t)s * U1max + u] : make_float2(0.f, 0.f);
         }
     };
 
     float2 ring[PF][K];
-    double st[K];     // alpha(t-1, u_j)  /  beta(t+1, u_j)
+    double st[K];     // alpha(t-1, u_j)  /  beta(t+1, u_j): this lane's value on the previous diagonal
     float skp[K];     // forward only: skip(t-1, u_j)
+    double send[K];   // what the neighbouring lane needs from this lane's previous diagonal
 #pragma unroll
-    for (int j = 0; j < K; ++j) { st[j] = NEG; skp[j] = 0.f; }
-    double send = NEG;
+    for (int j = 0; j < K; ++j) { st[j] = NEG; skp[j] = 0.f; send[j] = NEG; }
 
     if (!backward) {
 #pragma unroll
@@ -223,30 +244,27 @@ __global__ __launch_bounds__(64) void rnnt_sweep_kernel(
                 for (int j = 0; j < K; ++j) cur[j] = ring[i][j];
                 load_row(s + PF, ring[i]);
                 if (s < nsteps) {
-                    const int t = s - lane;
-                    const bool active = (t >= 0) & (t < T);
-                    const double left_in = lane_shift_up_d(send, NEG);
-                    double nw[K];
+                    double rot[K];
+#pragma unroll
+                    for (int j = 0; j < K; ++j) rot[j] = lane_rotate_up_d(send[j]);
 #pragma unroll
                     for (int j = 0; j < K; ++j) {
-                        const int u = u0 + j;
+                        const int u = lane + kWave * j;
+                        const int t = s - u;
+                        const bool active = (t >= 0) & (t < T) & (u <= U);
+                        // alpha(t, u-1) + emit(t, u-1): from lane-1, or for lane 0 from lane 63's previous column block
+                        const double recv = (lane == 0) ? (j == 0 ? NEG : rot[j > 0 ? j - 1 : 0]) : rot[j];
                         const double top = (t >= 1) ? st[j] + (double)skp[j] : NEG;
-                        double left = (j == 0) ? left_in : nw[j > 0 ? j - 1 : 0] + (double)cur[j > 0 ? j - 1 : 0].y;
-                        left = (u >= 1) ? left : NEG;
+                        const double left = (u >= 1) ? recv : NEG;
                         double v = log_add_exp_d(top, left);
                         v = (t == 0 && u == 0) ? 0.0 : v;
-                        v = (active && u <= U) ? v : NEG;
-                        nw[j] = v;
-                    }
-                    send = nw[K - 1] + (double)cur[K - 1].y;
-#pragma unroll
-                    for (int j = 0; j < K; ++j) {
-                        const int u = u0 + j;
-                        if (active && u <= U) {
-                            out[(size_t)s * U1max + u] = nw[j];
-                            if (t == T - 1 && u == U) ll_out[b] = nw[j] + (double)cur[j].x;
+                        v = active ? v : NEG;
+                        if (active) {
+                            out[(size_t)s * U1max + u] = v;
+                            if (t == T - 1 && u == U) ll_out[b] = v + (double)cur[j].x;
                         }
-                        st[j] = nw[j];
+                        send[j] = v + (double)cur[j].y;
+                        st[j] = v;
                         skp[j] = cur[j].x;
                     }
                 }
@@ -264,30 +282,27 @@ __global__ __launch_bounds__(64) void rnnt_sweep_kernel(
                 for (int j = 0; j < K; ++j) cur[j] = ring[i][j];
                 load_row(s - PF, ring[i]);
                 if (s >= 0) {
-                    const int t = s - lane;
-                    const bool active = (t >= 0) & (t < T);
-                    const double right_in = lane_shift_down_d(send, NEG);
-                    double nw[K];
+                    double rot[K];
 #pragma unroll
-                    for (int j = K - 1; j >= 0; --j) {
-                        const int u = u0 + j;
-                        const double down = (t < T - 1) ? st[j] + (double)cur[j].x : NEG;
-                        double right = (j == K - 1) ? right_in : nw[j < K - 1 ? j + 1 : K - 1];
-                        right = (u < U) ? right + (double)cur[j].y : NEG;
-                        double v = log_add_exp_d(down, right);
-                        v = (t == T - 1 && u == U) ? (double)cur[j].x : v;
-                        v = (active && u <= U) ? v : NEG;
-                        nw[j] = v;
-                    }
-                    send = nw[0];
+                    for (int j = 0; j < K; ++j) rot[j] = lane_rotate_down_d(send[j]);
 #pragma unroll
                     for (int j = 0; j < K; ++j) {
-                        const int u = u0 + j;
-                        if (active && u <= U) {
-                            out[(size_t)s * U1max + u] = nw[j];
-                            if (t == 0 && u == 0) { cost_ws[b] = -nw[j]; costs_out[b] = (float)(-nw[j]); }
+                        const int u = lane + kWave * j;
+                        const int t = s - u;
+                        const bool active = (t >= 0) & (t < T) & (u <= U);
+                        // beta(t, u+1): from lane+1, or for lane 63 from lane 0's next column block
+                        const double recv = (lane == kWave - 1) ? (j == K - 1 ? NEG : rot[j < K - 1 ? j + 1 : K - 1]) : rot[j];
+                        const double down = (t < T - 1) ? st[j] + (double)cur[j].x : NEG;
+                        const double right = (u < U) ? recv + (double)cur[j].y : NEG;
+                        double v = log_add_exp_d(down, right);
+                        v = (t == T - 1 && u == U) ? (double)cur[j].x : v;
+                        v = active ? v : NEG;
+                        if (active) {
+                            out[(size_t)s * U1max + u] = v;
+                            if (t == 0 && u == 0) { cost_ws[b] = -v; costs_out[b] = (float)(-v); }
                         }
-                        st[j] = nw[j];
+                        send[j] = v;
+                        st[j] = v;
                     }
                 }
             }
@@ -296,6 +311,7 @@ __global__ __launch_bounds__(64) void rnnt_sweep_kernel(
 }
 
 // ------------------------------------------------------------------ pass 3 --
+template <bool NT>
 __global__ __launch_bounds__(256) void rnnt_grad_kernel(
     const float *logits, const int32_t *__restrict__ targets,
     const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens,
@@ -330,12 +346,12 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             if (lane < h) grow[lane] = 0.f;
             if (lane < tail) grow[h + 4 * n4 + lane] = 0.f;
-            for (int i = lane; i < n4; i += kWave) __builtin_nontemporal_store(z, gbody + i);
+            for (int i = lane; i < n4; i += kWave) st4<NT>(z, gbody + i);
             continue;
         }
 
         const size_t dbase = (size_t)b * S * U1max;
-        const int s = t + u / K;
+        const int s = t + u;
         // Lattice state is fp64; the combinations below are small in magnitude
         // (log-occupancies), so they are formed in fp64 and only then rounded.
         const double al = alpha_skew[dbase + (size_t)s * U1max + u];
@@ -358,7 +374,7 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(
         if (u < U) {
             lab = targets[(size_t)b * (U1max - 1) + u];
             if (lab == blank && blank_special) lab = -1;
-            else lab_sub = (float)(cmd + beta_skew[dbase + (size_t)(t + (u + 1) / K) * U1max + (u + 1)]);
+            else lab_sub = (float)(cmd + beta_skew[dbase + (size_t)(s + 1) * U1max + (u + 1)]);
         }
         const int blk = blank_special ? blank : -1;
 
@@ -399,17 +415,17 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(
                 g.w = fix(g.w, x.w, v0 + 3);
             }
             g.x = finish(g.x); g.y = finish(g.y); g.z = finish(g.z); g.w = finish(g.w);
-            __builtin_nontemporal_store(g, gbody + i);
+            st4<NT>(g, gbody + i);
         };
         int i = lane;
         for (; i + 3 * kWave < n4; i += 4 * kWave) {
-            const f32x4 a = __builtin_nontemporal_load(body + i);
-            const f32x4 bq = __builtin_nontemporal_load(body + i + kWave);
-            const f32x4 cq = __builtin_nontemporal_load(body + i + 2 * kWave);
-            const f32x4 dq = __builtin_nontemporal_load(body + i + 3 * kWave);
+            const f32x4 a = ld4<NT>(body + i);
+            const f32x4 bq = ld4<NT>(body + i + kWave);
+            const f32x4 cq = ld4<NT>(body + i + 2 * kWave);
+            const f32x4 dq = ld4<NT>(body + i + 3 * kWave);
             do4(i, a); do4(i + kWave, bq); do4(i + 2 * kWave, cq); do4(i + 3 * kWave, dq);
         }
-        for (; i < n4; i += kWave) do4(i, __builtin_nontemporal_load(body + i));
+        for (; i < n4; i += kWave) do4(i, ld4<NT>(body + i));
     }
 }
 
@@ -427,7 +443,7 @@ __global__ void rnnt_export_kernel(const double *__restrict__ alpha_skew, const 
         const int t = c / U1max, u = c - t * U1max;
         float a = 0.f, be = 0.f;
         if (t < llens[b] && u <= tlens[b]) {
-            const size_t k = ((size_t)b * S + t + u / K) * U1max + u;
+            const size_t k = ((size_t)b * S + t + u) * U1max + u;
             a = (float)alpha_skew[k];
             be = (float)beta_skew[k];
         }
@@ -447,11 +463,13 @@ int check_shape(int B, int Tmax, int U1max, int V, int blank)
     return WR_OK;
 }
 
-int stream_grid(long nrows)
+int stream_grid(long nrows, int blocks_per_cu)
 {
-    // HBM-streaming grid: enough 4-wave blocks to fill 256 CUs at 8 blocks/CU, grid-stride beyond.
+    // HBM-streaming grid: 4-wave blocks, `blocks_per_cu` per CU (all resident: no tail of late blocks),
+    // grid-stride beyond.
     long blocks = (nrows + 3) / 4;
-    if (blocks > 256 * 8) blocks = 256 * 8;
+    const long cap = 256L * blocks_per_cu;
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
@@ -494,10 +512,15 @@ extern "C" int wr_rnnt_loss_fwd(const void *logits_d, int dtype, const int32_t *
     hipStream_t st = static_cast<hipStream_t>(stream);
     char *ws = static_cast<char *>(workspace_d);
     const long nrows = (long)B * Tmax * U1max;
-    hipLaunchKernelGGL(rnnt_lse_kernel, dim3(stream_grid(nrows)), dim3(256), 0, st,
-                       static_cast<const float *>(logits_d), targets_d, logit_lengths_d, target_lengths_d, B, Tmax,
-                       U1max, V, blank, w.K, w.S, reinterpret_cast<float2 *>(ws + w.lp_off),
-                       reinterpret_cast<float *>(ws + w.denom_off));
+    const dim3 grid1(stream_grid(nrows, tune_get(kTuneLseBlocksPerCu)));
+    if (tune_get(kTuneNonTemporal))
+        hipLaunchKernelGGL(rnnt_lse_kernel<true>, grid1, dim3(256), 0, st, static_cast<const float *>(logits_d), targets_d,
+                           logit_lengths_d, target_lengths_d, B, Tmax, U1max, V, blank, w.K, w.S,
+                           reinterpret_cast<float2 *>(ws + w.lp_off), reinterpret_cast<float *>(ws + w.denom_off));
+    else
+        hipLaunchKernelGGL(rnnt_lse_kernel<false>, grid1, dim3(256), 0, st, static_cast<const float *>(logits_d), targets_d,
+                           logit_lengths_d, target_lengths_d, B, Tmax, U1max, V, blank, w.K, w.S,
+                           reinterpret_cast<float2 *>(ws + w.lp_off), reinterpret_cast<float *>(ws + w.denom_off));
     WR_CHECK_LAUNCH("rnnt_lse_kernel");
     switch (w.K) {
         case 1: launch_sweep<1>(w, ws, logit_lengths_d, target_lengths_d, B, Tmax, U1max, costs_d, st); break;
@@ -529,12 +552,17 @@ extern "C" int wr_rnnt_loss_bwd(const void *logits_d, int dtype, const int32_t *
     hipStream_t st = static_cast<hipStream_t>(stream);
     const char *ws = static_cast<const char *>(workspace_d);
     const long nrows = (long)B * Tmax * U1max;
-    hipLaunchKernelGGL(rnnt_grad_kernel, dim3(stream_grid(nrows)), dim3(256), 0, st,
-                       static_cast<const float *>(logits_d), targets_d, logit_lengths_d, target_lengths_d, B, Tmax,
-                       U1max, V, blank, clamp, w.K, w.S, reinterpret_cast<const double *>(ws + w.alpha_off),
-                       reinterpret_cast<const double *>(ws + w.beta_off),
-                       reinterpret_cast<const float *>(ws + w.denom_off),
-                       reinterpret_cast<const double *>(ws + w.cost_off), grad_costs_d, static_cast<float *>(grads_d));
+    const dim3 grid3(stream_grid(nrows, tune_get(kTuneGradBlocksPerCu)));
+#define WR_LAUNCH_GRAD(NT)                                                                                          \
+    hipLaunchKernelGGL(rnnt_grad_kernel<NT>, grid3, dim3(256), 0, st, static_cast<const float *>(logits_d), targets_d, \
+                       logit_lengths_d, target_lengths_d, B, Tmax, U1max, V, blank, clamp, w.K, w.S,                 \
+                       reinterpret_cast<const double *>(ws + w.alpha_off),                                           \
+                       reinterpret_cast<const double *>(ws + w.beta_off),                                            \
+                       reinterpret_cast<const float *>(ws + w.denom_off),                                            \
+                       reinterpret_cast<const double *>(ws + w.cost_off), grad_costs_d, static_cast<float *>(grads_d))
+    if (tune_get(kTuneNonTemporal)) WR_LAUNCH_GRAD(true);
+    else WR_LAUNCH_GRAD(false);
+#undef WR_LAUNCH_GRAD
     WR_CHECK_LAUNCH("rnnt_grad_kernel");
     return WR_OK;
 }
