@@ -86,9 +86,84 @@ def bench_ctc(args):
                       "cpu_utt_per_s": round(B / cpu_ms * 1e3, 1), "cpu_threads": torch.get_num_threads()}), flush=True)
 
 
+def bench_greedy(args):
+    """BASELINE config 3: B=64 streams, chunks of 16 encoder frames, V=5000, LSTM 2x256, J=512, n_steps=64."""
+    import time
+    import types
+    import wenet_celoss_amd as w
+    from oracle import decode_oracle as do
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    V, E, P, J, H, L, N = 5000, 256, 256, 512, 256, 2, 64
+    T = 16 * args.chunks
+    pred = w.RNNPredictor(V, P, P, 0.1, H, L).to(dev).eval()
+    joint = w.TransducerJoint(V, E, P, J).to(dev).eval()
+    with torch.no_grad():
+        joint.ffn_out.weight *= 10
+        joint.ffn_out.bias[0] += 16.0
+    model = types.SimpleNamespace(blank=0, predictor=pred, joint=joint)
+    enc = torch.randn(N, T, E, device=dev)
+    lens = torch.full((N,), T)
+    for use_graph in (True, False):
+        hyps = w.basic_greedy_search(model, enc, lens, n_steps=64)          # builds the handle / graph
+        model._decoder_cache._dec.set_graph(use_graph)
+        w.basic_greedy_search(model, enc, lens, n_steps=64)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            hyps = w.basic_greedy_search(model, enc, lens, n_steps=64)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        ntok = sum(len(h) for h in hyps)
+        micro = ntok + N * T                                     # joiner evaluations actually needed
+        print(json.dumps({"what": "greedy_search", "hipGraph": use_graph, "streams": N, "frames": T, "tokens": ntok,
+                          "ms_per_call": round(dt * 1e3, 3), "utt_per_s": round(N / dt, 1),
+                          "lane_steps_per_s": round(micro / dt)}), flush=True)
+    # CPU reference: the reference's loop restated in numpy (oracle), one stream, scaled to 64
+    p = do.Predictor({k: v.detach().cpu().numpy() for k, v in pred.state_dict().items()}, L)
+    j = do.Joint({k: v.detach().cpu().numpy() for k, v in joint.state_dict().items()})
+    t0 = time.perf_counter()
+    ref = do.greedy_search(p, j, enc[0].cpu().numpy(), T, n_steps=64)
+    cdt = time.perf_counter() - t0
+    print(json.dumps({"what": "greedy_search_cpu_oracle", "one_stream_s": round(cdt, 3), "utt_per_s": round(1 / cdt, 2),
+                      "tokens_match": ref == hyps[0]}), flush=True)
+
+
+def bench_beam(args):
+    """BASELINE config 5: beam=8, B=16, T=1500, V=5000."""
+    import time
+    import wenet_celoss_amd as w
+    dev = torch.device("cuda:0")
+    torch.manual_seed(6)
+    V, E, P, J, H, L, B, T, beam = 5000, 256, 256, 512, 256, 2, 16, args.T if args.T != 1000 else 1500, 8
+    pred = w.RNNPredictor(V, P, P, 0.1, H, L).to(dev).eval()
+    joint = w.TransducerJoint(V, E, P, J).to(dev).eval()
+    ctc = w.CTC(V, E).to(dev).eval()
+    with torch.no_grad():
+        joint.ffn_out.weight *= 10
+        joint.ffn_out.bias[0] += 16.0
+    bs = w.PrefixBeamSearch(None, pred, joint, ctc, 0)
+    enc = torch.randn(B, T, E, device=dev)
+    lens = torch.full((B,), T, dtype=torch.int32)
+    for use_graph in (True, False):
+        out = bs.search_encoded(enc, lens, beam_size=beam)
+        bs._decoder_cache._dec.set_graph(use_graph)
+        bs.search_encoded(enc, lens, beam_size=beam)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = bs.search_encoded(enc, lens, beam_size=beam)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        print(json.dumps({"what": "prefix_beam_search", "hipGraph": use_graph, "B": B, "T": T, "beam": beam,
+                          "ms_per_call": round(dt * 1e3, 2), "frames_per_s": round(B * T / dt),
+                          "utt_per_s": round(B / dt, 2), "best_len": len(out[0][0].hyp)}), flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["joint", "ctc"])
+    ap.add_argument("what", choices=["joint", "ctc", "greedy", "beam"])
+    ap.add_argument("--chunks", type=int, default=4)
     ap.add_argument("--B", type=int, default=32)
     ap.add_argument("--T", type=int, default=1000)
     ap.add_argument("--U", type=int, default=150)
@@ -96,4 +171,4 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--dw", action="store_true")
     a = ap.parse_args()
-    {"joint": bench_joint, "ctc": bench_ctc}[a.what](a)
+    {"joint": bench_joint, "ctc": bench_ctc, "greedy": bench_greedy, "beam": bench_beam}[a.what](a)

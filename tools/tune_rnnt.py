@@ -27,7 +27,7 @@ st = _lib.current_stream(dev); P = _lib.ptr
 fwd = lambda: _lib.check(lib.wr_rnnt_loss_fwd(P(logits), 0, P(targets), P(ll), P(tl), B, T, U1, V, 0, P(costs), P(ws), wsb, st))
 bwd = lambda: _lib.check(lib.wr_rnnt_loss_bwd(P(logits), 0, P(targets), P(ll), P(tl), B, T, U1, V, 0, -1.0, P(gc), P(grads), P(ws), wsb, st))
 
-variants = [dict(lse=l, grad=g, nt=n) for n in (1, 0) for l, g in ((8, 7), (8, 8), (6, 6), (4, 4), (12, 12), (16, 16), (5, 5), (7, 7))]
+variants = [dict(lse=l, grad=g, nt=n) for n in (1, 0) for l, g in ((8, 7), (4, 4), (16, 16))]
 res = {i: ([], []) for i in range(len(variants))}
 for rnd in range(int(os.environ.get("ROUNDS", 5))):
     for i, v in enumerate(variants):
@@ -37,6 +37,14 @@ for rnd in range(int(os.environ.get("ROUNDS", 5))):
         e[0].record(); fwd(); e[1].record(); bwd(); e[2].record(); torch.cuda.synchronize()
         res[i][0].append(e[0].elapsed_time(e[1])); res[i][1].append(e[1].elapsed_time(e[2]))
 med = lambda a: sorted(a)[len(a) // 2]
+# same-process, same-device calibration: a plain 1:1 device copy of the same tensors (read + write)
+cp = []
+for _ in range(5):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); grads.copy_(logits); e1.record(); torch.cuda.synchronize()
+    cp.append(e0.elapsed_time(e1))
+print(json.dumps({"calibration": "torch copy_ (read+write)", "ms": round(med(cp), 3),
+                  "GBs": round(8.0 * V * B * T * U1 / med(cp) / 1e6)}))
 for i, v in enumerate(variants):
     f, b = med(res[i][0]), med(res[i][1])
     print(json.dumps(dict(v, fwd_ms=round(f, 3), bwd_ms=round(b, 3), fwd_GBs=round(4.0 * V * B * T * U1 / f / 1e6),

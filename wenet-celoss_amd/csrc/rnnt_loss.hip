@@ -31,7 +31,7 @@ namespace {
 struct RnntWs {
     int K;            // label columns per lane in the sweep (lane l owns u = l, l+64, ...)
     int S;            // number of anti-diagonals per utterance
-    size_t lp_off, alpha_off, beta_off, denom_off, ll_off, cost_off, total;
+    size_t lp_off, alpha_off, beta_off, denom_off, ll_off, cost_off, dump_off, total;
 };
 
 __host__ __device__ inline int rnnt_cols_per_lane(int U1max) { return (U1max + kWave - 1) / kWave; }
@@ -49,6 +49,7 @@ inline RnntWs rnnt_ws_layout(int B, int Tmax, int U1max)
     w.denom_off = off; off = align_up(off + (size_t)B * Tmax * U1max * sizeof(float), 256);
     w.ll_off = off;    off = align_up(off + (size_t)B * sizeof(double), 256);
     w.cost_off = off;  off = align_up(off + (size_t)B * sizeof(double), 256);
+    w.dump_off = off;  off = align_up(off + (size_t)B * 2 * kWave * sizeof(double), 256);
     w.total = off;
     return w;
 }
@@ -195,7 +196,8 @@ __global__ __launch_bounds__(64) void rnnt_sweep_kernel(
     const float2 *__restrict__ lp_skew, const int32_t *__restrict__ llens,
     const int32_t *__restrict__ tlens, int Tmax, int U1max, int S,
     double *__restrict__ alpha_skew, double *__restrict__ beta_skew,
-    double *__restrict__ ll_out, double *__restrict__ cost_ws, float *__restrict__ costs_out)
+    double *__restrict__ ll_out, double *__restrict__ cost_ws, float *__restrict__ costs_out,
+    double *__restrict__ dump /* [2*B*64] scratch that absorbs the stores of idle lanes */)
 {
     constexpr double NEG = (double)kNegInf;
     const int b = blockIdx.x;
@@ -206,6 +208,7 @@ __global__ __launch_bounds__(64) void rnnt_sweep_kernel(
     U = U < 0 ? 0 : (U > U1max - 1 ? U1max - 1 : U);
     const float2 *__restrict__ lp = lp_skew + (size_t)b * S * U1max;
     double *__restrict__ out = (backward ? beta_skew : alpha_skew) + (size_t)b * S * U1max;
+    double *__restrict__ sink = dump + ((size_t)b * 2 + (backward ? 1 : 0)) * kWave + lane;
     const int nsteps = (T > 0) ? T + U : 0;       // anti-diagonals that hold a valid cell
 
     if (nsteps == 0) {
@@ -215,20 +218,26 @@ __global__ __launch_bounds__(64) void rnnt_sweep_kernel(
         return;
     }
 
-    auto load_row = [&](int s, float2 (&dst)[K]) {
+    // The loop body below is straight-line code: loads are unconditional (addresses clamped into the
+    // utterance's rows, values masked afterwards) and idle lanes store to `sink`, so the compiler can
+    // keep PF rows of log-probs in flight with counted s_waitcnt instead of draining every step.
+    int ucol[K];
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const int u = lane + kWave * j;
-            const int t = s - u;
-            const bool ok = (s >= 0) & (s < nsteps) & (t >= 0) & (t < T) & (u <= U);
-            dst[j] = ok ? lp[(size_t)s * U1max + u] : make_float2(0.f, 0.f);
-        }
+    for (int j = 0; j < K; ++j) {
+        const int u = lane + kWave * j;
+        ucol[j] = u < U1max ? u : U1max - 1;
+    }
+    auto load_row = [&](int s, float2 (&dst)[K]) {
+        const int sc = s < 0 ? 0 : (s >= nsteps ? nsteps - 1 : s);
+#pragma unroll
+        for (int j = 0; j < K; ++j) dst[j] = lp[(size_t)sc * U1max + ucol[j]];
     };
 
     float2 ring[PF][K];
     double st[K];     // alpha(t-1, u_j)  /  beta(t+1, u_j): this lane's value on the previous diagonal
     float skp[K];     // forward only: skip(t-1, u_j)
     double send[K];   // what the neighbouring lane needs from this lane's previous diagonal
+    double result = 0.0;
 #pragma unroll
     for (int j = 0; j < K; ++j) { st[j] = NEG; skp[j] = 0.f; send[j] = NEG; }
 
@@ -238,75 +247,77 @@ __global__ __launch_bounds__(64) void rnnt_sweep_kernel(
         for (int base = 0; base < nsteps; base += PF) {
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
-                const int s = base + i;
+                const int s = base + i;           // steps s >= nsteps have no active lane
                 float2 cur[K];
 #pragma unroll
                 for (int j = 0; j < K; ++j) cur[j] = ring[i][j];
                 load_row(s + PF, ring[i]);
-                if (s < nsteps) {
-                    double rot[K];
+                double rot[K];
 #pragma unroll
-                    for (int j = 0; j < K; ++j) rot[j] = lane_rotate_up_d(send[j]);
+                for (int j = 0; j < K; ++j) rot[j] = lane_rotate_up_d(send[j]);
 #pragma unroll
-                    for (int j = 0; j < K; ++j) {
-                        const int u = lane + kWave * j;
-                        const int t = s - u;
-                        const bool active = (t >= 0) & (t < T) & (u <= U);
-                        // alpha(t, u-1) + emit(t, u-1): from lane-1, or for lane 0 from lane 63's previous column block
-                        const double recv = (lane == 0) ? (j == 0 ? NEG : rot[j > 0 ? j - 1 : 0]) : rot[j];
-                        const double top = (t >= 1) ? st[j] + (double)skp[j] : NEG;
-                        const double left = (u >= 1) ? recv : NEG;
-                        double v = log_add_exp_d(top, left);
-                        v = (t == 0 && u == 0) ? 0.0 : v;
-                        v = active ? v : NEG;
-                        if (active) {
-                            out[(size_t)s * U1max + u] = v;
-                            if (t == T - 1 && u == U) ll_out[b] = v + (double)cur[j].x;
-                        }
-                        send[j] = v + (double)cur[j].y;
-                        st[j] = v;
-                        skp[j] = cur[j].x;
-                    }
+                for (int j = 0; j < K; ++j) {
+                    const int u = lane + kWave * j;
+                    const int t = s - u;
+                    const bool active = (t >= 0) & (t < T) & (u <= U);
+                    const float sk = active ? cur[j].x : 0.f;
+                    const float em = active ? cur[j].y : 0.f;
+                    // alpha(t, u-1) + emit(t, u-1): from lane-1, or for lane 0 from lane 63's previous column block
+                    const double recv = (lane == 0) ? (j == 0 ? NEG : rot[j > 0 ? j - 1 : 0]) : rot[j];
+                    const double top = (t >= 1) ? st[j] + (double)skp[j] : NEG;
+                    const double left = (u >= 1) ? recv : NEG;
+                    double v = log_add_exp_d(top, left);
+                    v = (t == 0 && u == 0) ? 0.0 : v;
+                    v = active ? v : NEG;
+                    double *dst = active ? out + (size_t)s * U1max + u : sink;
+                    *dst = v;
+                    result = (active && t == T - 1 && u == U) ? v + (double)sk : result;
+                    send[j] = v + (double)em;
+                    st[j] = v;
+                    skp[j] = sk;
                 }
             }
         }
+        // exactly one lane saw the terminal cell (T-1, U)
+        const int owner = U & (kWave - 1);
+        if (lane == owner) ll_out[b] = result;
     } else {
 #pragma unroll
         for (int i = 0; i < PF; ++i) load_row(nsteps - 1 - i, ring[i]);
         for (int base = 0; base < nsteps; base += PF) {
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
-                const int s = nsteps - 1 - (base + i);
+                const int s = nsteps - 1 - (base + i);   // steps s < 0 have no active lane
                 float2 cur[K];
 #pragma unroll
                 for (int j = 0; j < K; ++j) cur[j] = ring[i][j];
                 load_row(s - PF, ring[i]);
-                if (s >= 0) {
-                    double rot[K];
+                double rot[K];
 #pragma unroll
-                    for (int j = 0; j < K; ++j) rot[j] = lane_rotate_down_d(send[j]);
+                for (int j = 0; j < K; ++j) rot[j] = lane_rotate_down_d(send[j]);
 #pragma unroll
-                    for (int j = 0; j < K; ++j) {
-                        const int u = lane + kWave * j;
-                        const int t = s - u;
-                        const bool active = (t >= 0) & (t < T) & (u <= U);
-                        // beta(t, u+1): from lane+1, or for lane 63 from lane 0's next column block
-                        const double recv = (lane == kWave - 1) ? (j == K - 1 ? NEG : rot[j < K - 1 ? j + 1 : K - 1]) : rot[j];
-                        const double down = (t < T - 1) ? st[j] + (double)cur[j].x : NEG;
-                        const double right = (u < U) ? recv + (double)cur[j].y : NEG;
-                        double v = log_add_exp_d(down, right);
-                        v = (t == T - 1 && u == U) ? (double)cur[j].x : v;
-                        v = active ? v : NEG;
-                        if (active) {
-                            out[(size_t)s * U1max + u] = v;
-                            if (t == 0 && u == 0) { cost_ws[b] = -v; costs_out[b] = (float)(-v); }
-                        }
-                        send[j] = v;
-                        st[j] = v;
-                    }
+                for (int j = 0; j < K; ++j) {
+                    const int u = lane + kWave * j;
+                    const int t = s - u;
+                    const bool active = (t >= 0) & (t < T) & (u <= U);
+                    const float sk = active ? cur[j].x : 0.f;
+                    const float em = active ? cur[j].y : 0.f;
+                    // beta(t, u+1): from lane+1, or for lane 63 from lane 0's next column block
+                    const double recv = (lane == kWave - 1) ? (j == K - 1 ? NEG : rot[j < K - 1 ? j + 1 : K - 1]) : rot[j];
+                    const double down = (t < T - 1) ? st[j] + (double)sk : NEG;
+                    const double right = (u < U) ? recv + (double)em : NEG;
+                    double v = log_add_exp_d(down, right);
+                    v = (t == T - 1 && u == U) ? (double)sk : v;
+                    v = active ? v : NEG;
+                    double *dst = active ? out + (size_t)s * U1max + u : sink;
+                    *dst = v;
+                    result = (active && t == 0 && u == 0) ? v : result;
+                    send[j] = v;
+                    st[j] = v;
                 }
             }
         }
+        if (lane == 0) { cost_ws[b] = -result; costs_out[b] = (float)(-result); }
     }
 }
 
@@ -482,7 +493,8 @@ void launch_sweep(const RnntWs &w, char *ws, const int32_t *llens, const int32_t
     hipLaunchKernelGGL((rnnt_sweep_kernel<K, PF>), dim3(B, 2), dim3(64), 0, st,
                        reinterpret_cast<const float2 *>(ws + w.lp_off), llens, tlens, Tmax, U1max, w.S,
                        reinterpret_cast<double *>(ws + w.alpha_off), reinterpret_cast<double *>(ws + w.beta_off),
-                       reinterpret_cast<double *>(ws + w.ll_off), reinterpret_cast<double *>(ws + w.cost_off), costs);
+                       reinterpret_cast<double *>(ws + w.ll_off), reinterpret_cast<double *>(ws + w.cost_off), costs,
+                       reinterpret_cast<double *>(ws + w.dump_off));
 }
 
 }  // namespace
