@@ -190,3 +190,26 @@ def test_medium_shape_properties():
     c32, g32 = oracle.rnnt_loss_f32(x.detach().cpu().numpy(), y.cpu().numpy(), ll.cpu().numpy(), tl.cpu().numpy())
     np.testing.assert_allclose(costs.detach().cpu().numpy(), c32, rtol=2e-5)
     np.testing.assert_allclose(g.cpu().numpy(), g32, rtol=1e-3, atol=2e-5)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize("V", [64, 37])
+def test_half_precision_logits(dtype, tol, V):
+    """AMP path (executor.py:91 autocast): fp16/bf16 logits in, fp32 arithmetic inside, gradient returned in the
+    input dtype.  Checked against the oracle evaluated on the same rounded logits; the tolerance is the output
+    dtype's rounding."""
+    import wenet_celoss_amd as w
+    rng = np.random.default_rng(21)
+    logits, targets, llens, tlens = make_case(rng, 3, 19, 7, V)
+    xh = torch.tensor(logits, device=DEV).to(dtype)
+    x = xh.clone().requires_grad_(True)
+    loss = w.rnnt_loss(x, torch.tensor(targets, device=DEV), torch.tensor(llens, device=DEV),
+                       torch.tensor(tlens, device=DEV), blank=0, reduction="none")
+    assert loss.dtype == dtype and x.dtype == dtype
+    loss.float().sum().backward()
+    assert x.grad.dtype == dtype
+    oc, og = oracle.rnnt_loss_f64(xh.float().cpu().numpy(), targets, llens, tlens)
+    np.testing.assert_allclose(loss.float().cpu().numpy(), oc, rtol=tol)
+    np.testing.assert_allclose(x.grad.float().cpu().numpy(), og, rtol=tol, atol=tol * 1e-1)
+    for b in range(3):
+        assert not x.grad[b, llens[b]:].any() and not x.grad[b, :, tlens[b] + 1:].any()

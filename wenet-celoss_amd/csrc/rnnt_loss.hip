@@ -55,19 +55,45 @@ inline RnntWs rnnt_ws_layout(int B, int Tmax, int U1max)
 }
 
 // ------------------------------------------------------------------ pass 1 --
-// Per-lane online (max, sum) in the log2 domain over one row of V floats.
+// Element types: float (the parity bar), _Float16 and __bf16 (AMP logits; arithmetic stays fp32).
+// A row is streamed in 16-byte vectors of VecOf<T>::N elements.
+template <typename T> struct VecOf;
+template <> struct VecOf<float>    { static constexpr int N = 4; typedef float    type __attribute__((ext_vector_type(4))); };
+template <> struct VecOf<_Float16> { static constexpr int N = 8; typedef _Float16 type __attribute__((ext_vector_type(8))); };
+template <> struct VecOf<__bf16>   { static constexpr int N = 8; typedef __bf16   type __attribute__((ext_vector_type(8))); };
+
+template <bool NT, typename V>
+__device__ __forceinline__ V ldv(const V *p)
+{
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT, typename V>
+__device__ __forceinline__ void stv(V v, V *p)
+{
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+// Per-lane online (max, sum) in the log2 domain over one row of V logits.
 struct RowStat {
     float m;   // running max of x*log2e
     float s;   // running sum of 2^(x*log2e - m)
 };
 
-__device__ __forceinline__ void stat_add4(RowStat &st, const f32x4 v)
+template <typename T>
+__device__ __forceinline__ void stat_addv(RowStat &st, const typename VecOf<T>::type v)
 {
-    const float y0 = v.x * kLog2e, y1 = v.y * kLog2e, y2 = v.z * kLog2e, y3 = v.w * kLog2e;
-    const float cm = fmaxf(fmaxf(y0, y1), fmaxf(y2, y3));
+    constexpr int N = VecOf<T>::N;
+    float y[N];
+    float cm = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { y[i] = (float)v[i] * kLog2e; cm = fmaxf(cm, y[i]); }
     const float nm = fmaxf(st.m, cm);
-    st.s = st.s * fast_exp2(st.m - nm) + (fast_exp2(y0 - nm) + fast_exp2(y1 - nm)) +
-           (fast_exp2(y2 - nm) + fast_exp2(y3 - nm));
+    float acc = st.s * fast_exp2(st.m - nm);
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc += fast_exp2(y[i] - nm);
+    st.s = acc;
     st.m = nm;
 }
 
@@ -79,49 +105,49 @@ __device__ __forceinline__ void stat_add1(RowStat &st, const float x)
     st.m = nm;
 }
 
-template <bool NT>
-__device__ __forceinline__ f32x4 ld4(const f32x4 *p)
-{
-    if constexpr (NT) return __builtin_nontemporal_load(p);
-    else return *p;
-}
-template <bool NT>
-__device__ __forceinline__ void st4(f32x4 v, f32x4 *p)
-{
-    if constexpr (NT) __builtin_nontemporal_store(v, p);
-    else *p = v;
-}
+// Split row[0..V) into a scalar head, a 16-byte aligned vector body and a scalar tail (any V, any base).
+template <typename T>
+struct RowSplit {
+    int h, nv, tail;
+    __device__ __forceinline__ RowSplit(const T *row, int V)
+    {
+        constexpr int N = VecOf<T>::N;
+        const int mis = (int)((reinterpret_cast<uintptr_t>(row) / sizeof(T)) & (N - 1));
+        const int head = (N - mis) & (N - 1);
+        h = head < V ? head : V;
+        nv = (V - h) / N;
+        tail = V - h - nv * N;
+    }
+};
 
 // Natural-log log-sum-exp of row[0..V) computed by one wave.
-template <bool NT>
-__device__ __forceinline__ float wave_row_lse(const float *__restrict__ row, int V, int lane)
+template <typename T, bool NT>
+__device__ __forceinline__ float wave_row_lse(const T *__restrict__ row, int V, int lane)
 {
+    typedef typename VecOf<T>::type vec_t;
+    constexpr int N = VecOf<T>::N;
     RowStat st{-3.0e38f, 0.f};
-    // 16-byte aligned body with scalar head/tail so that any V and any base work.
-    const int head = (int)((4 - ((reinterpret_cast<uintptr_t>(row) >> 2) & 3)) & 3);
-    const int h = head < V ? head : V;
-    const int n4 = (V - h) >> 2;
-    const int tail = V - h - 4 * n4;
-    if (lane < h) stat_add1(st, row[lane]);
-    if (lane < tail) stat_add1(st, row[h + 4 * n4 + lane]);
-    const f32x4 *__restrict__ body = reinterpret_cast<const f32x4 *>(row + h);
+    const RowSplit<T> sp(row, V);
+    if (lane < sp.h) stat_add1(st, (float)row[lane]);
+    if (lane < sp.tail) stat_add1(st, (float)row[sp.h + N * sp.nv + lane]);
+    const vec_t *__restrict__ body = reinterpret_cast<const vec_t *>(row + sp.h);
     int i = lane;
-    for (; i + 3 * kWave < n4; i += 4 * kWave) {
-        const f32x4 a = ld4<NT>(body + i);
-        const f32x4 b = ld4<NT>(body + i + kWave);
-        const f32x4 c = ld4<NT>(body + i + 2 * kWave);
-        const f32x4 d = ld4<NT>(body + i + 3 * kWave);
-        stat_add4(st, a); stat_add4(st, b); stat_add4(st, c); stat_add4(st, d);
+    for (; i + 3 * kWave < sp.nv; i += 4 * kWave) {
+        const vec_t a = ldv<NT>(body + i);
+        const vec_t b = ldv<NT>(body + i + kWave);
+        const vec_t c = ldv<NT>(body + i + 2 * kWave);
+        const vec_t d = ldv<NT>(body + i + 3 * kWave);
+        stat_addv<T>(st, a); stat_addv<T>(st, b); stat_addv<T>(st, c); stat_addv<T>(st, d);
     }
-    for (; i < n4; i += kWave) stat_add4(st, ld4<NT>(body + i));
+    for (; i < sp.nv; i += kWave) stat_addv<T>(st, ldv<NT>(body + i));
     const float M = wave_max(st.m);
     const float s = wave_sum(st.s * fast_exp2(st.m - M));
     return (M + fast_log2(s)) * kLn2;
 }
 
-template <bool NT>
+template <typename T, bool NT>
 __global__ __launch_bounds__(256) void rnnt_lse_kernel(
-    const float *__restrict__ logits, const int32_t *__restrict__ targets,
+    const T *__restrict__ logits, const int32_t *__restrict__ targets,
     const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens,
     int B, int Tmax, int U1max, int V, int blank, int K, int S,
     float2 *__restrict__ lp_skew, float *__restrict__ denom)
@@ -137,16 +163,16 @@ __global__ __launch_bounds__(256) void rnnt_lse_kernel(
         const int c = (int)(r - (long)b * cells);
         const int t = c / U1max;
         const int u = c - t * U1max;
-        const int T = llens[b], U = tlens[b];
-        if (t >= T || u > U) continue;
-        const float *row = logits + (size_t)r * V;
-        const float d = wave_row_lse<NT>(row, V, lane);
+        const int T_ = llens[b], U = tlens[b];
+        if (t >= T_ || u > U) continue;
+        const T *row = logits + (size_t)r * V;
+        const float d = wave_row_lse<T, NT>(row, V, lane);
         if (lane == 0) {
-            const float xb = row[blank];
+            const float xb = (float)row[blank];
             float em = 0.f;
             if (u < U) {
                 const int lab = targets[(size_t)b * (U1max - 1) + u];
-                em = row[lab] - d;
+                em = (float)row[lab] - d;
             }
             denom[r] = d;
             const int s = t + u;
@@ -322,15 +348,17 @@ __global__ __launch_bounds__(64) void rnnt_sweep_kernel(
 }
 
 // ------------------------------------------------------------------ pass 3 --
-template <bool NT>
+template <typename T, bool NT>
 __global__ __launch_bounds__(256) void rnnt_grad_kernel(
-    const float *logits, const int32_t *__restrict__ targets,
+    const T *logits, const int32_t *__restrict__ targets,
     const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens,
     int B, int Tmax, int U1max, int V, int blank, float clamp, int K, int S,
     const double *__restrict__ alpha_skew, const double *__restrict__ beta_skew,
     const float *__restrict__ denom, const double *__restrict__ cost_ws,
-    const float *__restrict__ grad_costs, float *grads)
+    const float *__restrict__ grad_costs, T *grads)
 {
+    typedef typename VecOf<T>::type vec_t;
+    constexpr int N = VecOf<T>::N;
     const int lane = threadIdx.x & (kWave - 1);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int waves_per_block = blockDim.x >> 6;
@@ -342,22 +370,22 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(
         const int c = (int)(r - (long)b * cells);
         const int t = c / U1max;
         const int u = c - t * U1max;
-        const int T = llens[b], U = tlens[b];
-        const float *row = logits + (size_t)r * V;
-        float *grow = grads + (size_t)r * V;
+        const int T_ = llens[b], U = tlens[b];
+        const T *row = logits + (size_t)r * V;
+        T *grow = grads + (size_t)r * V;
 
-        const int head = (int)((4 - ((reinterpret_cast<uintptr_t>(row) >> 2) & 3)) & 3);
-        const int h = head < V ? head : V;
-        const int n4 = (V - h) >> 2;
-        const int tail = V - h - 4 * n4;
-        const f32x4 *body = reinterpret_cast<const f32x4 *>(row + h);
-        f32x4 *gbody = reinterpret_cast<f32x4 *>(grow + h);
+        const RowSplit<T> sp(row, V);
+        const int h = sp.h, nv = sp.nv, tail = sp.tail;
+        const vec_t *body = reinterpret_cast<const vec_t *>(row + h);
+        vec_t *gbody = reinterpret_cast<vec_t *>(grow + h);
 
-        if (t >= T || u > U) {          // padded cell: gradient is exactly zero
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            if (lane < h) grow[lane] = 0.f;
-            if (lane < tail) grow[h + 4 * n4 + lane] = 0.f;
-            for (int i = lane; i < n4; i += kWave) st4<NT>(z, gbody + i);
+        if (t >= T_ || u > U) {          // padded cell: gradient is exactly zero
+            vec_t z;
+#pragma unroll
+            for (int q = 0; q < N; ++q) z[q] = (T)0.f;
+            if (lane < h) grow[lane] = (T)0.f;
+            if (lane < tail) grow[h + N * nv + lane] = (T)0.f;
+            for (int i = lane; i < nv; i += kWave) stv<NT>(z, gbody + i);
             continue;
         }
 
@@ -375,8 +403,8 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(
         // special entries (SURVEY.md App. A.1 case chain; first match wins)
         bool blank_special = false;
         float blank_sub = 0.f;                      // exponent (natural log) of the subtracted term, minus logit
-        if (t == T - 1 && u == U) { blank_special = true; blank_sub = (float)cmd; }
-        else if (t < T - 1) {
+        if (t == T_ - 1 && u == U) { blank_special = true; blank_sub = (float)cmd; }
+        else if (t < T_ - 1) {
             blank_special = true;
             blank_sub = (float)(cmd + beta_skew[dbase + (size_t)(s + 1) * U1max + u]);
         }
@@ -401,42 +429,40 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(
         };
 
         if (lane < h) {
-            const float x = row[lane];
-            grow[lane] = finish(fix(fast_exp2(fmaf(x, kLog2e, c2)), x, lane));
+            const float x = (float)row[lane];
+            grow[lane] = (T)finish(fix(fast_exp2(fmaf(x, kLog2e, c2)), x, lane));
         }
         if (lane < tail) {
-            const int v = h + 4 * n4 + lane;
-            const float x = row[v];
-            grow[v] = finish(fix(fast_exp2(fmaf(x, kLog2e, c2)), x, v));
+            const int v = h + N * nv + lane;
+            const float x = (float)row[v];
+            grow[v] = (T)finish(fix(fast_exp2(fmaf(x, kLog2e, c2)), x, v));
         }
-        // body index i covers elements v = h + 4*i .. h + 4*i + 3
-        const int iblk = (blk >= h) ? ((blk - h) >> 2) : -1;
-        const int ilab = (lab >= h) ? ((lab - h) >> 2) : -1;
-        auto do4 = [&](int i, const f32x4 x) {
-            f32x4 g;
-            g.x = fast_exp2(fmaf(x.x, kLog2e, c2));
-            g.y = fast_exp2(fmaf(x.y, kLog2e, c2));
-            g.z = fast_exp2(fmaf(x.z, kLog2e, c2));
-            g.w = fast_exp2(fmaf(x.w, kLog2e, c2));
+        // body vector i covers elements v = h + N*i .. h + N*i + N-1
+        const int iblk = (blk >= h) ? ((blk - h) / N) : -1;
+        const int ilab = (lab >= h) ? ((lab - h) / N) : -1;
+        auto dov = [&](int i, const vec_t x) {
+            float g[N];
+#pragma unroll
+            for (int q = 0; q < N; ++q) g[q] = fast_exp2(fmaf((float)x[q], kLog2e, c2));
             if (i == iblk || i == ilab) {
-                const int v0 = h + 4 * i;
-                g.x = fix(g.x, x.x, v0);
-                g.y = fix(g.y, x.y, v0 + 1);
-                g.z = fix(g.z, x.z, v0 + 2);
-                g.w = fix(g.w, x.w, v0 + 3);
+                const int v0 = h + N * i;
+#pragma unroll
+                for (int q = 0; q < N; ++q) g[q] = fix(g[q], (float)x[q], v0 + q);
             }
-            g.x = finish(g.x); g.y = finish(g.y); g.z = finish(g.z); g.w = finish(g.w);
-            st4<NT>(g, gbody + i);
+            vec_t o;
+#pragma unroll
+            for (int q = 0; q < N; ++q) o[q] = (T)finish(g[q]);
+            stv<NT>(o, gbody + i);
         };
         int i = lane;
-        for (; i + 3 * kWave < n4; i += 4 * kWave) {
-            const f32x4 a = ld4<NT>(body + i);
-            const f32x4 bq = ld4<NT>(body + i + kWave);
-            const f32x4 cq = ld4<NT>(body + i + 2 * kWave);
-            const f32x4 dq = ld4<NT>(body + i + 3 * kWave);
-            do4(i, a); do4(i + kWave, bq); do4(i + 2 * kWave, cq); do4(i + 3 * kWave, dq);
+        for (; i + 3 * kWave < nv; i += 4 * kWave) {
+            const vec_t a = ldv<NT>(body + i);
+            const vec_t bq = ldv<NT>(body + i + kWave);
+            const vec_t cq = ldv<NT>(body + i + 2 * kWave);
+            const vec_t dq = ldv<NT>(body + i + 3 * kWave);
+            dov(i, a); dov(i + kWave, bq); dov(i + 2 * kWave, cq); dov(i + 3 * kWave, dq);
         }
-        for (; i < n4; i += kWave) do4(i, ld4<NT>(body + i));
+        for (; i < nv; i += kWave) dov(i, ldv<NT>(body + i));
     }
 }
 
@@ -517,7 +543,7 @@ extern "C" int wr_rnnt_loss_fwd(const void *logits_d, int dtype, const int32_t *
     WR_REQUIRE(logits_d && logit_lengths_d && target_lengths_d && costs_d && workspace_d, WR_EINVAL,
                "rnnt_loss_fwd: null pointer argument");
     WR_REQUIRE(targets_d || U1max == 1, WR_EINVAL, "rnnt_loss_fwd: targets is null");
-    WR_REQUIRE(dtype == WR_F32, WR_EUNSUPPORTED, "rnnt_loss_fwd: dtype %d not supported yet (fp32 only)", dtype);
+    WR_REQUIRE(dtype == WR_F32 || dtype == WR_F16 || dtype == WR_BF16, WR_EINVAL, "rnnt_loss_fwd: unknown dtype %d", dtype);
     const RnntWs w = rnnt_ws_layout(B, Tmax, U1max);
     WR_REQUIRE(workspace_bytes >= w.total, WR_EWORKSPACE, "rnnt_loss_fwd: workspace %zu < required %zu",
                workspace_bytes, w.total);
@@ -525,14 +551,15 @@ extern "C" int wr_rnnt_loss_fwd(const void *logits_d, int dtype, const int32_t *
     char *ws = static_cast<char *>(workspace_d);
     const long nrows = (long)B * Tmax * U1max;
     const dim3 grid1(stream_grid(nrows, tune_get(kTuneLseBlocksPerCu)));
-    if (tune_get(kTuneNonTemporal))
-        hipLaunchKernelGGL(rnnt_lse_kernel<true>, grid1, dim3(256), 0, st, static_cast<const float *>(logits_d), targets_d,
-                           logit_lengths_d, target_lengths_d, B, Tmax, U1max, V, blank, w.K, w.S,
-                           reinterpret_cast<float2 *>(ws + w.lp_off), reinterpret_cast<float *>(ws + w.denom_off));
-    else
-        hipLaunchKernelGGL(rnnt_lse_kernel<false>, grid1, dim3(256), 0, st, static_cast<const float *>(logits_d), targets_d,
-                           logit_lengths_d, target_lengths_d, B, Tmax, U1max, V, blank, w.K, w.S,
-                           reinterpret_cast<float2 *>(ws + w.lp_off), reinterpret_cast<float *>(ws + w.denom_off));
+#define WR_LAUNCH_LSE(T, NT)                                                                                        \
+    hipLaunchKernelGGL((rnnt_lse_kernel<T, NT>), grid1, dim3(256), 0, st, static_cast<const T *>(logits_d), targets_d, \
+                       logit_lengths_d, target_lengths_d, B, Tmax, U1max, V, blank, w.K, w.S,                        \
+                       reinterpret_cast<float2 *>(ws + w.lp_off), reinterpret_cast<float *>(ws + w.denom_off))
+    const bool nt = tune_get(kTuneNonTemporal) != 0;
+    if (dtype == WR_F32) { if (nt) WR_LAUNCH_LSE(float, true); else WR_LAUNCH_LSE(float, false); }
+    else if (dtype == WR_F16) { if (nt) WR_LAUNCH_LSE(_Float16, true); else WR_LAUNCH_LSE(_Float16, false); }
+    else { if (nt) WR_LAUNCH_LSE(__bf16, true); else WR_LAUNCH_LSE(__bf16, false); }
+#undef WR_LAUNCH_LSE
     WR_CHECK_LAUNCH("rnnt_lse_kernel");
     switch (w.K) {
         case 1: launch_sweep<1>(w, ws, logit_lengths_d, target_lengths_d, B, Tmax, U1max, costs_d, st); break;
@@ -557,7 +584,7 @@ extern "C" int wr_rnnt_loss_bwd(const void *logits_d, int dtype, const int32_t *
     WR_REQUIRE(logits_d && logit_lengths_d && target_lengths_d && grads_d && workspace_d, WR_EINVAL,
                "rnnt_loss_bwd: null pointer argument");
     WR_REQUIRE(targets_d || U1max == 1, WR_EINVAL, "rnnt_loss_bwd: targets is null");
-    WR_REQUIRE(dtype == WR_F32, WR_EUNSUPPORTED, "rnnt_loss_bwd: dtype %d not supported yet (fp32 only)", dtype);
+    WR_REQUIRE(dtype == WR_F32 || dtype == WR_F16 || dtype == WR_BF16, WR_EINVAL, "rnnt_loss_bwd: unknown dtype %d", dtype);
     const RnntWs w = rnnt_ws_layout(B, Tmax, U1max);
     WR_REQUIRE(workspace_bytes >= w.total, WR_EWORKSPACE, "rnnt_loss_bwd: workspace %zu < required %zu",
                workspace_bytes, w.total);
@@ -565,15 +592,17 @@ extern "C" int wr_rnnt_loss_bwd(const void *logits_d, int dtype, const int32_t *
     const char *ws = static_cast<const char *>(workspace_d);
     const long nrows = (long)B * Tmax * U1max;
     const dim3 grid3(stream_grid(nrows, tune_get(kTuneGradBlocksPerCu)));
-#define WR_LAUNCH_GRAD(NT)                                                                                          \
-    hipLaunchKernelGGL(rnnt_grad_kernel<NT>, grid3, dim3(256), 0, st, static_cast<const float *>(logits_d), targets_d, \
+#define WR_LAUNCH_GRAD(T, NT)                                                                                       \
+    hipLaunchKernelGGL((rnnt_grad_kernel<T, NT>), grid3, dim3(256), 0, st, static_cast<const T *>(logits_d), targets_d, \
                        logit_lengths_d, target_lengths_d, B, Tmax, U1max, V, blank, clamp, w.K, w.S,                 \
                        reinterpret_cast<const double *>(ws + w.alpha_off),                                           \
                        reinterpret_cast<const double *>(ws + w.beta_off),                                            \
                        reinterpret_cast<const float *>(ws + w.denom_off),                                            \
-                       reinterpret_cast<const double *>(ws + w.cost_off), grad_costs_d, static_cast<float *>(grads_d))
-    if (tune_get(kTuneNonTemporal)) WR_LAUNCH_GRAD(true);
-    else WR_LAUNCH_GRAD(false);
+                       reinterpret_cast<const double *>(ws + w.cost_off), grad_costs_d, static_cast<T *>(grads_d))
+    const bool nt = tune_get(kTuneNonTemporal) != 0;
+    if (dtype == WR_F32) { if (nt) WR_LAUNCH_GRAD(float, true); else WR_LAUNCH_GRAD(float, false); }
+    else if (dtype == WR_F16) { if (nt) WR_LAUNCH_GRAD(_Float16, true); else WR_LAUNCH_GRAD(_Float16, false); }
+    else { if (nt) WR_LAUNCH_GRAD(__bf16, true); else WR_LAUNCH_GRAD(__bf16, false); }
 #undef WR_LAUNCH_GRAD
     WR_CHECK_LAUNCH("rnnt_grad_kernel");
     return WR_OK;
