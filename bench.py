@@ -144,6 +144,19 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # same-process calibration outside the timed region: the runtime's own device-to-device copy of the
+    # logits-sized buffer (one read + one write per byte, like the gradient pass).  MI355X parts differ
+    # by several per cent in sustained HBM rate; this says what this device gives a plain copy.
+    copy_gbs = None
+    if not inplace:
+        cms = []
+        for _ in range(3):
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record(); grads.copy_(logits); c1.record(); torch.cuda.synchronize()
+            cms.append(c0.elapsed_time(c1))
+        copy_gbs = 2 * 4.0 * B * T * U1 * V / (sorted(cms)[1] * 1e-3) / 1e9
+        bwd()                                            # restore the gradient buffer's contents
+
     fwd_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
     bwd_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
     ms_per_step = elapsed * 1e3 / args.steps
@@ -178,7 +191,8 @@ def main():
                      "bytes_per_launch": bytes_bwd, "avg_ms": round(bwd_ms, 4),
                      "other": {"rnnt_lse+sweep": {"achieved": round(lse_gbs, 1), "avg_ms": round(fwd_ms, 4),
                                                   "bytes_per_launch": bytes_fwd}},
-                     "whole_step_GBps": round((bytes_fwd + bytes_bwd) / (ms_per_step * 1e-3) / 1e9, 1)},
+                     "whole_step_GBps": round((bytes_fwd + bytes_bwd) / (ms_per_step * 1e-3) / 1e9, 1),
+                     "device_copy_GBps": None if copy_gbs is None else round(copy_gbs, 1)},
     }
 
     if rank == 0 and world == 1 and args.cpu_sample != 0:

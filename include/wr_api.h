@@ -50,7 +50,8 @@ const char *wr_last_error(void);
 
 /* Benchmarking hook: process-wide launch-shape knobs of the streaming kernels.  Results never depend
  * on them; the defaults are the measured best.  key 0: workgroups per CU of the RNN-T row-lse pass,
- * key 1: of the RNN-T gradient pass, key 2: non-temporal loads/stores (0/1). */
+ * key 1: of the RNN-T gradient pass, key 2: non-temporal bits (1: gradient-pass loads, 2: gradient-pass
+ * stores, 4: row-lse loads), key 3 / key 4: 16-byte vectors in flight per lane in the gradient / row-lse pass (4 or 8). */
 int wr_tune_set(int key, int value);
 
 /* ------------------------------------------------------------------------

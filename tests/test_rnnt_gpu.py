@@ -209,7 +209,7 @@ def test_half_precision_logits(dtype, tol, V):
     loss.float().sum().backward()
     assert x.grad.dtype == dtype
     oc, og = oracle.rnnt_loss_f64(xh.float().cpu().numpy(), targets, llens, tlens)
-    np.testing.assert_allclose(loss.float().cpu().numpy(), oc, rtol=tol)
+    np.testing.assert_allclose(loss.detach().float().cpu().numpy(), oc, rtol=tol)
     np.testing.assert_allclose(x.grad.float().cpu().numpy(), og, rtol=tol, atol=tol * 1e-1)
     for b in range(3):
         assert not x.grad[b, llens[b]:].any() and not x.grad[b, :, tlens[b] + 1:].any()

@@ -27,11 +27,11 @@ st = _lib.current_stream(dev); P = _lib.ptr
 fwd = lambda: _lib.check(lib.wr_rnnt_loss_fwd(P(logits), 0, P(targets), P(ll), P(tl), B, T, U1, V, 0, P(costs), P(ws), wsb, st))
 bwd = lambda: _lib.check(lib.wr_rnnt_loss_bwd(P(logits), 0, P(targets), P(ll), P(tl), B, T, U1, V, 0, -1.0, P(gc), P(grads), P(ws), wsb, st))
 
-variants = [dict(lse=l, grad=g, nt=n) for n in (1, 0) for l, g in ((8, 7), (4, 4), (16, 16))]
+variants = [dict(lse=l, grad=g, nt=6, un=u, lun=lu) for u in (4, 8) for lu in (4, 8) for l, g in ((8, 8), (6, 6), (12, 12))]
 res = {i: ([], []) for i in range(len(variants))}
 for rnd in range(int(os.environ.get("ROUNDS", 5))):
     for i, v in enumerate(variants):
-        lib.wr_tune_set(0, v["lse"]); lib.wr_tune_set(1, v["grad"]); lib.wr_tune_set(2, v["nt"])
+        lib.wr_tune_set(0, v["lse"]); lib.wr_tune_set(1, v["grad"]); lib.wr_tune_set(2, v["nt"]); lib.wr_tune_set(3, v["un"]); lib.wr_tune_set(4, v["lun"])
         fwd(); bwd(); torch.cuda.synchronize()
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         e[0].record(); fwd(); e[1].record(); bwd(); e[2].record(); torch.cuda.synchronize()

@@ -49,7 +49,7 @@ inline RnntWs rnnt_ws_layout(int B, int Tmax, int U1max)
     w.denom_off = off; off = align_up(off + (size_t)B * Tmax * U1max * sizeof(float), 256);
     w.ll_off = off;    off = align_up(off + (size_t)B * sizeof(double), 256);
     w.cost_off = off;  off = align_up(off + (size_t)B * sizeof(double), 256);
-    w.dump_off = off;  off = align_up(off + (size_t)B * 2 * kWave * sizeof(double), 256);
+    w.dump_off = off;  off = align_up(off + (size_t)B * 2 * 512 * sizeof(double), 256);
     w.total = off;
     return w;
 }
@@ -121,7 +121,7 @@ struct RowSplit {
 };
 
 // Natural-log log-sum-exp of row[0..V) computed by one wave.
-template <typename T, bool NT>
+template <typename T, bool NT, int UN>
 __device__ __forceinline__ float wave_row_lse(const T *__restrict__ row, int V, int lane)
 {
     typedef typename VecOf<T>::type vec_t;
@@ -132,20 +132,28 @@ __device__ __forceinline__ float wave_row_lse(const T *__restrict__ row, int V, 
     if (lane < sp.tail) stat_add1(st, (float)row[sp.h + N * sp.nv + lane]);
     const vec_t *__restrict__ body = reinterpret_cast<const vec_t *>(row + sp.h);
     int i = lane;
-    for (; i + 3 * kWave < sp.nv; i += 4 * kWave) {
-        const vec_t a = ldv<NT>(body + i);
-        const vec_t b = ldv<NT>(body + i + kWave);
-        const vec_t c = ldv<NT>(body + i + 2 * kWave);
-        const vec_t d = ldv<NT>(body + i + 3 * kWave);
-        stat_addv<T>(st, a); stat_addv<T>(st, b); stat_addv<T>(st, c); stat_addv<T>(st, d);
+    for (; i + (UN - 1) * kWave < sp.nv; i += UN * kWave) {
+        vec_t x[UN];
+#pragma unroll
+        for (int q = 0; q < UN; ++q) x[q] = ldv<NT>(body + i + q * kWave);
+#pragma unroll
+        for (int q = 0; q < UN; ++q) stat_addv<T>(st, x[q]);
     }
-    for (; i < sp.nv; i += kWave) stat_addv<T>(st, ldv<NT>(body + i));
+    for (; i < sp.nv; i += (UN / 2) * kWave) {
+        vec_t x[UN / 2];
+#pragma unroll
+        for (int q = 0; q < UN / 2; ++q)
+            if (i + q * kWave < sp.nv) x[q] = ldv<NT>(body + i + q * kWave);
+#pragma unroll
+        for (int q = 0; q < UN / 2; ++q)
+            if (i + q * kWave < sp.nv) stat_addv<T>(st, x[q]);
+    }
     const float M = wave_max(st.m);
     const float s = wave_sum(st.s * fast_exp2(st.m - M));
     return (M + fast_log2(s)) * kLn2;
 }
 
-template <typename T, bool NT>
+template <typename T, bool NT, int UN>
 __global__ __launch_bounds__(256) void rnnt_lse_kernel(
     const T *__restrict__ logits, const int32_t *__restrict__ targets,
     const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens,
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(256) void rnnt_lse_kernel(
         const int T_ = llens[b], U = tlens[b];
         if (t >= T_ || u > U) continue;
         const T *row = logits + (size_t)r * V;
-        const float d = wave_row_lse<T, NT>(row, V, lane);
+        const float d = wave_row_lse<T, NT, UN>(row, V, lane);
         if (lane == 0) {
             const float xb = (float)row[blank];
             float em = 0.f;
@@ -212,143 +220,122 @@ __device__ __forceinline__ double lane_rotate_down_d(double v)
     return __hiloint2double(hi, lo);
 }
 
-// One wave per (utterance, direction).  Lane l owns the K label columns u_j = l + 64 j and at step s
-// works on the cells (t = s - u_j, u_j) of anti-diagonal s: the K cells of a lane are independent of
-// each other (K-way ILP), and what a cell needs from diagonal s -/+ 1 is its own previous value and the
-// previous value of the neighbouring lane (lane 63 wraps to lane 0's next column block) -- one DPP
-// wave rotate per owned column, no LDS, no barrier.
-template <int K, int PF>
-__global__ __launch_bounds__(64) void rnnt_sweep_kernel(
+// One workgroup per (utterance, direction), one lane per label column u (NW = ceil(U1max/64) waves).
+// At step s every lane works on the cell (t = s - u, u) of anti-diagonal s.  What a cell needs from
+// diagonal s -/+ 1 is the lane's own previous value and its neighbouring lane's previous value: inside a
+// wave that is one DPP wave rotate; across the wave boundary (lane 63 -> lane 0 of the next wave) it goes
+// through an 8-byte LDS slot, double buffered, with one s_barrier per step.  The loop body is
+// straight-line: loads are unconditional (clamped rows, values masked afterwards) and idle lanes store
+// to a sink, so PF rows of log-probs stay in flight under counted s_waitcnt.
+template <int PF>
+__global__ __launch_bounds__(512) void rnnt_sweep_kernel(
     const float2 *__restrict__ lp_skew, const int32_t *__restrict__ llens,
     const int32_t *__restrict__ tlens, int Tmax, int U1max, int S,
     double *__restrict__ alpha_skew, double *__restrict__ beta_skew,
     double *__restrict__ ll_out, double *__restrict__ cost_ws, float *__restrict__ costs_out,
-    double *__restrict__ dump /* [2*B*64] scratch that absorbs the stores of idle lanes */)
+    double *__restrict__ dump /* [2*B*512] scratch that absorbs the stores of idle lanes */)
 {
     constexpr double NEG = (double)kNegInf;
+    __shared__ double xch[2][8];
     const int b = blockIdx.x;
     const bool backward = blockIdx.y != 0;
-    const int lane = threadIdx.x;
+    const int u = threadIdx.x;
+    const int lane = u & (kWave - 1), wave = u >> 6;
+    const int nw = blockDim.x >> 6;
     int T = llens[b], U = tlens[b];
     T = T < 0 ? 0 : (T > Tmax ? Tmax : T);
     U = U < 0 ? 0 : (U > U1max - 1 ? U1max - 1 : U);
-    const float2 *__restrict__ lp = lp_skew + (size_t)b * S * U1max;
-    double *__restrict__ out = (backward ? beta_skew : alpha_skew) + (size_t)b * S * U1max;
-    double *__restrict__ sink = dump + ((size_t)b * 2 + (backward ? 1 : 0)) * kWave + lane;
     const int nsteps = (T > 0) ? T + U : 0;       // anti-diagonals that hold a valid cell
 
     if (nsteps == 0) {
-        if (lane == 0) {
+        if (u == 0) {
             if (backward) { cost_ws[b] = 0.0; costs_out[b] = 0.f; } else ll_out[b] = 0.0;
         }
         return;
     }
+    const bool in_row = u < U1max;
+    const int col = in_row ? u : U1max - 1;
+    const float2 *__restrict__ lp = lp_skew + (size_t)b * S * U1max + col;
+    double *__restrict__ out = (backward ? beta_skew : alpha_skew) + (size_t)b * S * U1max + col;
+    double *__restrict__ sink = dump + ((size_t)b * 2 + (backward ? 1 : 0)) * 512 + u;
 
-    // The loop body below is straight-line code: loads are unconditional (addresses clamped into the
-    // utterance's rows, values masked afterwards) and idle lanes store to `sink`, so the compiler can
-    // keep PF rows of log-probs in flight with counted s_waitcnt instead of draining every step.
-    int ucol[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        const int u = lane + kWave * j;
-        ucol[j] = u < U1max ? u : U1max - 1;
-    }
-    auto load_row = [&](int s, float2 (&dst)[K]) {
+    auto load_row = [&](int s) -> float2 {
         const int sc = s < 0 ? 0 : (s >= nsteps ? nsteps - 1 : s);
-#pragma unroll
-        for (int j = 0; j < K; ++j) dst[j] = lp[(size_t)sc * U1max + ucol[j]];
+        return lp[(size_t)sc * U1max];
     };
 
-    float2 ring[PF][K];
-    double st[K];     // alpha(t-1, u_j)  /  beta(t+1, u_j): this lane's value on the previous diagonal
-    float skp[K];     // forward only: skip(t-1, u_j)
-    double send[K];   // what the neighbouring lane needs from this lane's previous diagonal
+    float2 ring[PF];
+    double st = NEG;      // alpha(t-1, u) / beta(t+1, u): this lane's value on the previous diagonal
+    float skp = 0.f;      // forward only: skip(t-1, u)
+    double send = NEG;    // what the neighbouring lane needs from this lane's previous diagonal
     double result = 0.0;
-#pragma unroll
-    for (int j = 0; j < K; ++j) { st[j] = NEG; skp[j] = 0.f; send[j] = NEG; }
 
     if (!backward) {
 #pragma unroll
-        for (int i = 0; i < PF; ++i) load_row(i, ring[i]);
+        for (int i = 0; i < PF; ++i) ring[i] = load_row(i);
         for (int base = 0; base < nsteps; base += PF) {
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const int s = base + i;           // steps s >= nsteps have no active lane
-                float2 cur[K];
-#pragma unroll
-                for (int j = 0; j < K; ++j) cur[j] = ring[i][j];
-                load_row(s + PF, ring[i]);
-                double rot[K];
-#pragma unroll
-                for (int j = 0; j < K; ++j) rot[j] = lane_rotate_up_d(send[j]);
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const int u = lane + kWave * j;
-                    const int t = s - u;
-                    const bool active = (t >= 0) & (t < T) & (u <= U);
-                    const float sk = active ? cur[j].x : 0.f;
-                    const float em = active ? cur[j].y : 0.f;
-                    // alpha(t, u-1) + emit(t, u-1): from lane-1, or for lane 0 from lane 63's previous column block
-                    const double recv = (lane == 0) ? (j == 0 ? NEG : rot[j > 0 ? j - 1 : 0]) : rot[j];
-                    const double top = (t >= 1) ? st[j] + (double)skp[j] : NEG;
-                    const double left = (u >= 1) ? recv : NEG;
-                    double v = log_add_exp_d(top, left);
-                    v = (t == 0 && u == 0) ? 0.0 : v;
-                    v = active ? v : NEG;
-                    double *dst = active ? out + (size_t)s * U1max + u : sink;
-                    *dst = v;
-                    result = (active && t == T - 1 && u == U) ? v + (double)sk : result;
-                    send[j] = v + (double)em;
-                    st[j] = v;
-                    skp[j] = sk;
-                }
+                const float2 cur = ring[i];
+                ring[i] = load_row(s + PF);
+                // alpha(t, u-1) + emit(t, u-1) from the lane to the left
+                double recv = lane_rotate_up_d(send);
+                if (lane == 0) recv = (wave == 0) ? ((s == 0) ? 0.0 : NEG) : xch[(s + 1) & 1][wave - 1];
+                const int t = s - u;
+                const bool active = (t >= 0) & (t < T) & (u <= U);
+                const float sk = active ? cur.x : 0.f;
+                const float em = active ? cur.y : 0.f;
+                const double top = (t >= 1) ? st + (double)skp : NEG;
+                double v = log_add_exp_d(top, recv);     // the origin sees recv = 0, top = -inf  ->  0
+                v = active ? v : NEG;
+                double *dst = active ? out + (size_t)s * U1max : sink;
+                *dst = v;
+                result = (active && t == T - 1 && u == U) ? v + (double)sk : result;
+                send = v + (double)em;
+                if (lane == kWave - 1) xch[s & 1][wave] = send;
+                st = v;
+                skp = sk;
+                if (nw > 1) __syncthreads();
             }
         }
-        // exactly one lane saw the terminal cell (T-1, U)
-        const int owner = U & (kWave - 1);
-        if (lane == owner) ll_out[b] = result;
+        if (u == U) ll_out[b] = result;          // exactly one lane saw the terminal cell (T-1, U)
     } else {
 #pragma unroll
-        for (int i = 0; i < PF; ++i) load_row(nsteps - 1 - i, ring[i]);
+        for (int i = 0; i < PF; ++i) ring[i] = load_row(nsteps - 1 - i);
         for (int base = 0; base < nsteps; base += PF) {
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const int s = nsteps - 1 - (base + i);   // steps s < 0 have no active lane
-                float2 cur[K];
-#pragma unroll
-                for (int j = 0; j < K; ++j) cur[j] = ring[i][j];
-                load_row(s - PF, ring[i]);
-                double rot[K];
-#pragma unroll
-                for (int j = 0; j < K; ++j) rot[j] = lane_rotate_down_d(send[j]);
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const int u = lane + kWave * j;
-                    const int t = s - u;
-                    const bool active = (t >= 0) & (t < T) & (u <= U);
-                    const float sk = active ? cur[j].x : 0.f;
-                    const float em = active ? cur[j].y : 0.f;
-                    // beta(t, u+1): from lane+1, or for lane 63 from lane 0's next column block
-                    const double recv = (lane == kWave - 1) ? (j == K - 1 ? NEG : rot[j < K - 1 ? j + 1 : K - 1]) : rot[j];
-                    const double down = (t < T - 1) ? st[j] + (double)sk : NEG;
-                    const double right = (u < U) ? recv + (double)em : NEG;
-                    double v = log_add_exp_d(down, right);
-                    v = (t == T - 1 && u == U) ? (double)sk : v;
-                    v = active ? v : NEG;
-                    double *dst = active ? out + (size_t)s * U1max + u : sink;
-                    *dst = v;
-                    result = (active && t == 0 && u == 0) ? v : result;
-                    send[j] = v;
-                    st[j] = v;
-                }
+                const float2 cur = ring[i];
+                ring[i] = load_row(s - PF);
+                // beta(t, u+1) from the lane to the right
+                double recv = lane_rotate_down_d(send);
+                if (lane == kWave - 1) recv = (wave == nw - 1) ? NEG : xch[(s + 1) & 1][wave + 1];
+                const int t = s - u;
+                const bool active = (t >= 0) & (t < T) & (u <= U);
+                const float sk = active ? cur.x : 0.f;
+                const float em = active ? cur.y : 0.f;
+                const double down = (t < T - 1) ? st + (double)sk : NEG;
+                const double right = (u < U) ? recv + (double)em : NEG;
+                double v = log_add_exp_d(down, right);
+                v = (t == T - 1 && u == U) ? (double)sk : v;
+                v = active ? v : NEG;
+                double *dst = active ? out + (size_t)s * U1max : sink;
+                *dst = v;
+                result = (active && t == 0 && u == 0) ? v : result;
+                send = v;
+                if (lane == 0) xch[s & 1][wave] = send;
+                st = v;
+                if (nw > 1) __syncthreads();
             }
         }
-        if (lane == 0) { cost_ws[b] = -result; costs_out[b] = (float)(-result); }
+        if (u == 0) { cost_ws[b] = -result; costs_out[b] = (float)(-result); }
     }
 }
 
 // ------------------------------------------------------------------ pass 3 --
-template <typename T, bool NT>
+template <typename T, bool NT /* loads */, bool NTS /* stores */, int UN>
 __global__ __launch_bounds__(256) void rnnt_grad_kernel(
     const T *logits, const int32_t *__restrict__ targets,
     const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens,
@@ -385,7 +372,7 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(
             for (int q = 0; q < N; ++q) z[q] = (T)0.f;
             if (lane < h) grow[lane] = (T)0.f;
             if (lane < tail) grow[h + N * nv + lane] = (T)0.f;
-            for (int i = lane; i < nv; i += kWave) stv<NT>(z, gbody + i);
+            for (int i = lane; i < nv; i += kWave) stv<NTS>(z, gbody + i);
             continue;
         }
 
@@ -452,17 +439,25 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(
             vec_t o;
 #pragma unroll
             for (int q = 0; q < N; ++q) o[q] = (T)finish(g[q]);
-            stv<NT>(o, gbody + i);
+            stv<NTS>(o, gbody + i);
         };
         int i = lane;
-        for (; i + 3 * kWave < nv; i += 4 * kWave) {
-            const vec_t a = ldv<NT>(body + i);
-            const vec_t bq = ldv<NT>(body + i + kWave);
-            const vec_t cq = ldv<NT>(body + i + 2 * kWave);
-            const vec_t dq = ldv<NT>(body + i + 3 * kWave);
-            dov(i, a); dov(i + kWave, bq); dov(i + 2 * kWave, cq); dov(i + 3 * kWave, dq);
+        for (; i + (UN - 1) * kWave < nv; i += UN * kWave) {
+            vec_t x[UN];
+#pragma unroll
+            for (int q = 0; q < UN; ++q) x[q] = ldv<NT>(body + i + q * kWave);
+#pragma unroll
+            for (int q = 0; q < UN; ++q) dov(i + q * kWave, x[q]);
         }
-        for (; i < nv; i += kWave) dov(i, ldv<NT>(body + i));
+        for (; i < nv; i += (UN / 2) * kWave) {          // remainder: half-size batches, still issued together
+            vec_t x[UN / 2];
+#pragma unroll
+            for (int q = 0; q < UN / 2; ++q)
+                if (i + q * kWave < nv) x[q] = ldv<NT>(body + i + q * kWave);
+#pragma unroll
+            for (int q = 0; q < UN / 2; ++q)
+                if (i + q * kWave < nv) dov(i + q * kWave, x[q]);
+        }
     }
 }
 
@@ -511,12 +506,10 @@ int stream_grid(long nrows, int blocks_per_cu)
     return (int)blocks;
 }
 
-template <int K>
 void launch_sweep(const RnntWs &w, char *ws, const int32_t *llens, const int32_t *tlens, int B, int Tmax,
                   int U1max, float *costs, hipStream_t st)
 {
-    constexpr int PF = (K <= 2) ? 8 : (K <= 4 ? 6 : 4);   // log-prob rows kept in flight ahead of the sweep
-    hipLaunchKernelGGL((rnnt_sweep_kernel<K, PF>), dim3(B, 2), dim3(64), 0, st,
+    hipLaunchKernelGGL((rnnt_sweep_kernel<8>), dim3(B, 2), dim3(64 * w.K), 0, st,
                        reinterpret_cast<const float2 *>(ws + w.lp_off), llens, tlens, Tmax, U1max, w.S,
                        reinterpret_cast<double *>(ws + w.alpha_off), reinterpret_cast<double *>(ws + w.beta_off),
                        reinterpret_cast<double *>(ws + w.ll_off), reinterpret_cast<double *>(ws + w.cost_off), costs,
@@ -552,25 +545,19 @@ extern "C" int wr_rnnt_loss_fwd(const void *logits_d, int dtype, const int32_t *
     const long nrows = (long)B * Tmax * U1max;
     const dim3 grid1(stream_grid(nrows, tune_get(kTuneLseBlocksPerCu)));
 #define WR_LAUNCH_LSE(T, NT)                                                                                        \
-    hipLaunchKernelGGL((rnnt_lse_kernel<T, NT>), grid1, dim3(256), 0, st, static_cast<const T *>(logits_d), targets_d, \
+    if (tune_get(kTuneLseUnroll) >= 8) WR_LAUNCH_LSE_U(T, NT, 8); else WR_LAUNCH_LSE_U(T, NT, 4)
+#define WR_LAUNCH_LSE_U(T, NT, UN)                                                                                  \
+    hipLaunchKernelGGL((rnnt_lse_kernel<T, NT, UN>), grid1, dim3(256), 0, st, static_cast<const T *>(logits_d), targets_d, \
                        logit_lengths_d, target_lengths_d, B, Tmax, U1max, V, blank, w.K, w.S,                        \
                        reinterpret_cast<float2 *>(ws + w.lp_off), reinterpret_cast<float *>(ws + w.denom_off))
-    const bool nt = tune_get(kTuneNonTemporal) != 0;
-    if (dtype == WR_F32) { if (nt) WR_LAUNCH_LSE(float, true); else WR_LAUNCH_LSE(float, false); }
-    else if (dtype == WR_F16) { if (nt) WR_LAUNCH_LSE(_Float16, true); else WR_LAUNCH_LSE(_Float16, false); }
-    else { if (nt) WR_LAUNCH_LSE(__bf16, true); else WR_LAUNCH_LSE(__bf16, false); }
+    const bool nt = (tune_get(kTuneNonTemporal) & 4) != 0;
+    if (dtype == WR_F32) { if (nt) { WR_LAUNCH_LSE(float, true); } else { WR_LAUNCH_LSE(float, false); } }
+    else if (dtype == WR_F16) { if (nt) { WR_LAUNCH_LSE(_Float16, true); } else { WR_LAUNCH_LSE(_Float16, false); } }
+    else { if (nt) { WR_LAUNCH_LSE(__bf16, true); } else { WR_LAUNCH_LSE(__bf16, false); } }
 #undef WR_LAUNCH_LSE
+#undef WR_LAUNCH_LSE_U
     WR_CHECK_LAUNCH("rnnt_lse_kernel");
-    switch (w.K) {
-        case 1: launch_sweep<1>(w, ws, logit_lengths_d, target_lengths_d, B, Tmax, U1max, costs_d, st); break;
-        case 2: launch_sweep<2>(w, ws, logit_lengths_d, target_lengths_d, B, Tmax, U1max, costs_d, st); break;
-        case 3: launch_sweep<3>(w, ws, logit_lengths_d, target_lengths_d, B, Tmax, U1max, costs_d, st); break;
-        case 4: launch_sweep<4>(w, ws, logit_lengths_d, target_lengths_d, B, Tmax, U1max, costs_d, st); break;
-        case 5: launch_sweep<5>(w, ws, logit_lengths_d, target_lengths_d, B, Tmax, U1max, costs_d, st); break;
-        case 6: launch_sweep<6>(w, ws, logit_lengths_d, target_lengths_d, B, Tmax, U1max, costs_d, st); break;
-        case 7: launch_sweep<7>(w, ws, logit_lengths_d, target_lengths_d, B, Tmax, U1max, costs_d, st); break;
-        default: launch_sweep<8>(w, ws, logit_lengths_d, target_lengths_d, B, Tmax, U1max, costs_d, st); break;
-    }
+    launch_sweep(w, ws, logit_lengths_d, target_lengths_d, B, Tmax, U1max, costs_d, st);
     WR_CHECK_LAUNCH("rnnt_sweep_kernel");
     return WR_OK;
 }
@@ -592,18 +579,28 @@ extern "C" int wr_rnnt_loss_bwd(const void *logits_d, int dtype, const int32_t *
     const char *ws = static_cast<const char *>(workspace_d);
     const long nrows = (long)B * Tmax * U1max;
     const dim3 grid3(stream_grid(nrows, tune_get(kTuneGradBlocksPerCu)));
-#define WR_LAUNCH_GRAD(T, NT)                                                                                       \
-    hipLaunchKernelGGL((rnnt_grad_kernel<T, NT>), grid3, dim3(256), 0, st, static_cast<const T *>(logits_d), targets_d, \
+#define WR_LAUNCH_GRAD_U(T, NT, UN)                                                                                 \
+    if (nts) WR_LAUNCH_GRAD_US(T, NT, true, UN); else WR_LAUNCH_GRAD_US(T, NT, false, UN)
+#define WR_LAUNCH_GRAD_US(T, NT, NTS, UN)                                                                           \
+    hipLaunchKernelGGL((rnnt_grad_kernel<T, NT, NTS, UN>), grid3, dim3(256), 0, st, static_cast<const T *>(logits_d), targets_d, \
                        logit_lengths_d, target_lengths_d, B, Tmax, U1max, V, blank, clamp, w.K, w.S,                 \
                        reinterpret_cast<const double *>(ws + w.alpha_off),                                           \
                        reinterpret_cast<const double *>(ws + w.beta_off),                                            \
                        reinterpret_cast<const float *>(ws + w.denom_off),                                            \
                        reinterpret_cast<const double *>(ws + w.cost_off), grad_costs_d, static_cast<T *>(grads_d))
-    const bool nt = tune_get(kTuneNonTemporal) != 0;
+#define WR_LAUNCH_GRAD(T, NT)                                             \
+    do {                                                                   \
+        if (tune_get(kTuneGradUnroll) >= 8) { WR_LAUNCH_GRAD_U(T, NT, 8); } \
+        else { WR_LAUNCH_GRAD_U(T, NT, 4); }                               \
+    } while (0)
+    const bool nt = (tune_get(kTuneNonTemporal) & 1) != 0;
+    const bool nts = (tune_get(kTuneNonTemporal) & 2) != 0;
     if (dtype == WR_F32) { if (nt) WR_LAUNCH_GRAD(float, true); else WR_LAUNCH_GRAD(float, false); }
     else if (dtype == WR_F16) { if (nt) WR_LAUNCH_GRAD(_Float16, true); else WR_LAUNCH_GRAD(_Float16, false); }
     else { if (nt) WR_LAUNCH_GRAD(__bf16, true); else WR_LAUNCH_GRAD(__bf16, false); }
 #undef WR_LAUNCH_GRAD
+#undef WR_LAUNCH_GRAD_U
+#undef WR_LAUNCH_GRAD_US
     WR_CHECK_LAUNCH("rnnt_grad_kernel");
     return WR_OK;
 }
