@@ -168,6 +168,16 @@ def main():
     grad_gbs = bytes_bwd / (bwd_ms * 1e-3) / 1e9
     lse_gbs = bytes_fwd / (fwd_ms * 1e-3) / 1e9
 
+    # HBM traffic of the dominant kernel from the committed PMC profile of this same command/shape (bench.py
+    # cannot collect counters itself); only reported for the default configuration it was measured on.
+    traffic = None
+    try:
+        if (B, T, U, V) == (32, 1000, 150, 5000) and not args.ragged and not inplace:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                traffic = float(json.load(f)["kernels"]["rnnt_grad_kernel"]["hbm_bytes"])
+    except (OSError, KeyError, ValueError):
+        traffic = None
+
     out = {
         "metric": "utterances/sec RNN-T loss+grad (B=32,T=1000,U=150,V=5000)",
         "value": round(value, 3),
@@ -187,7 +197,7 @@ def main():
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world} (utterance shards, no collective)"},
         "roofline": {"bound": "hbm", "kernel": "rnnt_grad_kernel", "achieved": round(grad_gbs, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(grad_gbs / HBM_PEAK_GBS, 4),
-                     "traffic": None,
+                     "traffic": traffic,
                      "bytes_per_launch": bytes_bwd, "avg_ms": round(bwd_ms, 4),
                      "other": {"rnnt_lse+sweep": {"achieved": round(lse_gbs, 1), "avg_ms": round(fwd_ms, 4),
                                                   "bytes_per_launch": bytes_fwd}},

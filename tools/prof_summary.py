@@ -74,6 +74,17 @@ def main():
         if js:
             lines += ["", "bench.py line of the profiled (kernel-trace) run:", "", "```json", js[-1].strip(), "```"]
     open(os.path.join(out_dir, f"{a.tag}_summary.md"), "w").write("\n".join(lines) + "\n")
+    # machine-readable PMC traffic per launch (bytes), picked up by bench.py's roofline.traffic
+    import json
+    traffic = {}
+    for r in rows:
+        k = short(r["Name"])
+        if k in fetch and k in write:
+            traffic[k.split("<")[0]] = {"hbm_read_bytes": fetch[k] * 1024 * 2, "hbm_write_bytes": write[k] * 1024,
+                                        "hbm_bytes": fetch[k] * 1024 * 2 + write[k] * 1024,
+                                        "source": f"profiles/{a.tag}_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                                  "passes; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md)"}
+    json.dump({"tag": a.tag, "kernels": traffic}, open(os.path.join(out_dir, "traffic.json"), "w"), indent=1)
     print("\n".join(lines))
 
 
