@@ -10,23 +10,29 @@
 //
 // The reference runs ONE utterance at a time from Python with a host<->device
 // sync on every step (.item()).  Here `lanes` (independent streams for greedy;
-// utterances x beam hypotheses for beam search) advance together, one
-// micro-step = five small kernels with all control state in device memory:
+// utterances x beam hypotheses for beam search) advance together with all control
+// state in device memory.  Every activation that feeds a contraction is kept
+// K-MAJOR ([feature][lane], lanes padded to 32) so that the exact-fp32 MFMA
+// (v_mfma_f32_32x32x2_f32) fragments of both operands are plain coalesced 128-byte
+// reads from L2 -- no LDS staging, no transposes between stages:
 //
-//   lstm_step_kernel (x L)  predicated per lane: embed/LSTM cell -> new cache
-//   proj_step_kernel        projection + pred_ffn; writes the joiner activation
-//                           tanh(enc_ffn(enc)[t] + pred_ffn(pred)) k-major
-//   joint_step_kernel       logits[lane, :] = ffn_out(activation): exact-fp32 MFMA
-//                           (32x32x2), lanes x 32 vocabulary columns per workgroup,
-//                           K split over the 4 waves, operands read k-major
-//                           straight from L2 (weights are pre-transposed once)
+//   embed_gather_kernel     xT[k][lane] = embed[token[lane]][k]
+//   lane_gemm_kernel        C^T = A^T-segments x k-major weights (+bias): LSTM gates
+//                           (x W_ih^T + h W_hh^T), projection, pred_ffn, and the joiner
+//                           output ffn_out (row-major logits); 32 output columns per
+//                           workgroup, K split over the 4 waves, LDS only for the final
+//                           4-way reduction
+//   lstm_cell_kernel        gates -> (c, h), predicated per lane ("predictor steps only
+//                           after a non-blank")
+//   joint_act_kernel        ht[j][lane] = tanh(enc_ffn(enc)[utt, t_lane, j] + pp[j][lane])
 //   greedy_update_kernel    log-softmax + argmax (first index on ties) + the
 //                           frame/emission state machine + cache commit
 //   beam_topk_kernel /      log-softmax, CTC mixture, top-k in LDS; per-utterance
-//   beam_update_kernel      expansion, prefix fusion (float64 log_add), stable prune
+//   beam_update_kernel      expansion, prefix fusion (float64 log_add), stable prune --
+//                           one candidate per thread
 //
 // Micro-steps are replayed from a hipGraph (captured once per decoder handle) so
-// the host only checks a "lanes still active" word every few dozen steps.
+// the host only checks a "lanes still active" word every 16 steps.
 #include "wr_common.hpp"
 
 #include <math.h>
@@ -41,20 +47,21 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kMaxLayers = WR_MAX_LSTM_LAYERS;
-constexpr int kLG = 8;            // lanes per workgroup in the LSTM step
 constexpr int kMaxBeam = 16;
 constexpr int kStepsPerGraph = 16;
 
 struct Dims {
     int V, E, P, D, H, L, J;      // vocab, encoder dim, predictor out dim, embed dim, hidden, layers, join dim
-    int Jp, Vp;                   // J padded to 8, V padded to 256 (k-major joiner weight)
+    int Dp, Hp, Pp, Jp;           // K dimensions padded to a multiple of 8 (zero rows)
+    int G4p, Vp;                  // N dimensions: 4H padded to 32, V padded to 256
     int NL, NLp;                  // lanes, lanes padded to 32
 };
 
 // Device-resident decoder state; all pointers are carved from the caller's workspace.
+// "T" suffix = k-major ([feature][NLp]).
 struct DevState {
     Dims d;
-    // transposed (k-major) weights
+    // k-major (transposed, zero padded) weights
     const float *embed;
     float *wt_ih[kMaxLayers], *wt_hh[kMaxLayers], *bsum[kMaxLayers];
     float *proj_wt, *predffn_wt, *encffn_wt, *out_wt;
@@ -67,11 +74,14 @@ struct DevState {
     // lane state
     float *ep_all;                // [n_utt, T, J]
     int32_t *token, *lane_t, *noblk, *need_pred, *lane_active;
-    float *cache_h, *cache_c;     // [L, NL, H] committed state
-    float *new_h, *new_c;         // [L, NL, H] output of the last predictor step
-    float *pred_out;              // [NL, P]  projected predictor output (step API)
-    float *pp;                    // [NL, J]
-    float *ht;                    // [Jp, NLp]  joiner activation, k-major
+    float *xT;                    // [Dp][NLp]     embedding of each lane's token
+    float *cache_hT, *cache_cT;   // [L][Hp][NLp]  committed LSTM state
+    float *new_hT, *new_cT;       // [L][Hp][NLp]  output of the last predictor step
+    float *alt_hT, *alt_cT;       // [L][Hp][NLp]  staging for beam reordering
+    float *gatesT;                // [G4p][NLp]
+    float *outT;                  // [Pp][NLp]     projected predictor output
+    float *ppT;                   // [Jp][NLp]     pred_ffn(predictor output)
+    float *ht;                    // [Jp][NLp]     joiner activation
     float *logits;                // [NL, V]
     int32_t *active_count;        // lanes still decoding
     // greedy outputs / params
@@ -83,8 +93,6 @@ struct DevState {
     float ctc_weight, tr_weight;
     float *topv;                  // [NL, beam]
     int32_t *topi;
-    float *alt_h, *alt_c;         // second committed-cache buffer (beam reorders hypotheses)
-    int32_t *cache_sel;           // [n_utt] which committed buffer is current (0/1)
     int32_t *bhyps;               // [2, n_utt, beam, Lmax]
     int32_t *bhyp_lens;           // [2, n_utt, beam]
     double *bscores;              // [n_utt, beam]
@@ -92,6 +100,15 @@ struct DevState {
     int32_t *frame;               // [n_utt]
     int32_t *hyp_sel;             // [n_utt]
     int Lmax;
+};
+
+struct GemmArgs {
+    const float *A0, *B0;         // segment 0: A^T [K0][lda], B [K0][ldb]   (K multiples of 8)
+    const float *A1, *B1;         // optional segment 1
+    int K0, K1, lda, ldb;
+    const float *bias;            // [N] or null
+    float *C;
+    int ldc, N, n_lanes;
 };
 
 // ----------------------------------------------------------------- setup --
@@ -149,153 +166,122 @@ __global__ __launch_bounds__(256) void ep_all_kernel(DevState *s)
 // --------------------------------------------------------- predictor step --
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
-// grid (ceil(H/32), ceil(n_lanes/kLG)), 128 threads: thread r -> gate r/32, hidden unit blockIdx.x*32 + r%32
-__global__ __launch_bounds__(128) void lstm_step_kernel(DevState *s, int layer)
+// xT[k][lane] = embed[token[lane]][k]
+__global__ void embed_gather_kernel(DevState *s)
 {
-    extern __shared__ float sm[];
     const Dims &d = s->d;
-    const int in_dim = (layer == 0) ? d.D : d.H;
-    float *xh = sm;                               // [kLG][in_dim + H]
-    float *gates = sm + kLG * (in_dim + d.H);     // [kLG][128]
-    const int n0 = blockIdx.y * kLG;
-    const int tid = threadIdx.x;
-    const int NLH = d.NL * d.H;
-
-    int need_any = 0;
-    for (int g = 0; g < kLG; ++g) {
-        const int n = n0 + g;
-        if (n < s->n_lanes && s->lane_active[n] && s->need_pred[n]) need_any = 1;
-    }
-    if (!need_any) return;
-
-    for (int g = 0; g < kLG; ++g) {
-        const int n = n0 + g;
-        const bool on = (n < s->n_lanes) && s->lane_active[n] && s->need_pred[n];
-        const float *x = nullptr;
-        if (on) x = (layer == 0) ? s->embed + (size_t)s->token[n] * d.D
-                                 : s->new_h + (size_t)(layer - 1) * NLH + (size_t)n * d.H;
-        const float *h = on ? s->cache_h + (size_t)layer * NLH + (size_t)n * d.H : nullptr;
-        for (int k = tid; k < in_dim; k += 128) xh[g * (in_dim + d.H) + k] = on ? x[k] : 0.f;
-        for (int k = tid; k < d.H; k += 128) xh[g * (in_dim + d.H) + in_dim + k] = on ? h[k] : 0.f;
-    }
-    __syncthreads();
-    const int gate = tid >> 5, unit = blockIdx.x * 32 + (tid & 31);
-    const int row = gate * d.H + unit;
-    const int G4 = 4 * d.H;
-    float acc[kLG];
-#pragma unroll
-    for (int g = 0; g < kLG; ++g) acc[g] = 0.f;
-    if (unit < d.H) {
-        const float *wi = s->wt_ih[layer] + row;
-        for (int k = 0; k < in_dim; ++k) {
-            const float w = wi[(size_t)k * G4];
-#pragma unroll
-            for (int g = 0; g < kLG; ++g) acc[g] = fmaf(w, xh[g * (in_dim + d.H) + k], acc[g]);
-        }
-        const float *wh = s->wt_hh[layer] + row;
-        for (int k = 0; k < d.H; ++k) {
-            const float w = wh[(size_t)k * G4];
-#pragma unroll
-            for (int g = 0; g < kLG; ++g) acc[g] = fmaf(w, xh[g * (in_dim + d.H) + in_dim + k], acc[g]);
-        }
-        const float b = s->bsum[layer][row];
-#pragma unroll
-        for (int g = 0; g < kLG; ++g) gates[g * 128 + tid] = acc[g] + b;
-    }
-    __syncthreads();
-    for (int w = tid; w < kLG * 32; w += 128) {
-        const int g = w >> 5, u = w & 31;
-        const int n = n0 + g, un = blockIdx.x * 32 + u;
-        if (n >= s->n_lanes || un >= d.H) continue;
-        if (!(s->lane_active[n] && s->need_pred[n])) continue;
-        const float ig = sigmoidf_(gates[g * 128 + u]);
-        const float fg = sigmoidf_(gates[g * 128 + 32 + u]);
-        const float gg = tanhf(gates[g * 128 + 64 + u]);
-        const float og = sigmoidf_(gates[g * 128 + 96 + u]);
-        const size_t o = (size_t)layer * NLH + (size_t)n * d.H + un;
-        const float c = fg * s->cache_c[o] + ig * gg;
-        s->new_c[o] = c;
-        s->new_h[o] = og * tanhf(c);
-    }
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = idx % d.NLp, k = idx / d.NLp;
+    if (k >= d.D || lane >= s->n_lanes) return;
+    s->xT[(size_t)k * d.NLp + lane] = s->embed[(size_t)s->token[lane] * d.D + k];
 }
 
-// one workgroup per lane: projection + pred_ffn (if the predictor stepped), then the joiner activation
-__global__ __launch_bounds__(256) void proj_step_kernel(DevState *s)
-{
-    extern __shared__ float sm[];                 // [H] + [P]
-    const Dims &d = s->d;
-    const int n = blockIdx.x;
-    const int tid = threadIdx.x;
-    const bool active = s->lane_active[n] != 0;
-    if (active && s->need_pred[n]) {
-        float *hv = sm, *ov = sm + d.H;
-        const float *h = s->new_h + (size_t)(d.L - 1) * d.NL * d.H + (size_t)n * d.H;
-        for (int k = tid; k < d.H; k += 256) hv[k] = h[k];
-        __syncthreads();
-        for (int p = tid; p < d.P; p += 256) {
-            float a = 0.f;
-            for (int k = 0; k < d.H; ++k) a = fmaf(s->proj_wt[(size_t)k * d.P + p], hv[k], a);
-            ov[p] = a + s->proj_b[p];
-            s->pred_out[(size_t)n * d.P + p] = ov[p];
-        }
-        __syncthreads();
-        for (int j = tid; j < d.J; j += 256) {
-            float a = 0.f;
-            for (int k = 0; k < d.P; ++k) a = fmaf(s->predffn_wt[(size_t)k * d.J + j], ov[k], a);
-            s->pp[(size_t)n * d.J + j] = a + s->predffn_b[j];
-        }
-        __syncthreads();
-    }
-    // joiner activation for this lane's current frame (zero for idle lanes so the MFMA tile stays finite)
-    const int utt = n / s->lanes_per_utt;
-    const int t = s->lane_t[n];
-    const float *ep = s->ep_all + ((size_t)utt * s->T + (t < s->T ? t : s->T - 1)) * d.J;
-    for (int j = tid; j < d.Jp; j += 256) {
-        float v = 0.f;
-        if (active && j < d.J) v = tanhf(ep[j] + s->pp[(size_t)n * d.J + j]);
-        s->ht[(size_t)j * d.NLp + n] = v;
-    }
-}
-
-// logits[lane, v] = sum_k ht[k][lane] * out_wt[k][v] + b[v]; one workgroup per 32 vocabulary columns
-template <int MT /* 32-lane tiles */>
-__global__ __launch_bounds__(256) void joint_step_kernel(DevState *s)
+// C = sum over segments of A^T B (+ bias).  grid.x = column tiles of 32; 256 threads = 4 waves, each
+// takes a quarter of every segment's K; MT 32-lane tiles.  ROWMAJOR: C[lane][n] else C^T[n][lane].
+template <int MT, bool ROWMAJOR>
+__global__ __launch_bounds__(256) void lane_gemm_kernel(GemmArgs g)
 {
     __shared__ float red[4][MT][32 * 32];
-    const Dims &d = s->d;
-    const int v0 = blockIdx.x * 32;
+    const int n0 = blockIdx.x * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int kq = d.Jp / 4;                      // Jp is a multiple of 8 -> each quarter is even
-    const int kb = wave * kq;
     f32x16 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = (f32x16){0};
-    const float *__restrict__ A = s->ht + (size_t)(kb + half) * d.NLp + l31;
-    const float *__restrict__ Bm = s->out_wt + (size_t)(kb + half) * d.Vp + v0 + l31;
-#pragma unroll 4
-    for (int k = 0; k < kq; k += 2) {
-        const float b = Bm[(size_t)k * d.Vp];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const float a = A[(size_t)k * d.NLp + m * 32];
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[m], 0, 0, 0);
+    for (int seg = 0; seg < 2; ++seg) {
+        const float *__restrict__ As = seg ? g.A1 : g.A0;
+        const float *__restrict__ Bs = seg ? g.B1 : g.B0;
+        const int K = seg ? g.K1 : g.K0;
+        if (As == nullptr || K == 0) continue;
+        const int kq = K / 4, kb = wave * kq;
+        const float *__restrict__ A = As + (size_t)(kb + half) * g.lda + l31;
+        const float *__restrict__ Bm = Bs + (size_t)(kb + half) * g.ldb + n0 + l31;
+        // The operands come straight from L2: issue a whole chunk of fragment loads before the first MFMA
+        // of the chunk so that ~CH*(MT+1) loads are in flight per lane instead of one dependent load per step.
+        constexpr int CH = (MT <= 2) ? 16 : 8;
+        for (int k0 = 0; k0 < kq; k0 += 2 * CH) {
+            float bv[CH], av[MT][CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int k = k0 + 2 * i;
+                const bool ok = k < kq;
+                bv[i] = ok ? Bm[(size_t)k * g.ldb] : 0.f;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) av[m][i] = ok ? A[(size_t)k * g.lda + m * 32] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][i], bv[i], acc[m], 0, 0, 0);
         }
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;       // C/D layout of the 32x32 MFMA
             red[wave][m][row * 32 + l31] = acc[m][r];
         }
     __syncthreads();
-    for (int i = tid; i < MT * 1024; i += 256) {
-        const int m = i >> 10, rc = i & 1023;
-        const int n = m * 32 + (rc >> 5), v = v0 + (rc & 31);
-        if (n < s->n_lanes && v < d.V)
-            s->logits[(size_t)n * d.V + v] = (red[0][m][rc] + red[1][m][rc]) + (red[2][m][rc] + red[3][m][rc]) + s->out_b[v];
+    if (ROWMAJOR) {
+        for (int i = tid; i < MT * 1024; i += 256) {
+            const int m = i >> 10, rc = i & 1023;
+            const int n = m * 32 + (rc >> 5), v = n0 + (rc & 31);
+            if (n < g.n_lanes && v < g.N) {
+                const float bias = g.bias ? g.bias[v] : 0.f;
+                g.C[(size_t)n * g.ldc + v] = (red[0][m][rc] + red[1][m][rc]) + (red[2][m][rc] + red[3][m][rc]) + bias;
+            }
+        }
+    } else {
+        for (int i = tid; i < MT * 1024; i += 256) {
+            const int m = i >> 10, q = i & 1023;
+            const int col = q >> 5, ln = q & 31;                      // consecutive threads -> consecutive lanes
+            const int rc = ln * 32 + col;
+            const int v = n0 + col, n = m * 32 + ln;
+            if (v < g.N) {
+                const float bias = g.bias ? g.bias[v] : 0.f;
+                g.C[(size_t)v * g.ldc + n] = (red[0][m][rc] + red[1][m][rc]) + (red[2][m][rc] + red[3][m][rc]) + bias;
+            }
+        }
     }
+}
+
+// gates (i, f, g, o rows of gatesT) -> new cell / hidden state; only lanes whose predictor steps are written
+__global__ void lstm_cell_kernel(DevState *s, int layer)
+{
+    const Dims &d = s->d;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = idx % d.NLp, unit = idx / d.NLp;
+    if (unit >= d.H || lane >= s->n_lanes) return;
+    if (!(s->lane_active[lane] && s->need_pred[lane])) return;
+    const float *gt = s->gatesT;
+    const float ig = sigmoidf_(gt[(size_t)unit * d.NLp + lane]);
+    const float fg = sigmoidf_(gt[(size_t)(d.H + unit) * d.NLp + lane]);
+    const float gg = tanhf(gt[(size_t)(2 * d.H + unit) * d.NLp + lane]);
+    const float og = sigmoidf_(gt[(size_t)(3 * d.H + unit) * d.NLp + lane]);
+    const size_t o = ((size_t)layer * d.Hp + unit) * d.NLp + lane;
+    const float c = fg * s->cache_cT[o] + ig * gg;
+    s->new_cT[o] = c;
+    s->new_hT[o] = og * tanhf(c);
+}
+
+// ht[j][lane] = tanh(enc_ffn(enc)[utt, t_lane, j] + pp[j][lane]); zero for idle lanes
+__global__ void joint_act_kernel(DevState *s)
+{
+    const Dims &d = s->d;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = idx % d.NLp, j = idx / d.NLp;
+    if (j >= d.J || lane >= d.NLp) return;
+    float v = 0.f;
+    if (lane < s->n_lanes && s->lane_active[lane]) {
+        const int utt = lane / s->lanes_per_utt;
+        int t = s->lane_t[lane];
+        t = t < s->T ? t : s->T - 1;
+        v = tanhf(s->ep_all[((size_t)utt * s->T + t) * d.J + j] + s->ppT[(size_t)j * d.NLp + lane]);
+    }
+    s->ht[(size_t)j * d.NLp + lane] = v;
 }
 
 // ---------------------------------------------------------------- greedy --
@@ -304,12 +290,11 @@ __global__ void greedy_init_kernel(DevState *s)
     const Dims &d = s->d;
     const int n = blockIdx.x;
     const int tid = threadIdx.x;
-    for (int i = tid; i < d.L * d.H; i += blockDim.x) {
-        const int l = i / d.H, k = i % d.H;
-        const size_t o = (size_t)l * d.NL * d.H + (size_t)n * d.H + k;
-        s->cache_h[o] = 0.f; s->cache_c[o] = 0.f; s->new_h[o] = 0.f; s->new_c[o] = 0.f;
+    for (int i = tid; i < d.L * d.Hp; i += blockDim.x) {
+        const size_t o = (size_t)i * d.NLp + n;
+        s->cache_hT[o] = 0.f; s->cache_cT[o] = 0.f; s->new_hT[o] = 0.f; s->new_cT[o] = 0.f;
     }
-    for (int j = tid; j < d.J; j += blockDim.x) s->pp[(size_t)n * d.J + j] = 0.f;
+    for (int j = tid; j < d.Jp; j += blockDim.x) s->ppT[(size_t)j * d.NLp + n] = 0.f;
     if (tid == 0) {
         const int T = s->enc_lens[n] < s->T ? s->enc_lens[n] : s->T;
         s->token[n] = s->blank;
@@ -419,11 +404,10 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(DevState *s)
     }
     __syncthreads();
     if (s_commit) {                                // cache = new_cache (greedy_search copy.py:52)
-        for (int i = tid; i < d.L * d.H; i += 256) {
-            const int l = i / d.H, kk = i % d.H;
-            const size_t o = (size_t)l * d.NL * d.H + (size_t)n * d.H + kk;
-            s->cache_h[o] = s->new_h[o];
-            s->cache_c[o] = s->new_c[o];
+        for (int i = tid; i < d.L * d.Hp; i += 256) {
+            const size_t o = (size_t)i * d.NLp + n;
+            s->cache_hT[o] = s->new_hT[o];
+            s->cache_cT[o] = s->new_cT[o];
         }
     }
 }
@@ -434,13 +418,12 @@ __global__ void beam_init_kernel(DevState *s)
     const Dims &d = s->d;
     const int n = blockIdx.x, tid = threadIdx.x;
     const int b = n / s->beam, j = n % s->beam;
-    for (int i = tid; i < d.L * d.H; i += blockDim.x) {
-        const int l = i / d.H, k = i % d.H;
-        const size_t o = (size_t)l * d.NL * d.H + (size_t)n * d.H + k;
-        s->cache_h[o] = 0.f; s->cache_c[o] = 0.f; s->alt_h[o] = 0.f; s->alt_c[o] = 0.f;
-        s->new_h[o] = 0.f; s->new_c[o] = 0.f;
+    for (int i = tid; i < d.L * d.Hp; i += blockDim.x) {
+        const size_t o = (size_t)i * d.NLp + n;
+        s->cache_hT[o] = 0.f; s->cache_cT[o] = 0.f; s->alt_hT[o] = 0.f; s->alt_cT[o] = 0.f;
+        s->new_hT[o] = 0.f; s->new_cT[o] = 0.f;
     }
-    for (int q = tid; q < d.J; q += blockDim.x) s->pp[(size_t)n * d.J + q] = 0.f;
+    for (int q = tid; q < d.Jp; q += blockDim.x) s->ppT[(size_t)q * d.NLp + n] = 0.f;
     if (tid == 0) {
         const int T = s->enc_lens[b] < s->T ? s->enc_lens[b] : s->T;
         s->token[n] = s->blank;
@@ -453,7 +436,6 @@ __global__ void beam_init_kernel(DevState *s)
             s->n_hyps[b] = 1;
             s->frame[b] = 0;
             s->hyp_sel[b] = 0;
-            s->cache_sel[b] = 0;
             s->bscores[(size_t)b * s->beam] = 0.0;
         }
     }
@@ -511,13 +493,15 @@ __device__ __forceinline__ double log_add2(double a, double b)
     return mx + log(exp(a - mx) + exp(b - mx));
 }
 
-// one workgroup per utterance: expansion, prefix fusion, stable prune (prefix_beam_search.py:107-146)
+// one workgroup per utterance: expansion, prefix fusion, stable prune (prefix_beam_search.py:107-146),
+// one candidate (hypothesis j, rank t) per thread.
 __global__ __launch_bounds__(256) void beam_update_kernel(DevState *s)
 {
-    __shared__ int c_base[kMaxBeam * kMaxBeam], c_tok[kMaxBeam * kMaxBeam], c_len[kMaxBeam * kMaxBeam];
-    __shared__ double c_score[kMaxBeam * kMaxBeam];
-    __shared__ int order[kMaxBeam * kMaxBeam];
-    __shared__ int s_nf, s_keep;
+    constexpr int MC = kMaxBeam * kMaxBeam;
+    __shared__ int c_base[MC], c_tok[MC], c_len[MC], c_last[MC], c_rep[MC], order[kMaxBeam];
+    __shared__ double c_score[MC], f_score[MC];
+    __shared__ int s_keep;
+    extern __shared__ int32_t hyl[];              // [beam][Lmax] this utterance's hypotheses, staged once
     const Dims &d = s->d;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int beam = s->beam;
@@ -525,6 +509,7 @@ __global__ __launch_bounds__(256) void beam_update_kernel(DevState *s)
     const int fr = s->frame[b];
     if (fr >= T) return;
     const int N = s->n_hyps[b];
+    const int C = N * beam;
     const int sel = s->hyp_sel[b];
     const size_t hstride = (size_t)s->n_utt * beam * s->Lmax;
     const int32_t *hy = s->bhyps + sel * hstride + (size_t)b * beam * s->Lmax;
@@ -532,83 +517,91 @@ __global__ __launch_bounds__(256) void beam_update_kernel(DevState *s)
     const int32_t *hl = s->bhyp_lens + (size_t)sel * s->n_utt * beam + (size_t)b * beam;
     int32_t *hl2 = s->bhyp_lens + (size_t)(1 - sel) * s->n_utt * beam + (size_t)b * beam;
 
-    if (tid == 0) {
-        int nf = 0;
-        for (int j = 0; j < N; ++j) {
-            const int n = b * beam + j;
-            // scores tensor is fp32 built from Python floats (:86); add in fp32 (:105); .item() -> float64 (:116)
-            const float sj = (float)s->bscores[(size_t)b * beam + j];
-            for (int t = 0; t < beam; ++t) {
-                const int tok = s->topi[(size_t)n * beam + t];
-                const double sc = (double)(sj + s->topv[(size_t)n * beam + t]);
-                const int len = hl[j] + (tok != s->blank ? 1 : 0);
-                // prefix fusion: first occurrence wins, later equal hypotheses add their score (:130-142)
-                int hit = -1;
-                for (int f = 0; f < nf && hit < 0; ++f) {
-                    if (c_len[f] != len) continue;
-                    const int bj = c_base[f], bt = c_tok[f];
-                    const int lb = hl[bj];          // base length of the fused entry
-                    bool same = true;
-                    for (int q = len - 1; q >= 0 && same; --q) {
-                        const int a = (q < hl[j]) ? hy[(size_t)j * s->Lmax + q] : tok;
-                        const int c = (q < lb) ? hy[(size_t)bj * s->Lmax + q] : bt;
-                        same = (a == c);
-                    }
-                    if (same) hit = f;
-                }
-                if (hit >= 0) c_score[hit] = log_add2(c_score[hit], sc);
-                else {
-                    c_base[nf] = j; c_tok[nf] = tok; c_len[nf] = len; c_score[nf] = sc;
-                    ++nf;
-                }
-            }
-        }
-        // stable sort by score, descending (list.sort(key=score, reverse=True) keeps fusion order on ties)
-        for (int i = 0; i < nf; ++i) order[i] = i;
-        for (int i = 1; i < nf; ++i) {
-            const int o = order[i];
-            int p = i - 1;
-            while (p >= 0 && c_score[order[p]] < c_score[o]) { order[p + 1] = order[p]; --p; }
-            order[p + 1] = o;
-        }
-        s_nf = nf;
-        s_keep = nf < beam ? nf : beam;
+    for (int j = 0; j < N; ++j) {
+        const int lb = hl[j];
+        for (int q = tid; q < lb; q += 256) hyl[j * s->Lmax + q] = hy[(size_t)j * s->Lmax + q];
     }
     __syncthreads();
-    const int keep = s_keep;
-    const int csel = s->cache_sel[b];
-    const float *ch = csel ? s->alt_h : s->cache_h, *cc = csel ? s->alt_c : s->cache_c;
-    float *nh = csel ? s->cache_h : s->alt_h, *nc = csel ? s->cache_c : s->alt_c;
+    // phase 1: candidates in the reference's order (hypothesis-major, then top-k rank; :109-127)
+    if (tid < C) {
+        const int j = tid / beam, t = tid - j * beam;
+        const int n = b * beam + j;
+        const int tok = s->topi[(size_t)n * beam + t];
+        // scores tensor is fp32 built from Python floats (:86); add in fp32 (:105); .item() -> float64 (:116)
+        const float sj = (float)s->bscores[(size_t)b * beam + j];
+        c_score[tid] = (double)(sj + s->topv[(size_t)n * beam + t]);
+        c_base[tid] = j;
+        c_tok[tid] = tok;
+        const int lb = hl[j];
+        c_len[tid] = lb + (tok != s->blank ? 1 : 0);
+        c_last[tid] = (tok != s->blank) ? tok : hyl[j * s->Lmax + lb - 1];
+    }
+    __syncthreads();
+    // phase 2: class representative = the first candidate with the same token sequence (:130-142)
+    if (tid < C) {
+        int rep = tid;
+        const int j = c_base[tid], tok = c_tok[tid], len = c_len[tid], lbj = hl[j];
+        for (int f = 0; f < tid && rep == tid; ++f) {
+            if (c_len[f] != len || c_last[f] != c_last[tid]) continue;
+            const int bj = c_base[f], bt = c_tok[f], lb = hl[bj];
+            bool same = true;
+            for (int q = len - 2; q >= 0 && same; --q) {
+                const int x = (q < lbj) ? hyl[j * s->Lmax + q] : tok;
+                const int y = (q < lb) ? hyl[bj * s->Lmax + q] : bt;
+                same = (x == y);
+            }
+            if (same) rep = f;
+        }
+        c_rep[tid] = rep;
+    }
+    __syncthreads();
+    // phase 3: a representative accumulates its duplicates' scores in candidate order with float64 log_add
+    if (tid < C) {
+        double sc = c_score[tid];
+        if (c_rep[tid] == tid)
+            for (int f = tid + 1; f < C; ++f)
+                if (c_rep[f] == tid) sc = log_add2(sc, c_score[f]);
+        f_score[tid] = sc;
+    }
+    __syncthreads();
+    // phase 4: stable descending sort position among representatives (list.sort(reverse=True) keeps order on ties)
+    if (tid == 0) s_keep = 0;
+    __syncthreads();
+    if (tid < C && c_rep[tid] == tid) {
+        int rank = 0;
+        const double me = f_score[tid];
+        for (int f = 0; f < C; ++f)
+            if (c_rep[f] == f && (f_score[f] > me || (f_score[f] == me && f < tid))) ++rank;
+        if (rank < beam) order[rank] = tid;
+        atomicAdd(&s_keep, 1);
+    }
+    __syncthreads();
+    const int keep = s_keep < beam ? s_keep : beam;
+    // phase 5: write the pruned beam (other hypothesis buffer) and the caches that go with it (staging buffer)
     for (int e = 0; e < keep; ++e) {
         const int f = order[e];
-        const int j = c_base[f], tok = c_tok[f], len = c_len[f];
+        const int j = c_base[f], tok = c_tok[f];
         const int lb = hl[j];
-        for (int q = tid; q < lb; q += 256) hy2[(size_t)e * s->Lmax + q] = hy[(size_t)j * s->Lmax + q];
+        for (int q = tid; q < lb; q += 256) hy2[(size_t)e * s->Lmax + q] = hyl[j * s->Lmax + q];
         const int src = b * beam + j, dst = b * beam + e;
         // blank keeps the base hypothesis' cache, a label takes the predictor's new cache (:111-124)
         const bool blank_ext = (tok == s->blank);
-        for (int i = tid; i < d.L * d.H; i += 256) {
-            const int l = i / d.H, k = i % d.H;
-            const size_t so = (size_t)l * d.NL * d.H + (size_t)src * d.H + k;
-            const size_t dst_o = (size_t)l * d.NL * d.H + (size_t)dst * d.H + k;
-            nh[dst_o] = blank_ext ? ch[so] : s->new_h[so];
-            nc[dst_o] = blank_ext ? cc[so] : s->new_c[so];
+        for (int i = tid; i < d.L * d.Hp; i += 256) {
+            const size_t so = (size_t)i * d.NLp + src, dst_o = (size_t)i * d.NLp + dst;
+            s->alt_hT[dst_o] = blank_ext ? s->cache_hT[so] : s->new_hT[so];
+            s->alt_cT[dst_o] = blank_ext ? s->cache_cT[so] : s->new_cT[so];
         }
         if (tid == 0) {
             if (!blank_ext && lb < s->Lmax) hy2[(size_t)e * s->Lmax + lb] = tok;
-            hl2[e] = len;
+            hl2[e] = c_len[f];
         }
     }
     __syncthreads();
     if (tid == 0) {
         for (int e = 0; e < keep; ++e) {
             const int f = order[e];
-            s->bscores[(size_t)b * beam + e] = c_score[f];
-            const int n = b * beam + e;
-            const int tok = c_tok[f];
-            // next frame's predictor input is the last token of the hypothesis (:78-80)
-            const int j = c_base[f];
-            s->token[n] = (tok != s->blank) ? tok : hy[(size_t)j * s->Lmax + hl[j] - 1];
+            s->bscores[(size_t)b * beam + e] = f_score[f];
+            s->token[b * beam + e] = c_last[f];      // next frame's predictor input: last token of the hypothesis (:78-80)
         }
         const int nfr = fr + 1;
         for (int e = 0; e < beam; ++e) {
@@ -620,31 +613,21 @@ __global__ __launch_bounds__(256) void beam_update_kernel(DevState *s)
         s->n_hyps[b] = keep;
         s->frame[b] = nfr;
         s->hyp_sel[b] = 1 - sel;
-        s->cache_sel[b] = 1 - csel;
     }
 }
 
-// the LSTM step reads the committed cache through cache_h/cache_c; in beam mode the current buffer
-// alternates per utterance, so copy the current one into place before each frame's predictor step
-__global__ void beam_cache_gather_kernel(DevState *s)
+// the pruned beam's caches were staged in alt_*: make them the committed caches of the next frame
+__global__ void beam_cache_commit_kernel(DevState *s)
 {
     const Dims &d = s->d;
-    const int n = blockIdx.x, tid = threadIdx.x;
-    const int b = n / s->beam;
-    if (!s->lane_active[n] || s->cache_sel[b] == 0) return;
-    for (int i = tid; i < d.L * d.H; i += blockDim.x) {
-        const int l = i / d.H, k = i % d.H;
-        const size_t o = (size_t)l * d.NL * d.H + (size_t)n * d.H + k;
-        s->cache_h[o] = s->alt_h[o];
-        s->cache_c[o] = s->alt_c[o];
+    const long total = (long)d.L * d.Hp * d.NLp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i % d.NLp);
+        if (lane < s->n_lanes) {
+            s->cache_hT[i] = s->alt_hT[i];
+            s->cache_cT[i] = s->alt_cT[i];
+        }
     }
-}
-
-__global__ void beam_cache_fix_kernel(DevState *s)
-{
-    // after the gather, the "current" buffer for every utterance is cache_h/cache_c
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < s->n_utt) s->cache_sel[b] = 0;
 }
 
 __global__ void beam_export_kernel(DevState *s, int32_t *hyps_out, int32_t *lens_out, double *scores_out, int32_t *n_out)
@@ -680,6 +663,7 @@ struct wr_decoder {
     char *ws;
     size_t ws_bytes;
     int max_utt, Tmax, max_hyp, max_beam;
+    size_t zero_range[2];
     int32_t *h_active;            // pinned host word
     hipStream_t work;             // decode work runs here (graph capture is illegal on the legacy default stream)
     hipEvent_t ev_in, ev_out;     // ordering against the caller's stream, no device-wide sync
@@ -705,44 +689,51 @@ struct Carver {
 };
 
 size_t carve(const wr_transducer_weights *w, int max_lanes, int max_utt, int Tmax, int max_hyp, int max_beam, char *base,
-             DevState *st, DevState **dev)
+             DevState *st, DevState **dev, size_t *zero_range = nullptr)
 {
     Carver c{base, 0};
     Dims d;
     d.V = w->vocab_size; d.E = w->enc_dim; d.P = w->pred_dim; d.D = w->embed_dim; d.H = w->hidden; d.L = w->n_layers;
     d.J = w->join_dim;
-    d.Jp = (d.J + 7) / 8 * 8;
-    d.Vp = (d.V + 255) / 256 * 256;
+    auto up = [](int x, int m) { return (x + m - 1) / m * m; };
+    d.Dp = up(d.D, 8); d.Hp = up(d.H, 8); d.Pp = up(d.P, 8); d.Jp = up(d.J, 8);
+    d.G4p = up(4 * d.H, 32);
+    d.Vp = up(d.V, 256);
     d.NL = max_lanes;
-    d.NLp = (max_lanes + 31) / 32 * 32;
+    d.NLp = up(max_lanes, 32);
     DevState s;
     memset(&s, 0, sizeof(s));
     s.d = d;
     DevState *devp = c.take<DevState>(1);
+    const size_t zero_begin = align_up(c.off, 256);       // everything from here to zero_end is zero-filled at create
     for (int l = 0; l < d.L; ++l) {
-        const int in_dim = l == 0 ? d.D : d.H;
-        s.wt_ih[l] = c.take<float>((size_t)in_dim * 4 * d.H);
-        s.wt_hh[l] = c.take<float>((size_t)d.H * 4 * d.H);
-        s.bsum[l] = c.take<float>((size_t)4 * d.H);
+        const int in_p = l == 0 ? d.Dp : d.Hp;
+        s.wt_ih[l] = c.take<float>((size_t)in_p * d.G4p);
+        s.wt_hh[l] = c.take<float>((size_t)d.Hp * d.G4p);
+        s.bsum[l] = c.take<float>((size_t)d.G4p);
     }
-    s.proj_wt = c.take<float>((size_t)d.H * d.P);
-    s.predffn_wt = c.take<float>((size_t)d.P * d.J);
+    const int Pn = up(d.P, 32), Jn = up(d.J, 32);
+    s.proj_wt = c.take<float>((size_t)d.Hp * Pn);
+    s.predffn_wt = c.take<float>((size_t)d.Pp * Jn);
     s.encffn_wt = c.take<float>((size_t)d.E * d.J);
     s.out_wt = c.take<float>((size_t)d.Jp * d.Vp);
-    s.ep_all = c.take<float>((size_t)max_utt * Tmax * d.J);
-    s.token = c.take<int32_t>(d.NL); s.lane_t = c.take<int32_t>(d.NL); s.noblk = c.take<int32_t>(d.NL);
-    s.need_pred = c.take<int32_t>(d.NL); s.lane_active = c.take<int32_t>(d.NLp);
-    const size_t cs = (size_t)d.L * d.NL * d.H;
-    s.cache_h = c.take<float>(cs); s.cache_c = c.take<float>(cs);
-    s.new_h = c.take<float>(cs); s.new_c = c.take<float>(cs);
-    s.alt_h = c.take<float>(cs); s.alt_c = c.take<float>(cs);
-    s.pred_out = c.take<float>((size_t)d.NL * d.P);
-    s.pp = c.take<float>((size_t)d.NL * d.J);
+    s.xT = c.take<float>((size_t)d.Dp * d.NLp);
+    const size_t cs = (size_t)d.L * d.Hp * d.NLp;
+    s.cache_hT = c.take<float>(cs); s.cache_cT = c.take<float>(cs);
+    s.new_hT = c.take<float>(cs); s.new_cT = c.take<float>(cs);
+    s.alt_hT = c.take<float>(cs); s.alt_cT = c.take<float>(cs);
+    s.gatesT = c.take<float>((size_t)d.G4p * d.NLp);
+    s.outT = c.take<float>((size_t)d.Pp * d.NLp);
+    s.ppT = c.take<float>((size_t)d.Jp * d.NLp);
     s.ht = c.take<float>((size_t)d.Jp * d.NLp);
+    const size_t zero_end = align_up(c.off, 256);
+    s.ep_all = c.take<float>((size_t)max_utt * Tmax * d.J);
+    s.token = c.take<int32_t>(d.NLp); s.lane_t = c.take<int32_t>(d.NLp); s.noblk = c.take<int32_t>(d.NLp);
+    s.need_pred = c.take<int32_t>(d.NLp); s.lane_active = c.take<int32_t>(d.NLp);
     s.logits = c.take<float>((size_t)d.NL * d.V);
     s.active_count = c.take<int32_t>(64);
     s.topv = c.take<float>((size_t)d.NL * kMaxBeam); s.topi = c.take<int32_t>((size_t)d.NL * kMaxBeam);
-    s.cache_sel = c.take<int32_t>(max_utt); s.n_hyps = c.take<int32_t>(max_utt); s.frame = c.take<int32_t>(max_utt);
+    s.n_hyps = c.take<int32_t>(max_utt); s.frame = c.take<int32_t>(max_utt);
     s.hyp_sel = c.take<int32_t>(max_utt);
     const int Lmax = Tmax + 1;
     s.bhyps = c.take<int32_t>((size_t)2 * max_utt * max_beam * Lmax);
@@ -750,6 +741,7 @@ size_t carve(const wr_transducer_weights *w, int max_lanes, int max_utt, int Tma
     s.bscores = c.take<double>((size_t)max_utt * max_beam);
     s.Lmax = Lmax;
     s.max_hyp = max_hyp;
+    if (zero_range) { zero_range[0] = zero_begin; zero_range[1] = zero_end; }
     if (st) *st = s;
     if (dev) *dev = devp;
     return align_up(c.off, 256);
@@ -778,23 +770,59 @@ void launch_transpose(const float *src, int R, int C, int Rp, int Cp, float *dst
     hipLaunchKernelGGL(transpose_pad_kernel, dim3((Rp + 31) / 32, (Cp + 31) / 32), dim3(256), 0, st, src, R, C, Rp, Cp, dst);
 }
 
+template <bool ROWMAJOR>
+void launch_gemm(const GemmArgs &g, int n_cols_padded, int n_lanes, hipStream_t st)
+{
+    const int mt = (n_lanes + 31) / 32;
+    const dim3 grid(n_cols_padded / 32);
+    switch (mt) {
+        case 1: hipLaunchKernelGGL((lane_gemm_kernel<1, ROWMAJOR>), grid, dim3(256), 0, st, g); break;
+        case 2: hipLaunchKernelGGL((lane_gemm_kernel<2, ROWMAJOR>), grid, dim3(256), 0, st, g); break;
+        case 3: hipLaunchKernelGGL((lane_gemm_kernel<3, ROWMAJOR>), grid, dim3(256), 0, st, g); break;
+        default: hipLaunchKernelGGL((lane_gemm_kernel<4, ROWMAJOR>), grid, dim3(256), 0, st, g); break;
+    }
+}
+
+// predictor step (predicated per lane) up to and including pred_ffn
+void launch_predictor(wr_decoder *h, int n_lanes, hipStream_t st)
+{
+    const Dims &d = h->d;
+    const DevState &s = h->host;
+    auto up = [](int x, int m) { return (x + m - 1) / m * m; };
+    hipLaunchKernelGGL(embed_gather_kernel, dim3((d.D * d.NLp + 255) / 256), dim3(256), 0, st, h->dev);
+    const size_t ls = (size_t)d.Hp * d.NLp;
+    for (int l = 0; l < d.L; ++l) {
+        GemmArgs g{};
+        g.A0 = l == 0 ? s.xT : s.new_hT + (size_t)(l - 1) * ls;  g.B0 = s.wt_ih[l];  g.K0 = l == 0 ? d.Dp : d.Hp;
+        g.A1 = s.cache_hT + (size_t)l * ls;                       g.B1 = s.wt_hh[l];  g.K1 = d.Hp;
+        g.lda = d.NLp; g.ldb = d.G4p; g.bias = s.bsum[l]; g.C = s.gatesT; g.ldc = d.NLp; g.N = 4 * d.H; g.n_lanes = n_lanes;
+        launch_gemm<false>(g, d.G4p, n_lanes, st);
+        hipLaunchKernelGGL(lstm_cell_kernel, dim3((d.H * d.NLp + 255) / 256), dim3(256), 0, st, h->dev, l);
+    }
+    {
+        GemmArgs g{};
+        g.A0 = s.new_hT + (size_t)(d.L - 1) * ls; g.B0 = s.proj_wt; g.K0 = d.Hp;
+        g.lda = d.NLp; g.ldb = up(d.P, 32); g.bias = s.proj_b; g.C = s.outT; g.ldc = d.NLp; g.N = d.P; g.n_lanes = n_lanes;
+        launch_gemm<false>(g, up(d.P, 32), n_lanes, st);
+    }
+    {
+        GemmArgs g{};
+        g.A0 = s.outT; g.B0 = s.predffn_wt; g.K0 = d.Pp;
+        g.lda = d.NLp; g.ldb = up(d.J, 32); g.bias = s.predffn_b; g.C = s.ppT; g.ldc = d.NLp; g.N = d.J; g.n_lanes = n_lanes;
+        launch_gemm<false>(g, up(d.J, 32), n_lanes, st);
+    }
+}
+
 void launch_predictor_and_joint(wr_decoder *h, int n_lanes, hipStream_t st)
 {
     const Dims &d = h->d;
-    for (int l = 0; l < d.L; ++l) {
-        const int in_dim = l == 0 ? d.D : d.H;
-        const size_t lds = ((size_t)kLG * (in_dim + d.H) + kLG * 128) * sizeof(float);
-        hipLaunchKernelGGL(lstm_step_kernel, dim3((d.H + 31) / 32, (n_lanes + kLG - 1) / kLG), dim3(128), lds, st, h->dev, l);
-    }
-    hipLaunchKernelGGL(proj_step_kernel, dim3(n_lanes), dim3(256), (size_t)(d.H + d.P) * sizeof(float), st, h->dev);
-    const int mt = (n_lanes + 31) / 32;
-    const dim3 grid(d.Vp / 32);
-    switch (mt) {
-        case 1: hipLaunchKernelGGL((joint_step_kernel<1>), grid, dim3(256), 0, st, h->dev); break;
-        case 2: hipLaunchKernelGGL((joint_step_kernel<2>), grid, dim3(256), 0, st, h->dev); break;
-        case 3: hipLaunchKernelGGL((joint_step_kernel<3>), grid, dim3(256), 0, st, h->dev); break;
-        default: hipLaunchKernelGGL((joint_step_kernel<4>), grid, dim3(256), 0, st, h->dev); break;
-    }
+    const DevState &s = h->host;
+    launch_predictor(h, n_lanes, st);
+    hipLaunchKernelGGL(joint_act_kernel, dim3((d.J * d.NLp + 255) / 256), dim3(256), 0, st, h->dev);
+    GemmArgs g{};
+    g.A0 = s.ht; g.B0 = s.out_wt; g.K0 = d.Jp;
+    g.lda = d.NLp; g.ldb = d.Vp; g.bias = s.out_b; g.C = s.logits; g.ldc = d.V; g.N = d.V; g.n_lanes = n_lanes;
+    launch_gemm<true>(g, d.Vp, n_lanes, st);
 }
 
 }  // namespace
@@ -815,13 +843,21 @@ extern "C" int wr_decoder_create(const wr_transducer_weights *w, int max_lanes, 
     WR_REQUIRE(max_utt > 0 && max_utt <= max_lanes && Tmax > 0 && max_hyp >= 0, WR_EINVAL, "decoder_create: bad sizes");
     if (max_beam <= 0) max_beam = 1;
     WR_REQUIRE(max_beam <= kMaxBeam, WR_EUNSUPPORTED, "decoder_create: beam %d exceeds %d", max_beam, kMaxBeam);
+    {
+        const size_t hyp_lds = (size_t)max_beam * (Tmax + 1) * sizeof(int32_t);
+        WR_REQUIRE(max_beam == 1 || hyp_lds <= 140 * 1024, WR_EUNSUPPORTED,
+                   "decoder_create: beam %d x (Tmax %d + 1) hypotheses do not fit the beam-update kernel's LDS", max_beam, Tmax);
+        if (hyp_lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(beam_update_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)hyp_lds);
+    }
     const size_t need = carve(w, max_lanes, max_utt, Tmax, max_hyp, max_beam, nullptr, nullptr, nullptr);
     WR_REQUIRE(workspace_bytes >= need, WR_EWORKSPACE, "decoder_create: workspace %zu < required %zu", workspace_bytes, need);
     wr_decoder *h = new (std::nothrow) wr_decoder();
     WR_REQUIRE(h != nullptr, WR_EINVAL, "decoder_create: out of host memory");
     h->ws = static_cast<char *>(workspace_d);
     h->ws_bytes = workspace_bytes;
-    carve(w, max_lanes, max_utt, Tmax, max_hyp, max_beam, h->ws, &h->host, &h->dev);
+    carve(w, max_lanes, max_utt, Tmax, max_hyp, max_beam, h->ws, &h->host, &h->dev, h->zero_range);
     h->d = h->host.d;
     h->max_utt = max_utt; h->Tmax = Tmax; h->max_hyp = max_hyp; h->max_beam = max_beam;
     h->greedy_graph = nullptr; h->beam_graph = nullptr; h->greedy_graph_lanes = h->beam_graph_lanes = -1;
@@ -844,15 +880,17 @@ extern "C" int wr_decoder_create(const wr_transducer_weights *w, int max_lanes, 
     const Dims &d = h->d;
     DevState &s = h->host;
     s.embed = w->embed; s.proj_b = w->proj_b; s.predffn_b = w->pred_ffn_b; s.encffn_b = w->enc_ffn_b; s.out_b = w->out_b;
+    (void)hipMemsetAsync(h->ws + h->zero_range[0], 0, h->zero_range[1] - h->zero_range[0], st);
+    auto up = [](int x, int m) { return (x + m - 1) / m * m; };
     for (int l = 0; l < d.L; ++l) {
-        const int in_dim = l == 0 ? d.D : d.H;
-        launch_transpose(w->w_ih[l], 4 * d.H, in_dim, 4 * d.H, in_dim, s.wt_ih[l], st);
-        launch_transpose(w->w_hh[l], 4 * d.H, d.H, 4 * d.H, d.H, s.wt_hh[l], st);
+        const int in_dim = l == 0 ? d.D : d.H, in_p = l == 0 ? d.Dp : d.Hp;
+        launch_transpose(w->w_ih[l], 4 * d.H, in_dim, d.G4p, in_p, s.wt_ih[l], st);
+        launch_transpose(w->w_hh[l], 4 * d.H, d.H, d.G4p, d.Hp, s.wt_hh[l], st);
         hipLaunchKernelGGL(add_bias_kernel, dim3((4 * d.H + 255) / 256), dim3(256), 0, st, w->b_ih[l], w->b_hh[l], 4 * d.H,
                            s.bsum[l]);
     }
-    launch_transpose(w->proj_w, d.P, d.H, d.P, d.H, s.proj_wt, st);
-    launch_transpose(w->pred_ffn_w, d.J, d.P, d.J, d.P, s.predffn_wt, st);
+    launch_transpose(w->proj_w, d.P, d.H, up(d.P, 32), d.Hp, s.proj_wt, st);
+    launch_transpose(w->pred_ffn_w, d.J, d.P, up(d.J, 32), d.Pp, s.predffn_wt, st);
     launch_transpose(w->enc_ffn_w, d.J, d.E, d.J, d.E, s.encffn_wt, st);
     launch_transpose(w->out_w, d.V, d.J, d.Vp, d.Jp, s.out_wt, st);
     hipError_t e = hipGetLastError();
@@ -904,11 +942,11 @@ void greedy_micro_step(wr_decoder *h, int n_lanes, hipStream_t st)
 
 void beam_frame(wr_decoder *h, int n_lanes, int n_utt, hipStream_t st)
 {
-    hipLaunchKernelGGL(beam_cache_gather_kernel, dim3(n_lanes), dim3(128), 0, st, h->dev);
-    hipLaunchKernelGGL(beam_cache_fix_kernel, dim3((n_utt + 63) / 64), dim3(64), 0, st, h->dev);
     launch_predictor_and_joint(h, n_lanes, st);
     hipLaunchKernelGGL(beam_topk_kernel, dim3(n_lanes), dim3(256), (size_t)h->d.V * sizeof(float), st, h->dev);
-    hipLaunchKernelGGL(beam_update_kernel, dim3(n_utt), dim3(256), 0, st, h->dev);
+    hipLaunchKernelGGL(beam_update_kernel, dim3(n_utt), dim3(256), (size_t)h->host.beam * h->host.Lmax * sizeof(int32_t), st,
+                       h->dev);
+    hipLaunchKernelGGL(beam_cache_commit_kernel, dim3(64), dim3(256), 0, st, h->dev);
 }
 
 // Order the decoder's work stream after everything already enqueued on the caller's stream ...
@@ -1035,15 +1073,21 @@ extern "C" int wr_prefix_beam_search(wr_decoder *h, const float *enc_out_d, cons
 }
 
 namespace {
-// [L][srcN][H] -> [L][dstN][H] for the first N lanes
-__global__ void copy_cache_kernel(const float *__restrict__ src, int srcN, float *__restrict__ dst, int dstN, int L, int N, int H)
+// row-major [L][N][H]  <->  k-major [L][Hp][NLp]
+__global__ void cache_to_kmajor_kernel(const float *__restrict__ src, int N, int L, int H, int Hp, int NLp, float *__restrict__ dst)
 {
     const long total = (long)L * N * H;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int k = (int)(i % H);
-        const int n = (int)((i / H) % N);
-        const int l = (int)(i / ((long)H * N));
-        dst[((size_t)l * dstN + n) * H + k] = src[((size_t)l * srcN + n) * H + k];
+        const int k = (int)(i % H), n = (int)((i / H) % N), l = (int)(i / ((long)H * N));
+        dst[((size_t)l * Hp + k) * NLp + n] = src[i];
+    }
+}
+__global__ void cache_from_kmajor_kernel(const float *__restrict__ src, int N, int L, int H, int Hp, int NLp, float *__restrict__ dst)
+{
+    const long total = (long)L * N * H;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % H), n = (int)((i / H) % N), l = (int)(i / ((long)H * N));
+        dst[i] = src[((size_t)l * Hp + k) * NLp + n];
     }
 }
 
@@ -1053,17 +1097,10 @@ __global__ void step_setup_kernel(DevState *s, const int32_t *tokens, int N)
     if (n < s->d.NLp) {
         const int on = n < N;
         s->lane_active[n] = on;
-        if (n < s->d.NL) {
-            s->need_pred[n] = on;
-            s->lane_t[n] = 0;
-            if (on) s->token[n] = tokens[n];
-        }
+        s->need_pred[n] = on;
+        s->lane_t[n] = 0;
+        s->token[n] = on ? tokens[n] : 0;
     }
-}
-
-__global__ void copy_rows_kernel(const float *__restrict__ src, float *__restrict__ dst, long n)
-{
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 }  // namespace
 
@@ -1081,19 +1118,14 @@ extern "C" int wr_predictor_step(wr_decoder *h, const int32_t *tokens_d, const f
     DevState &s = h->host;
     s.n_utt = 1; s.T = 1; s.lanes_per_utt = d.NL; s.n_lanes = N; s.enc = nullptr; s.enc_lens = nullptr;
     if (int rc = upload_state(h, st)) return rc;
-    (void)hipMemsetAsync(s.ep_all, 0, sizeof(float) * d.J, st);
     hipLaunchKernelGGL(step_setup_kernel, dim3((d.NLp + 63) / 64), dim3(64), 0, st, h->dev, tokens_d, N);
-    hipLaunchKernelGGL(copy_cache_kernel, dim3(64), dim3(256), 0, st, cache_h_d, N, s.cache_h, d.NL, d.L, N, d.H);
-    hipLaunchKernelGGL(copy_cache_kernel, dim3(64), dim3(256), 0, st, cache_c_d, N, s.cache_c, d.NL, d.L, N, d.H);
-    for (int l = 0; l < d.L; ++l) {
-        const int in_dim = l == 0 ? d.D : d.H;
-        const size_t lds = ((size_t)kLG * (in_dim + d.H) + kLG * 128) * sizeof(float);
-        hipLaunchKernelGGL(lstm_step_kernel, dim3((d.H + 31) / 32, (N + kLG - 1) / kLG), dim3(128), lds, st, h->dev, l);
-    }
-    hipLaunchKernelGGL(proj_step_kernel, dim3(N), dim3(256), (size_t)(d.H + d.P) * sizeof(float), st, h->dev);
-    hipLaunchKernelGGL(copy_rows_kernel, dim3(32), dim3(256), 0, st, s.pred_out, out_d, (long)N * d.P);
-    hipLaunchKernelGGL(copy_cache_kernel, dim3(64), dim3(256), 0, st, s.new_h, d.NL, new_h_d, N, d.L, N, d.H);
-    hipLaunchKernelGGL(copy_cache_kernel, dim3(64), dim3(256), 0, st, s.new_c, d.NL, new_c_d, N, d.L, N, d.H);
+    hipLaunchKernelGGL(cache_to_kmajor_kernel, dim3(64), dim3(256), 0, st, cache_h_d, N, d.L, d.H, d.Hp, d.NLp, s.cache_hT);
+    hipLaunchKernelGGL(cache_to_kmajor_kernel, dim3(64), dim3(256), 0, st, cache_c_d, N, d.L, d.H, d.Hp, d.NLp, s.cache_cT);
+    launch_predictor(h, N, st);
+    // outT [Pp][NLp] -> out [N][P]: the same index map with L = 1
+    hipLaunchKernelGGL(cache_from_kmajor_kernel, dim3(32), dim3(256), 0, st, s.outT, N, 1, d.P, d.Pp, d.NLp, out_d);
+    hipLaunchKernelGGL(cache_from_kmajor_kernel, dim3(64), dim3(256), 0, st, s.new_hT, N, d.L, d.H, d.Hp, d.NLp, new_h_d);
+    hipLaunchKernelGGL(cache_from_kmajor_kernel, dim3(64), dim3(256), 0, st, s.new_cT, N, d.L, d.H, d.Hp, d.NLp, new_c_d);
     leave(h, caller);
     WR_CHECK_LAUNCH("predictor_step");
     return WR_OK;
