@@ -213,3 +213,60 @@ def test_half_precision_logits(dtype, tol, V):
     np.testing.assert_allclose(x.grad.float().cpu().numpy(), og, rtol=tol, atol=tol * 1e-1)
     for b in range(3):
         assert not x.grad[b, llens[b]:].any() and not x.grad[b, :, tlens[b] + 1:].any()
+
+
+def test_full_baseline_shape_properties():
+    """BASELINE.json configs[1] at full size (B=32, T=1000, U=150, V=5000, fp32; 96.6 GB of logits, gradient
+    written in place).  The f64 oracle cannot run at this size, so the check is through size-independent
+    properties: (1) forward/backward lattice agreement, -beta(0,0) == -(alpha(T-1,U) + log p(blank | T-1,U));
+    (2) every gradient row sums to zero; (3) padded cells are exactly zero; (4) the threaded fp32 CPU port
+    agrees on two whole utterances (cost and full gradient)."""
+    import wenet_celoss_amd as w
+    from wenet_celoss_amd.rnnt_loss import rnnt_lattice
+    free, _ = torch.cuda.mem_get_info()
+    B, T, U, V = 32, 1000, 150, 5000
+    if free < 110e9:
+        pytest.skip("needs ~100 GB of free HBM")
+    gen = torch.Generator(device=DEV).manual_seed(20260)
+    x = torch.empty(B, T, U + 1, V, device=DEV)
+    for b in range(B):
+        x[b].normal_(generator=gen)
+    y = torch.randint(1, V, (B, U), dtype=torch.int32, device=DEV, generator=gen)
+    cg = torch.Generator().manual_seed(1)
+    ll = torch.randint(T // 2, T + 1, (B,), generator=cg).to(torch.int32); ll[0] = T
+    tl = torch.randint(U // 3, U + 1, (B,), generator=cg).to(torch.int32); tl[1] = U
+    ll, tl = ll.to(DEV), tl.to(DEV)
+    keep = {b: x[b].cpu().numpy().copy() for b in (0, 5)}            # before the in-place gradient overwrites them
+    costs, alpha, beta = rnnt_lattice(x, y, ll, tl)
+    for b in range(0, B, 3):
+        Tb, Ub = int(ll[b]), int(tl[b])
+        lp_blank = torch.log_softmax(x[b, Tb - 1, Ub].double(), -1)[0].item()
+        fwd_ll = alpha[b, Tb - 1, Ub].item() + lp_blank
+        assert abs(fwd_ll + costs[b].item()) < 2e-3 * max(1.0, abs(fwd_ll) * 1e-3), (b, fwd_ll, costs[b].item())
+        assert abs(beta[b, 0, 0].item() + costs[b].item()) < 1e-2
+    del alpha, beta
+    # in-place gradient through the C-ABI directly (an autograd leaf cannot be overwritten)
+    from wenet_celoss_amd import _lib
+    lib = _lib.load()
+    xd = x.detach()
+    wsb = lib.wr_rnnt_workspace_bytes(B, T, U + 1)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    c2 = torch.empty(B, device=DEV)
+    st = _lib.current_stream(torch.device(DEV)); P = _lib.ptr
+    _lib.check(lib.wr_rnnt_loss_fwd(P(xd), 0, P(y), P(ll), P(tl), B, T, U + 1, V, 0, P(c2), P(ws), wsb, st))
+    _lib.check(lib.wr_rnnt_loss_bwd(P(xd), 0, P(y), P(ll), P(tl), B, T, U + 1, V, 0, -1.0, None, P(xd), P(ws), wsb, st))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(c2, costs)
+    g = xd                                                            # now holds the gradient
+    for b in (0, 7, 31):
+        Tb, Ub = int(ll[b]), int(tl[b])
+        assert g[b, :Tb, :Ub + 1].sum(-1).abs().max().item() < 3e-5
+        assert not g[b, Tb:].any() and not g[b, :, Ub + 1:].any()
+    for b, xb in keep.items():
+        lb, ub = np.array([int(ll[b])], np.int32), np.array([int(tl[b])], np.int32)
+        xs = np.ascontiguousarray(xb[None, :lb[0], :ub[0] + 1])
+        ys = np.ascontiguousarray(y[b:b + 1, :max(ub[0], 1)].cpu().numpy())
+        c32, g32 = oracle.rnnt_loss_f32(xs, ys, lb, ub, nthreads=16)
+        assert abs(c32[0] - costs[b].item()) < 1e-4 * abs(c32[0])
+        got = g[b, :lb[0], :ub[0] + 1].cpu().numpy()
+        np.testing.assert_allclose(got, g32[0], rtol=2e-2, atol=3e-5)    # the fp32 CPU lattice is the noisy side here

@@ -35,11 +35,15 @@ def bench_joint(args):
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     st = _lib.current_stream(dev); P = _lib.ptr
     f = lambda: _lib.check(lib.wr_joint_fwd(P(ep), P(pp), P(w), P(b), None, None, B, T, U1, J, V, P(out), P(ws), ws_bytes, st))
-    ms = timeit(f, args.steps)
     flops = 2.0 * B * T * U1 * J * V
-    print(json.dumps({"what": "joint_fwd", "shape": [B, T, U1, J, V], "ms": round(ms, 3),
-                      "TFLOPs": round(flops / ms / 1e9, 2), "peak_f32_mfma": 157.3,
-                      "frac": round(flops / ms / 1e9 / 157.3, 4)}), flush=True)
+    for variant in (0, 1, 2):
+        lib.wr_tune_set(5, variant)
+        ms = timeit(f, args.steps)
+        chk = float(out[0, 0, 0, :8].abs().sum())
+        print(json.dumps({"what": "joint_fwd", "variant": variant, "shape": [B, T, U1, J, V], "ms": round(ms, 3),
+                          "TFLOPs": round(flops / ms / 1e9, 2), "peak_f32_mfma": 157.3,
+                          "frac": round(flops / ms / 1e9 / 157.3, 4), "probe": chk}), flush=True)
+    lib.wr_tune_set(5, 2)
     dz = torch.empty(B, T, U1, J, device=dev); h = torch.empty_like(dz)
     g = lambda: _lib.check(lib.wr_joint_bwd_dz(P(out), P(ep), P(pp), P(w), None, None, B, T, U1, J, V, P(dz), P(h), st))
     ms = timeit(g, args.steps)

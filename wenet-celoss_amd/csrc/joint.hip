@@ -33,7 +33,7 @@ constexpr int kBK = 8;         // k-slice depth of the streamed operand (forward
 constexpr int kHPad = kBM + 1; // k-major activation tile row stride (floats)
 
 inline int joint_vpad(int V) { return (V + kBN - 1) / kBN * kBN; }
-inline int joint_jpad(int J) { return (J + kBK - 1) / kBK * kBK; }   // forward k-depth, zero padded
+inline int joint_jpad(int J) { return (J + 31) / 32 * 32; }   // forward k-depth, zero padded (multiple of 2*PFK)
 
 // W [V, J] row-major (nn.Linear weight)  ->  Wt [J, Vp] (k-major, zero padded to a multiple of 256 columns)
 __global__ void joint_transpose_w_kernel(const float *__restrict__ w, int V, int J, int Jp, int Vp, float *__restrict__ wt)
@@ -169,46 +169,135 @@ __global__ __launch_bounds__(256) void joint_fwd_kernel(
     }
 }
 
+// Forward, variant 2: the streamed operand never touches LDS.  Each wave owns its own 64 output columns, so
+// its B fragments (k-major W^T rows, 128 contiguous bytes per 32 columns) are not shared with the other
+// waves: they are loaded straight from L2 into registers, PFK k-steps ahead, and the k-loop has no barrier
+// and no LDS write at all -- only the read-only activation tile lives in LDS.
+template <int PFK, int CT /* 32-column tiles per wave: 2 -> 4 waves, 1 -> 8 waves */>
+__global__ __launch_bounds__(CT == 2 ? 256 : 512) void joint_fwd_direct_kernel(
+    const float *__restrict__ ep, const float *__restrict__ pp, const float *__restrict__ wt /* [Jp, Vp] */,
+    const float *__restrict__ bias, const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens,
+    int B, int T, int U1, int J, int Jp, int V, int Vp, float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *Ht = lds;                                  // [Jp][65]
+    const long M = (long)B * T * U1;
+    const long m0 = (long)blockIdx.x * kBM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    if (llens != nullptr && tlens != nullptr) {
+        int valid = 0;
+        const long m = m0 + tid;
+        if (tid < kBM && m < M) {
+            const long bt = m / U1;
+            const int u = (int)(m - bt * U1);
+            const int b = (int)(bt / T), t = (int)(bt - (long)b * T);
+            valid = (t < llens[b]) && (u <= tlens[b]);
+        }
+        if (!__syncthreads_or(valid)) return;
+    }
+    fill_h_tile(Ht, ep, pp, m0, M, T, U1, J, Jp);
+    __syncthreads();
+
+    const int nchunks = Vp / kBN;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wcol = wave * (32 * CT);
+    const float *__restrict__ Ah = Ht + half * kHPad + l31;       // + k * kHPad (+32 for the second row tile)
+
+    for (int nc = 0; nc < nchunks; ++nc) {
+        const int v0 = nc * kBN;
+        f32x16 acc[2][CT];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[r][c] = (f32x16){0};
+        const float *__restrict__ Bp = wt + (size_t)half * Vp + v0 + wcol + l31;   // + k * Vp (+32 second column tile)
+        // Register ping-pong in blocks of PFK k-steps: while the MFMAs of one block run, the B fragments (L2)
+        // and A fragments (LDS) of the next block are in flight in the other register set.  Straight-line,
+        // unconditional loads (the prefetch past the end wraps to block 0 of the same chunk); sched_barrier
+        // keeps the load group ahead of the MFMA group.
+        float pb[CT][PFK], pa[2][PFK];      // set P
+        float qb[CT][PFK], qa[2][PFK];      // set Q
+#define WR_LOAD_SET(b_, a_, kb_)                                                         \
+        _Pragma("unroll") for (int c = 0; c < CT; ++c)                                   \
+            _Pragma("unroll") for (int i = 0; i < PFK; ++i)                              \
+                b_[c][i] = Bp[(size_t)((kb_) + 2 * i) * Vp + 32 * c];                    \
+        _Pragma("unroll") for (int r = 0; r < 2; ++r)                                    \
+            _Pragma("unroll") for (int i = 0; i < PFK; ++i)                              \
+                a_[r][i] = Ah[((kb_) + 2 * i) * kHPad + 32 * r];
+#define WR_MFMA_SET(b_, a_)                                                                              \
+        _Pragma("unroll") for (int i = 0; i < PFK; ++i)                                                  \
+            _Pragma("unroll") for (int r = 0; r < 2; ++r)                                                \
+                _Pragma("unroll") for (int c = 0; c < CT; ++c)                                           \
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[r][i], b_[c][i], acc[r][c], 0, 0, 0);
+        WR_LOAD_SET(pb, pa, 0)
+        for (int kk = 0; kk < Jp; kk += 4 * PFK) {          // Jp is a multiple of 32 = 4 * PFK at PFK = 8
+            const int k1 = kk + 2 * PFK;
+            WR_LOAD_SET(qb, qa, k1)
+            __builtin_amdgcn_sched_barrier(0);
+            WR_MFMA_SET(pb, pa)
+            __builtin_amdgcn_sched_barrier(0);
+            const int k2 = (kk + 4 * PFK < Jp) ? kk + 4 * PFK : 0;
+            WR_LOAD_SET(pb, pa, k2)
+            __builtin_amdgcn_sched_barrier(0);
+            WR_MFMA_SET(qb, qa)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef WR_LOAD_SET
+#undef WR_MFMA_SET
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int col = v0 + wcol + 32 * c + l31;
+            const float bv = (col < V) ? bias[col] : 0.f;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * half;   // C/D layout of the 32x32 MFMA
+                    const long m = m0 + row;
+                    if (m < M && col < V) out[(size_t)m * V + col] = acc[rt][c][r] + bv;
+                }
+        }
+    }
+}
+
 // --------------------------------------------------------------- backward --
 // dZ tile (64 cells x J) = dY tile (64 x V) * W (V x J), then * (1 - H^2).
-// 4 waves, each 64 rows x (J/4) columns; J <= 512 -> at most 2 x 4 MFMA tiles per wave.
-constexpr int kBKv = 16;       // v-slice depth of the streamed dY / W operands
+// 8 waves (2 per SIMD), each 64 rows x 64 J-columns.  The dY slice (shared by all waves, streamed once from
+// HBM) is staged v-major in LDS, double buffered, one barrier per 16-deep slice; the W fragments belong to
+// one wave only and are loaded straight from L2 into a register ping-pong (no LDS, same scheme as forward).
+constexpr int kBKv = 16;       // v-slice depth of the streamed dY operand
+constexpr int kBwdWaves = 8;
 
-template <int NT /* 32-col tiles per wave = J/128 */>
-__global__ __launch_bounds__(256) void joint_bwd_dz_kernel(
+__global__ __launch_bounds__(512) void joint_bwd_dz_kernel(
     const float *__restrict__ gout /* [M, V] */, const float *__restrict__ ep, const float *__restrict__ pp,
     const float *__restrict__ w /* [V, J] */, const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens,
     int B, int T, int U1, int J, int V, float *__restrict__ dz /* [M, J] */, float *__restrict__ hout /* [M,J] or null */)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *As = lds;                                   // [2][kBKv][65]   dY slice, v-major
-    constexpr int JP = NT * 128;                       // W slice row stride (J zero padded)
-    float *Bs = lds + 2 * kBKv * kHPad;                // [2][kBKv][JP]   W slice
+    __shared__ float As[2][kBKv][kHPad];               // dY slice, v-major
     const long M = (long)B * T * U1;
     const long m0 = (long)blockIdx.x * kBM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int wcol = wave * (NT * 32);
+    const int wcol = wave * 64;
+    const bool wave_on = wcol < J;                     // waves beyond join_dim only help staging
 
-    f32x16 acc[2][NT];
+    f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x16){0};
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
 
-    // staging maps
-    //  A: 64 rows x 16 v  = 1024 floats -> 4 per thread: row = tid>>2, v4 = (tid&3)*4  (16-B pieces of a dY row)
-    const int arow = tid >> 2, av = (tid & 3) * 4;
+    // staging map for the dY slice: 64 rows x 16 v = 256 float4 -> threads 0..255
+    const int arow = (tid & 255) >> 2, av = (tid & 3) * 4;
     const long am = m0 + arow;
-    //  B: 16 v x J floats -> J/64 float4 per thread per ... generic loop below
+    const bool stager = tid < 256;
     const int nslices = (V + kBKv - 1) / kBKv;
-    const int b4_per_row = J / 4;                       // float4 per W row
-    const int b4_total = kBKv * b4_per_row;             // float4 per slice
 
     auto load_a = [&](int s, f32x4 &r) {
         const int v = s * kBKv + av;
         r = (f32x4){0, 0, 0, 0};
-        if (am < M) {
+        if (stager && am < M) {
             const float *src = gout + (size_t)am * V + v;
             if (v + 3 < V && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) r = *reinterpret_cast<const f32x4 *>(src);
             else {
@@ -219,70 +308,79 @@ __global__ __launch_bounds__(256) void joint_bwd_dz_kernel(
             }
         }
     };
-    auto store_a = [&](float *dst, const f32x4 &r) {
-        dst[(av + 0) * kHPad + arow] = r.x;
-        dst[(av + 1) * kHPad + arow] = r.y;
-        dst[(av + 2) * kHPad + arow] = r.z;
-        dst[(av + 3) * kHPad + arow] = r.w;
+    auto store_a = [&](int buf, const f32x4 &r) {
+        if (stager) {
+            As[buf][av + 0][arow] = r.x;
+            As[buf][av + 1][arow] = r.y;
+            As[buf][av + 2][arow] = r.z;
+            As[buf][av + 3][arow] = r.w;
+        }
     };
-    constexpr int kBMax = 8;                            // float4 per thread per slice at J=512: 16*128/256
-    auto load_b = [&](int s, f32x4 (&r)[kBMax]) {
+    // W fragment addresses: lane reads W[v + half][wcol + 32*c + l31]; columns/rows past the end are clamped
+    // (their products are multiplied by zero-padded dY or discarded in the epilogue)
+    int colc[2];
 #pragma unroll
-        for (int i = 0; i < kBMax; ++i) {
-            const int idx = tid + i * 256;
-            r[i] = (f32x4){0, 0, 0, 0};
-            if (idx < b4_total) {
-                const int vr = idx / b4_per_row, c4 = idx - vr * b4_per_row;
-                const int v = s * kBKv + vr;
-                if (v < V) r[i] = *reinterpret_cast<const f32x4 *>(w + (size_t)v * J + c4 * 4);
-            }
-        }
-    };
-    auto store_b = [&](float *dst, const f32x4 (&r)[kBMax]) {
-#pragma unroll
-        for (int i = 0; i < kBMax; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < b4_total) {
-                const int vr = idx / b4_per_row, c4 = idx - vr * b4_per_row;
-                *reinterpret_cast<f32x4 *>(dst + (size_t)vr * JP + c4 * 4) = r[i];
-            }
-        }
-    };
-    if (J < JP) {                                       // zero the never-written pad columns of both buffers once
-        for (int idx = tid; idx < 2 * kBKv * (JP - J); idx += 256) {
-            const int vr = idx / (JP - J), c = J + idx - vr * (JP - J);
-            Bs[(size_t)vr * JP + c] = 0.f;
-        }
+    for (int c = 0; c < 2; ++c) {
+        const int col = wcol + 32 * c + l31;
+        colc[c] = col < J ? col : J - 1;
     }
+    auto load_b = [&](int s, float (&b)[2][kBKv / 2]) {
+#pragma unroll
+        for (int i = 0; i < kBKv / 2; ++i) {
+            int v = s * kBKv + 2 * i + half;
+            v = v < V ? v : V - 1;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) b[c][i] = w[(size_t)v * J + colc[c]];
+        }
+    };
+    auto mfma_slice = [&](int buf, const float (&b)[2][kBKv / 2]) {
+#pragma unroll
+        for (int i = 0; i < kBKv / 2; ++i) {
+            const float a0 = As[buf][2 * i + half][l31];
+            const float a1 = As[buf][2 * i + half][32 + l31];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[c][i], acc[0][c], 0, 0, 0);
+                acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[c][i], acc[1][c], 0, 0, 0);
+            }
+        }
+    };
 
+    float pb[2][kBKv / 2], qb[2][kBKv / 2];
     {
-        f32x4 ra; f32x4 rb[kBMax];
-        load_a(0, ra); load_b(0, rb);
-        store_a(As, ra); store_b(Bs, rb);
+        f32x4 ra;
+        load_a(0, ra);
+        load_b(0, pb);
+        store_a(0, ra);
     }
     __syncthreads();
-    for (int s = 0; s < nslices; ++s) {
-        const float *ca = As + (s & 1) * (kBKv * kHPad);
-        const float *cb = Bs + (size_t)(s & 1) * (kBKv * JP);
-        float *na = As + ((s + 1) & 1) * (kBKv * kHPad);
-        float *nb = Bs + (size_t)((s + 1) & 1) * (kBKv * JP);
-        f32x4 ra; f32x4 rb[kBMax];
-        const bool more = (s + 1 < nslices);
-        if (more) { load_a(s + 1, ra); load_b(s + 1, rb); }
-#pragma unroll
-        for (int kk = 0; kk < kBKv; kk += 2) {
-            const float a0 = ca[(kk + half) * kHPad + l31];
-            const float a1 = ca[(kk + half) * kHPad + 32 + l31];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const float b = cb[(size_t)(kk + half) * JP + wcol + j * 32 + l31];
-                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1][j], 0, 0, 0);
-            }
+    for (int s = 0; s < nslices; s += 2) {
+        // even slice: compute from (As[0], pb) while slice s+1 is loaded into (regs -> As[1], qb)
+        {
+            f32x4 ra;
+            const int sn = (s + 1 < nslices) ? s + 1 : s;
+            load_a(sn, ra);
+            load_b(sn, qb);
+            __builtin_amdgcn_sched_barrier(0);
+            if (wave_on) mfma_slice(0, pb);
+            __builtin_amdgcn_sched_barrier(0);
+            store_a(1, ra);
         }
-        if (more) { store_a(na, ra); store_b(nb, rb); }
+        __syncthreads();
+        if (s + 1 >= nslices) break;
+        {
+            f32x4 ra;
+            const int sn = (s + 2 < nslices) ? s + 2 : s + 1;
+            load_a(sn, ra);
+            load_b(sn, pb);
+            __builtin_amdgcn_sched_barrier(0);
+            if (wave_on) mfma_slice(1, qb);
+            __builtin_amdgcn_sched_barrier(0);
+            store_a(0, ra);
+        }
         __syncthreads();
     }
+    if (!wave_on) return;
     // epilogue: dZ = dH * (1 - H^2), H recomputed per element
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -302,11 +400,11 @@ __global__ __launch_bounds__(256) void joint_bwd_dz_kernel(
             const float *__restrict__ e = ep + (size_t)bt * J;
             const float *__restrict__ p = pp + ((size_t)b * U1 + u) * J;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int k = wcol + j * 32 + l31;
+            for (int c = 0; c < 2; ++c) {
+                const int k = wcol + c * 32 + l31;
                 if (k >= J) continue;
                 const float h = tanhf(e[k] + p[k]);
-                const float g = valid ? acc[i][j][r] * (1.f - h * h) : 0.f;
+                const float g = valid ? acc[i][c][r] * (1.f - h * h) : 0.f;
                 dz[(size_t)m * J + k] = g;
                 if (hout) hout[(size_t)m * J + k] = valid ? h : 0.f;
             }
@@ -354,8 +452,21 @@ extern "C" int wr_joint_fwd(const float *ep_d, const float *pp_d, const float *w
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lds);
     const long M = (long)B * T * U1;
-    hipLaunchKernelGGL(joint_fwd_kernel, dim3((unsigned)((M + kBM - 1) / kBM)), dim3(256), lds, st, ep_d, pp_d, wt,
-                       b_out_d, logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, out_d);
+    const int variant = tune_get(kTuneJointFwdVariant);
+    if (variant == 0) {
+        hipLaunchKernelGGL(joint_fwd_kernel, dim3((unsigned)((M + kBM - 1) / kBM)), dim3(256), lds, st, ep_d, pp_d, wt,
+                           b_out_d, logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, out_d);
+    } else {
+        const size_t lds2 = (size_t)Jp * kHPad * sizeof(float);
+#define WR_LAUNCH_FWD2(PFK, CT)                                                                                      \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_fwd_direct_kernel<PFK, CT>),                    \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);                              \
+        hipLaunchKernelGGL((joint_fwd_direct_kernel<PFK, CT>), dim3((unsigned)((M + kBM - 1) / kBM)),                  \
+                           dim3(CT == 2 ? 256 : 512), lds2, st, ep_d, pp_d, wt, b_out_d, logit_lengths_d,              \
+                           target_lengths_d, B, T, U1, J, Jp, V, Vp, out_d)
+        if (variant == 2) { WR_LAUNCH_FWD2(8, 1); } else { WR_LAUNCH_FWD2(8, 2); }
+#undef WR_LAUNCH_FWD2
+    }
     WR_CHECK_LAUNCH("joint_fwd_kernel");
     return WR_OK;
 }
@@ -371,20 +482,8 @@ extern "C" int wr_joint_bwd_dz(const float *gout_d, const float *ep_d, const flo
     hipStream_t st = static_cast<hipStream_t>(stream);
     const long M = (long)B * T * U1;
     const dim3 grid((unsigned)((M + kBM - 1) / kBM));
-    const int NTr = (J + 127) / 128;
-    const size_t lds = (2 * kBKv * kHPad + 2 * (size_t)kBKv * NTr * 128) * sizeof(float);
-#define WR_LAUNCH_DZ(NT)                                                                                         \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_bwd_dz_kernel<NT>),                                  \
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                    \
-    hipLaunchKernelGGL((joint_bwd_dz_kernel<NT>), grid, dim3(256), lds, st, gout_d, ep_d, pp_d, w_out_d,          \
-                       logit_lengths_d, target_lengths_d, B, T, U1, J, V, dz_d, h_d)
-    switch (NTr) {
-        case 1: WR_LAUNCH_DZ(1); break;
-        case 2: WR_LAUNCH_DZ(2); break;
-        case 3: WR_LAUNCH_DZ(3); break;
-        default: WR_LAUNCH_DZ(4); break;
-    }
-#undef WR_LAUNCH_DZ
+    hipLaunchKernelGGL(joint_bwd_dz_kernel, grid, dim3(64 * kBwdWaves), 0, st, gout_d, ep_d, pp_d, w_out_d,
+                       logit_lengths_d, target_lengths_d, B, T, U1, J, V, dz_d, h_d);
     WR_CHECK_LAUNCH("joint_bwd_dz_kernel");
     return WR_OK;
 }
