@@ -9,13 +9,12 @@
 //           writes denom(b,t) and the log-probs the lattice needs --
 //           lp_blank(b,t) and lp_label(b,t,i) for the S_b labels -- (S+1 values
 //           instead of 2S+1: every even state of the extended sequence is blank).
-//   pass 2  ctc_sweep_kernel  one wave per (utterance, direction); lane l owns
-//           KS = ceil((2*Smax+1)/64) adjacent states of the extended label
-//           sequence.  alpha_t(s) depends on alpha_{t-1}(s, s-1, s-2): the two
-//           values that cross a lane boundary come from the left neighbour by
-//           DPP wave shifts (no LDS, no barrier).  State in fp64, the bounded
-//           log-sum-exp correction in fp32 (same precision argument as the
-//           RNN-T sweep).  Latency-bound: T dependent steps.
+//   pass 2  ctc_sweep_kernel  one workgroup per (utterance, direction), one lane per
+//           state of the extended label sequence (ceil((2*Smax+1)/64) waves).
+//           alpha_t(s) depends on alpha_{t-1}(s, s-1, s-2): the previous frame's
+//           states sit in a double-buffered LDS array; one barrier per frame.
+//           State in fp64, the bounded log-sum-exp correction in fp32 (same
+//           precision argument as the RNN-T sweep).  Latency-bound: T dependent steps.
 //   pass 3  ctc_grad_kernel   one workgroup per frame: softmax row into LDS,
 //           subtract the state occupancies exp(alpha+beta+nll-lp) with LDS float
 //           atomics (repeated labels and the S+1 blank states collide), write the
@@ -30,7 +29,7 @@ namespace {
 struct CtcWs {
     int KS;           // extended-label states per lane
     int SP;           // 2*Smax+1
-    size_t denom_off, lpb_off, lpl_off, alpha_off, beta_off, nll_off, total;
+    size_t denom_off, lpb_off, lpl_off, alpha_off, beta_off, nll_off, dump_off, total;
 };
 
 inline CtcWs ctc_ws_layout(int B, int Tmax, int Smax)
@@ -46,6 +45,7 @@ inline CtcWs ctc_ws_layout(int B, int Tmax, int Smax)
     w.alpha_off = off; off = align_up(off + frames * w.SP * sizeof(double), 256);
     w.beta_off = off;  off = align_up(off + frames * w.SP * sizeof(double), 256);
     w.nll_off = off;   off = align_up(off + (size_t)B * sizeof(double), 256);
+    w.dump_off = off;  off = align_up(off + (size_t)B * 2 * 512 * sizeof(double), 256);
     w.total = off;
     return w;
 }
@@ -122,185 +122,123 @@ __device__ __forceinline__ double lse3_d(double a, double b, double c)
     return (m == (double)kNegInf) ? (double)kNegInf : m + (double)r;
 }
 
-__device__ __forceinline__ double dpp_up_d(double v, double fill)
-{
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), 0x138, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), 0x138, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double dpp_down_d(double v, double fill)
-{
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), 0x130, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), 0x130, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-
-// KS states per lane.  State s: even -> blank, odd -> label (s-1)/2.
-template <int KS, int PF>
-__global__ __launch_bounds__(64) void ctc_sweep_kernel(
+// One workgroup per (utterance, direction), one lane per state of the extended label sequence
+// (NW = ceil((2*Smax+1)/64) waves).  alpha_t(s) depends on alpha_{t-1}(s), (s-1), (s-2) only, so the previous
+// frame's states live in a double-buffered LDS array and a step is: three LDS reads, one fp64/fp32 log-sum-exp,
+// one LDS write, one s_barrier.  Log-prob rows are prefetched PF frames ahead with unconditional (clamped) loads;
+// idle lanes store to a sink so the loop body is straight-line.
+template <int PF>
+__global__ __launch_bounds__(512) void ctc_sweep_kernel(
     const float *__restrict__ lp_blank, const float *__restrict__ lp_label,
     const int32_t *__restrict__ targets, const int32_t *__restrict__ ilens,
     const int32_t *__restrict__ tlens, int Tmax, int Smax, int SP,
     double *__restrict__ alpha, double *__restrict__ beta, double *__restrict__ nll_ws,
-    float *__restrict__ nll_out)
+    float *__restrict__ nll_out, double *__restrict__ dump)
 {
     constexpr double NEG = (double)kNegInf;
+    __shared__ double prev[2][512 + 4];            // states shifted by 2; two NEG guard cells on each side
     const int b = blockIdx.x;
     const bool backward = blockIdx.y != 0;
-    const int lane = threadIdx.x;
+    const int s = threadIdx.x;                     // state index
     int T = ilens[b], S = tlens[b];
     T = T < 0 ? 0 : (T > Tmax ? Tmax : T);
     S = S < 0 ? 0 : (S > Smax ? Smax : S);
-    const int NS = 2 * S + 1;                 // states of this utterance
-    const int s0 = lane * KS;
+    const int NS = 2 * S + 1;                      // states of this utterance
     const float *__restrict__ lpb = lp_blank + (size_t)b * Tmax;
     const float *__restrict__ lpl = lp_label + (size_t)b * Tmax * Smax;
     double *__restrict__ out = (backward ? beta : alpha) + (size_t)b * Tmax * SP;
+    double *__restrict__ sink = dump + ((size_t)b * 2 + (backward ? 1 : 0)) * 512 + s;
 
     if (T == 0) {
         // no frames: feasible only for the empty target (ATen: nll = 0 if S == 0 else inf)
-        if (lane == 0 && backward) {
+        if (s == 0 && backward) {
             const double v = (S == 0) ? 0.0 : (double)__builtin_huge_valf();
             nll_ws[b] = v;
             nll_out[b] = (float)v;
         }
         return;
     }
-
-    // per-state constants: the label of each owned state and whether the s-2 (fwd) / s+2 (bwd) skip is allowed
-    int lab_idx[KS];      // index into lp_label row, -1 for blank / out of range
-    bool skip_ok[KS];
-#pragma unroll
-    for (int j = 0; j < KS; ++j) {
-        const int s = s0 + j;
-        lab_idx[j] = -1;
-        skip_ok[j] = false;
-        if (s < NS && (s & 1)) {
-            const int i = s >> 1;
-            lab_idx[j] = i;
-            const int me = targets[(size_t)b * Smax + i];
-            if (!backward) {
-                if (i >= 1) skip_ok[j] = (me != targets[(size_t)b * Smax + i - 1]);
-            } else {
-                if (i + 1 < S) skip_ok[j] = (me != targets[(size_t)b * Smax + i + 1]);
-            }
-        }
+    const bool live = s < NS;
+    // per-state constants: which log-prob this state reads and whether the s-2 (fwd) / s+2 (bwd) skip is allowed
+    const bool is_label = live && (s & 1);
+    const int li = is_label ? (s >> 1) : 0;
+    bool skip_ok = false;
+    if (is_label) {
+        const int me = targets[(size_t)b * Smax + li];
+        if (!backward) { if (li >= 1) skip_ok = (me != targets[(size_t)b * Smax + li - 1]); }
+        else { if (li + 1 < S) skip_ok = (me != targets[(size_t)b * Smax + li + 1]); }
     }
-
-    auto load_lp = [&](int t, float (&dst)[KS]) {
-        const bool ok = (t >= 0) & (t < T);
-        const float lb = ok ? lpb[t] : 0.f;
-#pragma unroll
-        for (int j = 0; j < KS; ++j) {
-            float v = lb;
-            if (lab_idx[j] >= 0) v = ok ? lpl[(size_t)t * Smax + lab_idx[j]] : 0.f;
-            dst[j] = v;
-        }
+    auto load_lp = [&](int t) -> float {
+        const int tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        const float lb = lpb[tc];
+        const float ll = lpl[(size_t)tc * Smax + li];
+        return is_label ? ll : lb;
     };
+    for (int i = threadIdx.x; i < 2 * (512 + 4); i += blockDim.x) (&prev[0][0])[i] = NEG;
+    __syncthreads();
 
-    float ring[PF][KS];
-    double st[KS];
-#pragma unroll
-    for (int j = 0; j < KS; ++j) st[j] = NEG;
-
+    float ring[PF];
+    int cur = 0;
     if (!backward) {
         // t = 0: alpha_0(0) = lp(0,blank), alpha_0(1) = lp(0,y_1)
-        float lp0[KS];
-        load_lp(0, lp0);
-#pragma unroll
-        for (int j = 0; j < KS; ++j) {
-            const int s = s0 + j;
-            st[j] = (s < NS && s <= 1) ? (double)lp0[j] : NEG;
-            if (s < NS) out[s] = st[j];
+        {
+            const double v = (live && s <= 1) ? (double)load_lp(0) : NEG;
+            prev[0][s + 2] = v;
+            *(live ? out + s : sink) = v;
         }
 #pragma unroll
-        for (int i = 0; i < PF; ++i) load_lp(1 + i, ring[i]);
+        for (int i = 0; i < PF; ++i) ring[i] = load_lp(1 + i);
+        __syncthreads();
         for (int base = 1; base < T; base += PF) {
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
-                const int t = base + i;
-                float cur[KS];
-#pragma unroll
-                for (int j = 0; j < KS; ++j) cur[j] = ring[i][j];
-                load_lp(t + PF, ring[i]);
-                if (t < T) {
-                    // neighbours' last two states of the previous frame
-                    const double l1 = dpp_up_d(st[KS - 1], NEG);                       // state s0-1
-                    const double l2 = (KS >= 2) ? dpp_up_d(st[KS >= 2 ? KS - 2 : 0], NEG)  // state s0-2
-                                                : dpp_up_d(l1, NEG);
-                    double nw[KS];
-#pragma unroll
-                    for (int j = 0; j < KS; ++j) {
-                        const int s = s0 + j;
-                        const double a0 = st[j];
-                        const double a1 = (j >= 1) ? st[j >= 1 ? j - 1 : 0] : l1;
-                        double a2 = (j >= 2) ? st[j >= 2 ? j - 2 : 0] : (j == 1 ? l1 : l2);
-                        a2 = skip_ok[j] ? a2 : NEG;
-                        double v = lse3_d(a0, a1, a2);
-                        v = (v == NEG) ? NEG : v + (double)cur[j];
-                        nw[j] = (s < NS) ? v : NEG;
-                    }
-#pragma unroll
-                    for (int j = 0; j < KS; ++j) {
-                        st[j] = nw[j];
-                        if (s0 + j < NS) out[(size_t)t * SP + s0 + j] = nw[j];
-                    }
-                }
+                const int t = base + i;             // frames t >= T only rewrite the guard-free LDS copy; no global effect
+                const float lp = ring[i];
+                ring[i] = load_lp(t + PF);
+                const double a0 = prev[cur][s + 2];
+                const double a1 = prev[cur][s + 1];
+                const double a2 = skip_ok ? prev[cur][s] : NEG;
+                double v = lse3_d(a0, a1, a2);
+                v = (v == NEG) ? NEG : v + (double)lp;
+                v = live ? v : NEG;
+                const bool on = live && (t < T);
+                if (t < T) prev[cur ^ 1][s + 2] = v;
+                *(on ? out + (size_t)t * SP + s : sink) = v;
+                if (t < T) cur ^= 1;
+                __syncthreads();
             }
         }
     } else {
-        float lpT[KS];
-        load_lp(T - 1, lpT);
-#pragma unroll
-        for (int j = 0; j < KS; ++j) {
-            const int s = s0 + j;
-            st[j] = (s < NS && s >= NS - 2) ? (double)lpT[j] : NEG;
-            if (s < NS) out[(size_t)(T - 1) * SP + s] = st[j];
+        {
+            const double v = (live && s >= NS - 2) ? (double)load_lp(T - 1) : NEG;
+            prev[0][s + 2] = v;
+            *(live ? out + (size_t)(T - 1) * SP + s : sink) = v;
         }
 #pragma unroll
-        for (int i = 0; i < PF; ++i) load_lp(T - 2 - i, ring[i]);
+        for (int i = 0; i < PF; ++i) ring[i] = load_lp(T - 2 - i);
+        __syncthreads();
         for (int base = 0; base < T - 1; base += PF) {
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const int t = T - 2 - (base + i);
-                float cur[KS];
-#pragma unroll
-                for (int j = 0; j < KS; ++j) cur[j] = ring[i][j];
-                load_lp(t - PF, ring[i]);
-                if (t >= 0) {
-                    const double r1 = dpp_down_d(st[0], NEG);                          // state s0+KS
-                    const double r2 = (KS >= 2) ? dpp_down_d(st[KS >= 2 ? 1 : 0], NEG)    // state s0+KS+1
-                                                : dpp_down_d(r1, NEG);
-                    double nw[KS];
-#pragma unroll
-                    for (int j = 0; j < KS; ++j) {
-                        const int s = s0 + j;
-                        const double a0 = st[j];
-                        const double a1 = (j + 1 < KS) ? st[j + 1 < KS ? j + 1 : KS - 1] : r1;
-                        double a2;
-                        if (j + 2 < KS) a2 = st[j + 2 < KS ? j + 2 : KS - 1];
-                        else if (j + 2 == KS) a2 = r1;
-                        else a2 = r2;
-                        a2 = skip_ok[j] ? a2 : NEG;
-                        double v = lse3_d(a0, a1, a2);
-                        v = (v == NEG) ? NEG : v + (double)cur[j];
-                        nw[j] = (s < NS) ? v : NEG;
-                    }
-#pragma unroll
-                    for (int j = 0; j < KS; ++j) {
-                        st[j] = nw[j];
-                        if (s0 + j < NS) out[(size_t)t * SP + s0 + j] = nw[j];
-                    }
-                }
+                const float lp = ring[i];
+                ring[i] = load_lp(t - PF);
+                const double a0 = prev[cur][s + 2];
+                const double a1 = prev[cur][s + 3];
+                const double a2 = skip_ok ? prev[cur][s + 4] : NEG;
+                double v = lse3_d(a0, a1, a2);
+                v = (v == NEG) ? NEG : v + (double)lp;
+                v = live ? v : NEG;
+                const bool on = live && (t >= 0);
+                if (t >= 0) prev[cur ^ 1][s + 2] = v;
+                *(on ? out + (size_t)(t < 0 ? 0 : t) * SP + s : sink) = v;
+                if (t >= 0) cur ^= 1;
+                __syncthreads();
             }
         }
         // nll = -logsumexp(beta_0(0), beta_0(1))
-        const double b0 = __shfl(st[0], 0, kWave);
-        double b1 = NEG;
-        if (NS > 1) b1 = (KS >= 2) ? __shfl(st[KS >= 2 ? 1 : 0], 0, kWave) : __shfl(st[0], 1, kWave);
-        if (lane == 0) {
-            const double ll = lse3_d(b0, b1, NEG);
+        if (s == 0) {
+            const double ll = lse3_d(prev[cur][2], NS > 1 ? prev[cur][3] : NEG, NEG);
             nll_ws[b] = -ll;
             nll_out[b] = (float)(-ll);
         }
@@ -366,16 +304,14 @@ int ctc_check(int B, int Tmax, int Smax, int V, int blank)
     return WR_OK;
 }
 
-template <int KS>
 void launch_ctc_sweep(const CtcWs &w, char *ws, const int32_t *targets, const int32_t *ilens, const int32_t *tlens,
                       int B, int Tmax, int Smax, float *nll, hipStream_t st)
 {
-    constexpr int PF = (KS <= 2) ? 8 : (KS <= 5 ? 6 : 4);
-    hipLaunchKernelGGL((ctc_sweep_kernel<KS, PF>), dim3(B, 2), dim3(64), 0, st,
+    hipLaunchKernelGGL((ctc_sweep_kernel<8>), dim3(B, 2), dim3(64 * w.KS), 0, st,
                        reinterpret_cast<const float *>(ws + w.lpb_off), reinterpret_cast<const float *>(ws + w.lpl_off),
                        targets, ilens, tlens, Tmax, Smax > 0 ? Smax : 1, w.SP,
                        reinterpret_cast<double *>(ws + w.alpha_off), reinterpret_cast<double *>(ws + w.beta_off),
-                       reinterpret_cast<double *>(ws + w.nll_off), nll);
+                       reinterpret_cast<double *>(ws + w.nll_off), nll, reinterpret_cast<double *>(ws + w.dump_off));
 }
 
 }  // namespace
@@ -413,16 +349,7 @@ extern "C" int wr_ctc_loss_fwd(const void *logits_d, int dtype, const int32_t *t
                        reinterpret_cast<float *>(ws + w.denom_off), reinterpret_cast<float *>(ws + w.lpb_off),
                        reinterpret_cast<float *>(ws + w.lpl_off));
     WR_CHECK_LAUNCH("ctc_lse_kernel");
-    switch (w.KS) {
-        case 1: launch_ctc_sweep<1>(w, ws, targets_d, input_lengths_d, target_lengths_d, B, Tmax, Smax, nll_d, st); break;
-        case 2: launch_ctc_sweep<2>(w, ws, targets_d, input_lengths_d, target_lengths_d, B, Tmax, Smax, nll_d, st); break;
-        case 3: launch_ctc_sweep<3>(w, ws, targets_d, input_lengths_d, target_lengths_d, B, Tmax, Smax, nll_d, st); break;
-        case 4: launch_ctc_sweep<4>(w, ws, targets_d, input_lengths_d, target_lengths_d, B, Tmax, Smax, nll_d, st); break;
-        case 5: launch_ctc_sweep<5>(w, ws, targets_d, input_lengths_d, target_lengths_d, B, Tmax, Smax, nll_d, st); break;
-        case 6: launch_ctc_sweep<6>(w, ws, targets_d, input_lengths_d, target_lengths_d, B, Tmax, Smax, nll_d, st); break;
-        case 7: launch_ctc_sweep<7>(w, ws, targets_d, input_lengths_d, target_lengths_d, B, Tmax, Smax, nll_d, st); break;
-        default: launch_ctc_sweep<8>(w, ws, targets_d, input_lengths_d, target_lengths_d, B, Tmax, Smax, nll_d, st); break;
-    }
+    launch_ctc_sweep(w, ws, targets_d, input_lengths_d, target_lengths_d, B, Tmax, Smax, nll_d, st);
     WR_CHECK_LAUNCH("ctc_sweep_kernel");
     return WR_OK;
 }
