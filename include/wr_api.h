@@ -228,6 +228,18 @@ int wr_decoder_set_graph(wr_decoder *h, int enable /* 0: plain launches instead 
 int wr_greedy_search(wr_decoder *h, const float *enc_out_d, const int32_t *enc_lens_d, int N, int T,
                      int n_steps, int blank, int32_t *hyps_d, int32_t *hyp_lens_d, void *stream);
 
+/* Streaming (chunk-synchronous) greedy search: the stateful reset_cache() / forward_greedy_search(chunk)
+ * pair that the reference's C++ runtime drives ("wenet/transducer/transducer ref.py":541-606, consumed at
+ * runtime/core/decoder/torch_asr_model.cc:126,313).  reset != 0 starts N fresh streams; otherwise the
+ * predictor cache, last token, "predictor must step" flag, per-frame emission counter and predictor
+ * output of every stream carry over from the previous call.  hyps/hyp_lens receive the tokens emitted in
+ * THIS chunk.  reference_new_cache != 0 reproduces the reference's `new_cache = self.cache` at the top of
+ * each chunk (the not-yet-committed predictor state of the previous chunk is dropped); 0 keeps it, which
+ * makes chunked decoding identical to decoding the concatenated frames with wr_greedy_search. */
+int wr_greedy_search_chunk(wr_decoder *h, const float *enc_chunk_d, const int32_t *chunk_lens_d, int N, int T,
+                           int n_steps, int blank, int reset, int reference_new_cache, int32_t *hyps_d,
+                           int32_t *hyp_lens_d, void *stream);
+
 /* enc_out [B, T, E], ctc_logp [B, T, V] = log_softmax(ctc_lo(enc_out)) (ctc.py:66-75).
  * Out: hyps [B, beam, Tmax+1] (each begins with the seed blank, padded with -1), hyp_lens [B, beam],
  * scores [B, beam] float64 (best first), n_hyps [B]. */

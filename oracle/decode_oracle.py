@@ -134,6 +134,50 @@ def greedy_search(pred: Predictor, joint: Joint, enc, T, blank=0, n_steps=64, re
     return (hyps, min_margin) if return_margin else hyps
 
 
+class StreamingGreedy:
+    """reset_cache / forward_greedy_search of "wenet/transducer/transducer ref.py":541-606 for one stream.
+    That file cannot be imported here (it pulls in k2 and torchaudio at module level), so this restatement
+    has no reference-produced fixture: PARITY UNPINNED for the streaming export; it is checked against the
+    pinned offline greedy loop instead (a chunked decode with `reference_new_cache=False` must equal the
+    offline decode of the concatenated frames).  `reference_new_cache=True` keeps the reference's
+    `new_cache = self.cache` at the top of every chunk (:571)."""
+
+    def __init__(self, pred: Predictor, joint: Joint, blank=0):
+        self.pred, self.joint, self.blank = pred, joint, blank
+        self.reset_cache()
+
+    def reset_cache(self):
+        self.cache = self.pred.init_state(1)
+        self.pending = self.cache
+        self.out = None
+        self.tok = np.array([self.blank])
+        self.per_frame = 0
+        self.prev_nblk = True
+
+    def forward_greedy_search(self, enc, T, n_steps=64, reference_new_cache=True):
+        padding = np.zeros((1, 1), F)
+        new_cache = self.cache if reference_new_cache else self.pending
+        hyps, t = [], 0
+        while t < T:
+            if self.prev_nblk:
+                self.out, new_cache = self.pred.forward_step(self.tok, padding, self.cache)
+            lp = log_softmax(self.joint(enc[t][None, :], self.out))[0]
+            k = int(lp.argmax())
+            if k != self.blank:
+                hyps.append(k)
+                self.prev_nblk = True
+                self.per_frame += 1
+                self.tok = np.array([k])
+                self.cache = new_cache
+            if k == self.blank or self.per_frame >= n_steps:
+                if k == self.blank:
+                    self.prev_nblk = False
+                t += 1
+                self.per_frame = 0
+        self.pending = new_cache
+        return hyps
+
+
 def ctc_log_softmax(w, enc):
     """ctc.py:66-75: log_softmax(ctc_lo(hs)).  enc (T,E) -> (T,V)"""
     return log_softmax(enc @ np.asarray(w["ctc_lo.weight"], F).T + np.asarray(w["ctc_lo.bias"], F))

@@ -180,3 +180,41 @@ def test_config3_shape_streams_match_oracle():
             compared += 1
     assert compared >= 8
     assert sum(len(h) for h in hyps) > N         # something was emitted
+
+
+def test_streaming_chunks_equal_offline_and_reference_quirk():
+    """Chunk-synchronous greedy ("transducer ref.py":541-606): with the pending predictor state kept, decoding
+    chunk by chunk equals decoding the concatenated frames; with `reference_new_cache=True` it equals the
+    restated reference loop (which resets new_cache to the committed cache at every chunk start)."""
+    import wenet_celoss_amd as w
+    d = np.load(names("greedy_core_1.npz")[0])
+    pred, joint, _ = build_modules(d)
+    m = w.Transducer(64, 0, torch.nn.Identity(), pred, joint, ctc_weight=0.0, transducer_weight=1.0, hw_weight=0.0)
+    enc = torch.tensor(d["enc"], device=DEV)                # (1, 60, 16)
+    T, n_steps = int(d["T"]), int(d["n_steps"])
+    chunks = [(0, 16), (16, 32), (32, 37), (37, 60)]
+    m.reset_cache(1, chunk_frames=32, n_steps=n_steps)
+    got = []
+    for a, b in chunks:
+        got += m.forward_greedy_search(enc[:, a:b].contiguous(), torch.tensor([b - a]), n_steps=n_steps,
+                                       reference_new_cache=False)
+    assert got == list(d["hyp"])                            # == the reference's offline tokens for the whole utterance
+    p = do.Predictor(sub(d, "pred_"), int(d["n_layers"])); j = do.Joint(sub(d, "joint_"))
+    for quirk in (True, False):
+        ref = do.StreamingGreedy(p, j)
+        m.reset_cache(1, chunk_frames=32, n_steps=n_steps)
+        for a, b in chunks:
+            r = ref.forward_greedy_search(d["enc"][0, a:b], b - a, n_steps=n_steps, reference_new_cache=quirk)
+            g = m.forward_greedy_search(enc[:, a:b].contiguous(), torch.tensor([b - a]), n_steps=n_steps,
+                                        reference_new_cache=quirk)
+            assert g == r, (quirk, a, b)
+    # several streams at once, different chunk lengths per stream
+    m.reset_cache(3, chunk_frames=32, n_steps=n_steps)
+    encs = torch.cat([enc, enc.flip(1), enc * 0.5], 0)
+    outs = [[], [], []]
+    for a, b in chunks:
+        lens = torch.tensor([b - a, max(b - a - 3, 1), b - a])
+        res = m.forward_greedy_search(encs[:, a:b].contiguous(), lens, n_steps=n_steps, reference_new_cache=False)
+        for i in range(3):
+            outs[i] += res[i]
+    assert outs[0] == list(d["hyp"])

@@ -308,6 +308,31 @@ __global__ void greedy_init_kernel(DevState *s)
     }
 }
 
+// Streaming: start the next chunk of every stream with the state the previous chunk left behind
+// (reset_cache / forward_greedy_search of "transducer ref.py":541-606).  `ref_new_cache` reproduces the
+// reference's `new_cache = self.cache` at the top of each chunk (the not-yet-committed predictor state of the
+// previous chunk is dropped); 0 keeps it, so that chunked decoding equals decoding the concatenation.
+__global__ void greedy_chunk_init_kernel(DevState *s, int ref_new_cache)
+{
+    const Dims &d = s->d;
+    const int n = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (ref_new_cache)
+        for (int i = tid; i < d.L * d.Hp; i += blockDim.x) {
+            const size_t o = (size_t)i * d.NLp + n;
+            s->new_hT[o] = s->cache_hT[o];
+            s->new_cT[o] = s->cache_cT[o];
+        }
+    if (tid == 0) {
+        const int T = s->enc_lens[n] < s->T ? s->enc_lens[n] : s->T;
+        s->lane_t[n] = 0;
+        s->hyp_lens[n] = 0;
+        const int act = T > 0;
+        s->lane_active[n] = act;
+        if (act) atomicAdd(s->active_count, 1);
+    }
+}
+
 // block-wide argmax with "first index on ties"
 __device__ __forceinline__ void block_argmax(float &val, int &idx, float *sv, int *si)
 {
@@ -670,6 +695,7 @@ struct wr_decoder {
     hipGraphExec_t greedy_graph;
     hipGraphExec_t beam_graph;
     int greedy_graph_lanes, beam_graph_lanes;
+    int stream_lanes;             // lanes whose streaming state (cache, token, flags) is live; -1: none
     bool use_graph;
 };
 
@@ -862,6 +888,7 @@ extern "C" int wr_decoder_create(const wr_transducer_weights *w, int max_lanes, 
     h->max_utt = max_utt; h->Tmax = Tmax; h->max_hyp = max_hyp; h->max_beam = max_beam;
     h->greedy_graph = nullptr; h->beam_graph = nullptr; h->greedy_graph_lanes = h->beam_graph_lanes = -1;
     h->use_graph = true;
+    h->stream_lanes = -1;
     h->h_active = nullptr;
     if (hipHostMalloc(reinterpret_cast<void **>(&h->h_active), 64, hipHostMallocDefault) != hipSuccess) {
         delete h;
@@ -981,13 +1008,17 @@ int capture(hipStream_t st, int reps, F body, hipGraphExec_t *out)
 
 }  // namespace
 
-extern "C" int wr_greedy_search(wr_decoder *h, const float *enc_out_d, const int32_t *enc_lens_d, int N, int T, int n_steps,
-                                int blank, int32_t *hyps_d, int32_t *hyp_lens_d, void *stream)
+namespace {
+// mode 0: fresh utterances; 1: next chunk, keep the pending predictor state; 2: next chunk, reference quirk
+int greedy_run(wr_decoder *h, const float *enc_out_d, const int32_t *enc_lens_d, int N, int T, int n_steps, int blank,
+               int32_t *hyps_d, int32_t *hyp_lens_d, void *stream, int mode)
 {
     WR_REQUIRE(h && enc_out_d && enc_lens_d && hyps_d && hyp_lens_d, WR_EINVAL, "greedy_search: null pointer argument");
     WR_REQUIRE(N > 0 && N <= h->d.NL && N <= h->max_utt, WR_EINVAL, "greedy_search: N=%d exceeds the decoder's capacity", N);
     WR_REQUIRE(T > 0 && T <= h->Tmax, WR_EINVAL, "greedy_search: T=%d exceeds the decoder's Tmax=%d", T, h->Tmax);
     WR_REQUIRE(n_steps >= 1 && blank >= 0 && blank < h->d.V, WR_EINVAL, "greedy_search: bad n_steps/blank");
+    WR_REQUIRE(mode == 0 || h->stream_lanes == N, WR_EINVAL,
+               "greedy_search_chunk: no stream state for %d lanes (call with reset first)", N);
     hipStream_t caller = static_cast<hipStream_t>(stream);
     hipStream_t st = enter(h, caller);
     DevState &s = h->host;
@@ -999,8 +1030,10 @@ extern "C" int wr_greedy_search(wr_decoder *h, const float *enc_out_d, const int
     (void)hipMemsetAsync(s.lane_active, 0, sizeof(int32_t) * h->d.NLp, st);
     hipLaunchKernelGGL(ep_all_kernel, dim3((unsigned)(((long)N * T + 7) / 8)), dim3(256), (size_t)8 * h->d.E * sizeof(float), st,
                        h->dev);
-    hipLaunchKernelGGL(greedy_init_kernel, dim3(N), dim3(128), 0, st, h->dev);
+    if (mode == 0) hipLaunchKernelGGL(greedy_init_kernel, dim3(N), dim3(128), 0, st, h->dev);
+    else hipLaunchKernelGGL(greedy_chunk_init_kernel, dim3(N), dim3(128), 0, st, h->dev, mode == 2 ? 1 : 0);
     WR_CHECK_LAUNCH("greedy_init");
+    h->stream_lanes = N;
     if (h->use_graph && h->greedy_graph_lanes != N) {
         if (h->greedy_graph) { (void)hipGraphExecDestroy(h->greedy_graph); h->greedy_graph = nullptr; }
         if (int rc = capture(st, kStepsPerGraph, [&] { greedy_micro_step(h, N, st); }, &h->greedy_graph)) return rc;
@@ -1023,6 +1056,21 @@ extern "C" int wr_greedy_search(wr_decoder *h, const float *enc_out_d, const int
     leave(h, caller);
     WR_CHECK_LAUNCH("greedy_search");
     return WR_OK;
+}
+}  // namespace
+
+extern "C" int wr_greedy_search(wr_decoder *h, const float *enc_out_d, const int32_t *enc_lens_d, int N, int T, int n_steps,
+                                int blank, int32_t *hyps_d, int32_t *hyp_lens_d, void *stream)
+{
+    return greedy_run(h, enc_out_d, enc_lens_d, N, T, n_steps, blank, hyps_d, hyp_lens_d, stream, 0);
+}
+
+extern "C" int wr_greedy_search_chunk(wr_decoder *h, const float *enc_chunk_d, const int32_t *chunk_lens_d, int N, int T,
+                                      int n_steps, int blank, int reset, int reference_new_cache, int32_t *hyps_d,
+                                      int32_t *hyp_lens_d, void *stream)
+{
+    return greedy_run(h, enc_chunk_d, chunk_lens_d, N, T, n_steps, blank, hyps_d, hyp_lens_d, stream,
+                      reset ? 0 : (reference_new_cache ? 2 : 1));
 }
 
 extern "C" int wr_prefix_beam_search(wr_decoder *h, const float *enc_out_d, const int32_t *enc_lens_d,

@@ -104,6 +104,24 @@ class DeviceDecoder:
             raise RuntimeError(f"greedy search produced {max(hl_c)} tokens but the decoder was sized for {self.max_hyp}")
         return [hy_c[i, :hl_c[i]].tolist() for i in range(N)]
 
+    def greedy_chunk(self, encoder_chunk: torch.Tensor, chunk_lens: torch.Tensor, n_steps: int = 64, blank: int = 0,
+                     reset: bool = False, reference_new_cache: bool = True) -> List[List[int]]:
+        """Streaming greedy search: tokens emitted in this chunk for each stream (state carries over)."""
+        enc = _f32(encoder_chunk)
+        N, T, _ = enc.shape
+        lens = chunk_lens.to(device=self.device, dtype=torch.int32).reshape(-1).contiguous()
+        hyps = torch.empty(N, max(self.max_hyp, 1), dtype=torch.int32, device=self.device)
+        hl = torch.empty(N, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self._lib.wr_greedy_search_chunk(self._h, _lib.ptr(enc), _lib.ptr(lens), N, T, int(n_steps), int(blank),
+                                                  int(reset), int(reference_new_cache), _lib.ptr(hyps), _lib.ptr(hl),
+                                                  _lib.current_stream(self.device))
+        _lib.check(rc, "wr_greedy_search_chunk")
+        hl_c, hy_c = hl.cpu().tolist(), hyps.cpu()
+        if max(hl_c, default=0) > self.max_hyp:
+            raise RuntimeError(f"greedy search produced {max(hl_c)} tokens but the decoder was sized for {self.max_hyp}")
+        return [hy_c[i, :hl_c[i]].tolist() for i in range(N)]
+
     def prefix_beam(self, encoder_out: torch.Tensor, encoder_out_lens: torch.Tensor, ctc_logp: torch.Tensor,
                     beam_size: int, ctc_weight: float, transducer_weight: float, blank: int = 0
                     ) -> List[List[Tuple[List[int], float]]]:

@@ -278,6 +278,35 @@ class Transducer(nn.Module):
         encoder_out, encoder_mask = self.encoder(speech, speech_lengths, decoding_chunk_size, num_decoding_left_chunks)
         return basic_greedy_search(self, encoder_out, encoder_mask.squeeze(1).sum(1), n_steps=n_steps)
 
+    # ------------------------------------- streaming greedy ("transducer ref.py":541-606) --
+    def reset_cache(self, n_streams: int = 1, chunk_frames: int = 64, n_steps: int = 64) -> None:
+        """Start `n_streams` fresh streams (the reference's reset_cache is the n_streams=1 case)."""
+        self._stream = dict(n=n_streams, fresh=True, tmax=chunk_frames, n_steps=n_steps)
+
+    def forward_greedy_search(self, encoder_out: torch.Tensor, encoder_out_lens: torch.Tensor, n_steps: int = 64,
+                              reference_new_cache: bool = True):
+        """Decode the next chunk of encoder frames of every stream: encoder_out (N, Tchunk, E) -> tokens of this
+        chunk (List[int] for one stream as in the reference, List[List[int]] for several)."""
+        st = getattr(self, "_stream", None)
+        if st is None:
+            self.reset_cache(encoder_out.size(0))
+            st = self._stream
+        N, T, _ = encoder_out.shape
+        assert N == st["n"], "call reset_cache(n_streams) before changing the number of streams"
+        lens = torch.as_tensor(encoder_out_lens).reshape(-1)
+        if lens.numel() == 1 and N > 1:
+            lens = lens.expand(N)
+        dec = self._decoder_cache.get(self.predictor, self.joint, lanes=N, utts=N, tmax=max(T, st["tmax"]),
+                                      max_hyp=max(T, st["tmax"]) * n_steps, beam=1)
+        if not st["fresh"] and getattr(self, "_stream_dec", None) is not dec:
+            raise RuntimeError("the decoder handle was rebuilt (weights changed or capacity grew) in the middle of a "
+                               "stream: call reset_cache() with the largest chunk size first")
+        hyps = dec.greedy_chunk(encoder_out, lens, n_steps=n_steps, blank=self.blank, reset=st["fresh"],
+                                reference_new_cache=reference_new_cache)
+        st["fresh"] = False
+        self._stream_dec = dec
+        return hyps[0] if N == 1 else hyps
+
     # ----------------------------------------------------- step exports (:600-629) --
     def forward_encoder_chunk(self, xs, offset: int, required_cache_size: int, att_cache=torch.zeros(0, 0, 0, 0),
                               cnn_cache=torch.zeros(0, 0, 0, 0)):
