@@ -74,6 +74,7 @@ struct DevState {
     // lane state
     float *ep_all;                // [n_utt, T, J]
     int32_t *token, *lane_t, *noblk, *need_pred, *lane_active;
+    int32_t *new_is_cache;        // streaming quirk: the pending predictor state equals the committed one
     float *xT;                    // [Dp][NLp]     embedding of each lane's token
     float *cache_hT, *cache_cT;   // [L][Hp][NLp]  committed LSTM state
     float *new_hT, *new_cT;       // [L][Hp][NLp]  output of the last predictor step
@@ -301,6 +302,7 @@ __global__ void greedy_init_kernel(DevState *s)
         s->lane_t[n] = 0;
         s->noblk[n] = 0;
         s->need_pred[n] = 1;
+        s->new_is_cache[n] = 0;
         s->hyp_lens[n] = 0;
         const int act = T > 0;
         s->lane_active[n] = act;
@@ -317,16 +319,15 @@ __global__ void greedy_chunk_init_kernel(DevState *s, int ref_new_cache)
     const Dims &d = s->d;
     const int n = blockIdx.x;
     const int tid = threadIdx.x;
-    if (ref_new_cache)
-        for (int i = tid; i < d.L * d.Hp; i += blockDim.x) {
-            const size_t o = (size_t)i * d.NLp + n;
-            s->new_hT[o] = s->cache_hT[o];
-            s->new_cT[o] = s->cache_cT[o];
-        }
+    (void)d;
     if (tid == 0) {
         const int T = s->enc_lens[n] < s->T ? s->enc_lens[n] : s->T;
         s->lane_t[n] = 0;
         s->hyp_lens[n] = 0;
+        // `new_cache = self.cache` at the top of a chunk: until the predictor steps again, committing is a no-op.
+        // (The pending state itself is left alone -- the predictor OUTPUT of the last step stays valid, as
+        // self.pred_out_step does in the reference.)
+        s->new_is_cache[n] = ref_new_cache ? 1 : 0;
         const int act = T > 0;
         s->lane_active[n] = act;
         if (act) atomicAdd(s->active_count, 1);
@@ -404,6 +405,7 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(DevState *s)
     if (tid == 0) {
         int t = s->lane_t[n], nb = s->noblk[n];
         int commit = 0;
+        if (s->need_pred[n]) s->new_is_cache[n] = 0;      // the predictor stepped in this micro-step
         if (k != s->blank) {
             const int len = s->hyp_lens[n];
             if (len < s->max_hyp) s->hyps[(size_t)n * s->max_hyp + len] = k;
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(DevState *s)
             s->need_pred[n] = 1;
             nb += 1;
             s->token[n] = k;
-            commit = 1;
+            commit = s->new_is_cache[n] ? 0 : 1;
         }
         if (k == s->blank || nb >= s->n_steps) {
             if (k == s->blank) s->need_pred[n] = 0;
@@ -756,6 +758,7 @@ size_t carve(const wr_transducer_weights *w, int max_lanes, int max_utt, int Tma
     s.ep_all = c.take<float>((size_t)max_utt * Tmax * d.J);
     s.token = c.take<int32_t>(d.NLp); s.lane_t = c.take<int32_t>(d.NLp); s.noblk = c.take<int32_t>(d.NLp);
     s.need_pred = c.take<int32_t>(d.NLp); s.lane_active = c.take<int32_t>(d.NLp);
+    s.new_is_cache = c.take<int32_t>(d.NLp);
     s.logits = c.take<float>((size_t)d.NL * d.V);
     s.active_count = c.take<int32_t>(64);
     s.topv = c.take<float>((size_t)d.NL * kMaxBeam); s.topi = c.take<int32_t>((size_t)d.NL * kMaxBeam);
