@@ -147,9 +147,8 @@ int wr_ctc_loss_bwd(const void *logits_d, int dtype,
  *
  * wr_joint_bwd_dz: dz[b,t,u,:] = (gout[b,t,u,:] @ w_out) * (1 - tanh(ep+pp)^2),
  * zero in padded cells when lengths are given; h_d (optional, [B,T,U1,J])
- * receives tanh(ep+pp) for the weight-gradient GEMM (dW = gout^T h), which --
- * like d ep = sum_u dz and d pp = sum_t dz -- is a plain library reduction/GEMM
- * on the host side.
+ * receives tanh(ep+pp) for the weight gradient (wr_joint_bwd_dw).  d ep = sum_u dz
+ * and d pp = sum_t dz are plain library reductions on the host side.
  * ---------------------------------------------------------------------- */
 size_t wr_joint_workspace_bytes(int J, int V);
 
@@ -164,6 +163,17 @@ int wr_joint_bwd_dz(const float *gout_d /* [B,T,U1,V] */, const float *ep_d, con
                     const int32_t *logit_lengths_d /* nullable */, const int32_t *target_lengths_d /* nullable */,
                     int B, int T, int U1, int J, int V,
                     float *dz_d /* [B,T,U1,J] */, float *h_d /* [B,T,U1,J] or NULL */, void *stream);
+
+/* Weight gradient of ffn_out:  dw[v, :] = sum over lattice cells of gout[cell, v] * h[cell, :],
+ * db[v] = sum of gout[cell, v]  (h = tanh(ep+pp) as written by wr_joint_bwd_dz).  With lengths, cells in the
+ * padded region do not contribute.  db_d may be NULL.  Deterministic (partial slabs + ordered reduction). */
+size_t wr_joint_dw_workspace_bytes(int J, int V);
+
+int wr_joint_bwd_dw(const float *gout_d /* [B,T,U1,V] */, const float *h_d /* [B,T,U1,J] */,
+                    const int32_t *logit_lengths_d /* nullable */, const int32_t *target_lengths_d /* nullable */,
+                    int B, int T, int U1, int J, int V,
+                    float *dw_d /* [V,J] */, float *db_d /* [V] or NULL */,
+                    void *workspace_d, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------
  * Transducer decoding: batched greedy search, batched prefix beam search and

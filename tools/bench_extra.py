@@ -49,6 +49,13 @@ def bench_joint(args):
     ms = timeit(g, args.steps)
     print(json.dumps({"what": "joint_bwd_dz", "shape": [B, T, U1, J, V], "ms": round(ms, 3),
                       "TFLOPs": round(flops / ms / 1e9, 2), "frac": round(flops / ms / 1e9 / 157.3, 4)}), flush=True)
+    wsb2 = lib.wr_joint_dw_workspace_bytes(J, V)
+    ws2 = torch.empty(wsb2, dtype=torch.uint8, device=dev)
+    dwt = torch.empty(V, J, device=dev); dbt = torch.empty(V, device=dev)
+    kdw = lambda: _lib.check(lib.wr_joint_bwd_dw(P(out), P(h), None, None, B, T, U1, J, V, P(dwt), P(dbt), P(ws2), wsb2, st))
+    ms = timeit(kdw, args.steps)
+    print(json.dumps({"what": "joint_bwd_dw", "shape": [B, T, U1, J, V], "ms": round(ms, 3),
+                      "TFLOPs": round(flops / ms / 1e9, 2), "frac": round(flops / ms / 1e9 / 157.3, 4)}), flush=True)
     if args.dw:
         g2 = out.view(-1, V)
         k = lambda: g2.t().mm(h.view(-1, J))

@@ -412,6 +412,145 @@ __global__ __launch_bounds__(512) void joint_bwd_dz_kernel(
     }
 }
 
+// ------------------------------------------------------ weight gradient --
+// dW[v][k] = sum_m dY[m][v] * H[m][k]   and   db[v] = sum_m dY[m][v]      (M = B*T*U1 lattice cells)
+// A reduction over millions of cells: one workgroup owns a slab of 128 vocabulary rows x all J columns
+// (8 waves = 2 V-halves x 4 J-quarters, 2x4 MFMA tiles = 128 accumulator registers per lane) and one of
+// `parts` contiguous ranges of cells; both operands are k(=cell)-major as stored (dY [M][V], H [M][J]), so
+// every fragment is a coalesced 128-byte read straight into a register ping-pong -- no LDS.  The `parts`
+// partial slabs are summed by a second, deterministic kernel (no float atomics).  Workgroups of the same
+// cell range are adjacent in the grid so that the H rows they all read are served from L2 / Infinity Cache.
+constexpr int kDwSlab = 128;
+constexpr int kDwPF = 4;       // k-steps (pairs of cells) per register set
+
+__global__ __launch_bounds__(512) void joint_bwd_dw_kernel(
+    const float *__restrict__ gout /* [M, V] */, const float *__restrict__ h /* [M, J] */,
+    const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens, int B, int T, int U1, int J, int V,
+    int nslabs, long rows_per_part, float *__restrict__ part_dw /* [parts][V][J] */,
+    float *__restrict__ part_db /* [parts][V] */)
+{
+    const long M = (long)B * T * U1;
+    const int slab = blockIdx.x % nslabs, part = blockIdx.x / nslabs;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wv = wave >> 2, wk = wave & 3;                  // V-half, J-quarter of this wave
+    const int v0 = slab * kDwSlab + wv * 64;
+    const int k0 = wk * 128;
+    const long mbeg = (long)part * rows_per_part;
+    long mend = mbeg + rows_per_part;
+    mend = mend < M ? mend : M;
+    const bool masked = (llens != nullptr && tlens != nullptr);
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x16){0};
+    float bsum[2] = {0.f, 0.f};
+
+    int vcol[2], kcol[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int v = v0 + 32 * i + l31; vcol[i] = v < V ? v : V - 1; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int k = k0 + 32 * j + l31; kcol[j] = k < J ? k : J - 1; }
+
+    // a lattice cell contributes only if it is inside the utterance's valid region (padded cells of dY may hold
+    // anything when the caller did not produce it with the RNN-T gradient kernel)
+    auto row_scale = [&](long m) -> float {
+        if (m >= mend) return 0.f;
+        if (!masked) return 1.f;
+        const long bt = m / U1;
+        const int u = (int)(m - bt * U1);
+        const int b = (int)(bt / T), t = (int)(bt - (long)b * T);
+        return (t < llens[b] && u <= tlens[b]) ? 1.f : 0.f;
+    };
+    auto load_set = [&](long m, float (&a)[2][kDwPF], float (&bb)[4][kDwPF], float (&sc)[kDwPF]) {
+#pragma unroll
+        for (int q = 0; q < kDwPF; ++q) {
+            long r = m + 2 * q + half;
+            sc[q] = row_scale(r);
+            r = r < M ? r : M - 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i][q] = gout[(size_t)r * V + vcol[i]];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bb[j][q] = h[(size_t)r * J + kcol[j]];
+        }
+    };
+    auto mfma_set = [&](const float (&a)[2][kDwPF], const float (&bb)[4][kDwPF], const float (&sc)[kDwPF]) {
+#pragma unroll
+        for (int q = 0; q < kDwPF; ++q) {
+            const float a0 = a[0][q] * sc[q], a1 = a[1][q] * sc[q];
+            bsum[0] += a0;
+            bsum[1] += a1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bb[j][q], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bb[j][q], acc[1][j], 0, 0, 0);
+            }
+        }
+    };
+
+    float pa[2][kDwPF], pb[4][kDwPF], ps[kDwPF];
+    float qa[2][kDwPF], qb[4][kDwPF], qs[kDwPF];
+    constexpr int STEP = 2 * kDwPF;                            // cells per register set
+    load_set(mbeg, pa, pb, ps);
+    for (long m = mbeg; m < mend; m += 2 * STEP) {
+        load_set(m + STEP, qa, qb, qs);                        // rows past mend are scaled by 0
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_set(pa, pb, ps);
+        __builtin_amdgcn_sched_barrier(0);
+        load_set(m + 2 * STEP, pa, pb, ps);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_set(qa, qb, qs);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // partial slab: D layout col = lane&31 (-> k), row = (r&3) + 8*(r>>2) + 4*half (-> v)
+    float *__restrict__ pd = part_dw + (size_t)part * V * J;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int v = v0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (v >= V) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + 32 * j + l31;
+                if (k < J) pd[(size_t)v * J + k] = acc[i][j][r];
+            }
+        }
+    if (wk == 0) {                                             // column sums: add the two cell-parities
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float tot = bsum[i] + __shfl_xor(bsum[i], 32, kWave);
+            const int v = v0 + 32 * i + l31;
+            if (half == 0 && v < V) part_db[(size_t)part * V + v] = tot;
+        }
+    }
+}
+
+__global__ void joint_dw_reduce_kernel(const float *__restrict__ part_dw, const float *__restrict__ part_db, int parts,
+                                       long nw, int V, float *__restrict__ dw, float *__restrict__ db)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nw + V; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        if (i < nw) {
+            for (int p = 0; p < parts; ++p) s += part_dw[(size_t)p * nw + i];
+            dw[i] = s;
+        } else if (db != nullptr) {
+            const long v = i - nw;
+            for (int p = 0; p < parts; ++p) s += part_db[(size_t)p * V + v];
+            db[v] = s;
+        }
+    }
+}
+
+inline int dw_parts(int V)
+{
+    const int nslabs = (V + kDwSlab - 1) / kDwSlab;
+    int parts = 256 / nslabs;                                  // one workgroup per CU
+    return parts < 1 ? 1 : parts;
+}
+
 int joint_check(int B, int T, int U1, int J, int V)
 {
     WR_REQUIRE(B > 0 && T > 0 && U1 > 0 && J > 0 && V > 0, WR_EINVAL,
@@ -485,5 +624,39 @@ extern "C" int wr_joint_bwd_dz(const float *gout_d, const float *ep_d, const flo
     hipLaunchKernelGGL(joint_bwd_dz_kernel, grid, dim3(64 * kBwdWaves), 0, st, gout_d, ep_d, pp_d, w_out_d,
                        logit_lengths_d, target_lengths_d, B, T, U1, J, V, dz_d, h_d);
     WR_CHECK_LAUNCH("joint_bwd_dz_kernel");
+    return WR_OK;
+}
+
+extern "C" size_t wr_joint_dw_workspace_bytes(int J, int V)
+{
+    if (J <= 0 || V <= 0) return 0;
+    return align_up((size_t)dw_parts(V) * ((size_t)V * J + V) * sizeof(float), 256);
+}
+
+extern "C" int wr_joint_bwd_dw(const float *gout_d, const float *h_d, const int32_t *logit_lengths_d,
+                               const int32_t *target_lengths_d, int B, int T, int U1, int J, int V, float *dw_d,
+                               float *db_d, void *workspace_d, size_t workspace_bytes, void *stream)
+{
+    if (int rc = joint_check(B, T, U1, J, V)) return rc;
+    WR_REQUIRE(gout_d && h_d && dw_d && workspace_d, WR_EINVAL, "joint_bwd_dw: null pointer argument");
+    WR_REQUIRE((logit_lengths_d == nullptr) == (target_lengths_d == nullptr), WR_EINVAL,
+               "joint_bwd_dw: pass both length arrays or neither");
+    const int parts = dw_parts(V);
+    const size_t need = (size_t)parts * ((size_t)V * J + V) * sizeof(float);
+    WR_REQUIRE(workspace_bytes >= need, WR_EWORKSPACE, "joint_bwd_dw: workspace %zu < required %zu", workspace_bytes, need);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long M = (long)B * T * U1;
+    const int nslabs = (V + kDwSlab - 1) / kDwSlab;
+    const long per = 4 * kDwPF;                                // the main loop advances in units of two register sets
+    long rows_per_part = (M + parts - 1) / parts;
+    rows_per_part = (rows_per_part + per - 1) / per * per;
+    float *part_dw = static_cast<float *>(workspace_d);
+    float *part_db = part_dw + (size_t)parts * V * J;
+    hipLaunchKernelGGL(joint_bwd_dw_kernel, dim3(nslabs * parts), dim3(512), 0, st, gout_d, h_d, logit_lengths_d,
+                       target_lengths_d, B, T, U1, J, V, nslabs, rows_per_part, part_dw, part_db);
+    WR_CHECK_LAUNCH("joint_bwd_dw_kernel");
+    hipLaunchKernelGGL(joint_dw_reduce_kernel, dim3(1024), dim3(256), 0, st, part_dw, part_db, parts, (long)V * J, V, dw_d,
+                       db_d);
+    WR_CHECK_LAUNCH("joint_dw_reduce_kernel");
     return WR_OK;
 }

@@ -7,9 +7,8 @@ load unchanged), same ``forward(enc_out, pred_out) -> (B, T, U, V)``.
 The two pre-join projections are plain library GEMMs on small tensors
 (torch.nn.Linear on rocBLAS).  Everything after them -- broadcast add, tanh,
 the 512 -> V contraction and its backward w.r.t. the activations -- is the
-fused HIP path (``wr_joint_fwd`` / ``wr_joint_bwd_dz``).  The weight gradient
-``dW = dY^T H`` and the two reductions of ``dZ`` over u / t are library
-GEMM / sum calls.
+fused HIP path (``wr_joint_fwd`` / ``wr_joint_bwd_dz`` / ``wr_joint_bwd_dw``); only the
+two reductions of ``dZ`` over u / t are library sum calls.
 
 Supported configuration: the reference's shipped one (``joint_mode='add'``,
 ``activation='tanh'``, ``postjoin_linear=False``,
@@ -68,15 +67,25 @@ class _JointFn(torch.autograd.Function):
         _lib.check(rc, "wr_joint_bwd_dz")
         d_ep = dz.sum(dim=2)
         d_pp = dz.sum(dim=1)
-        g2 = gout.view(-1, V)
-        if llens is not None:
-            # padded cells were skipped in forward: their incoming gradient must not leak into dW / db
-            tt = torch.arange(T, device=dev)[None, :, None] < llens[:, None, None]
-            uu = torch.arange(U1, device=dev)[None, None, :] <= tlens[:, None, None]
-            mask = (tt & uu).view(-1, 1)
-            g2 = torch.where(mask, g2, torch.zeros((), device=dev))
-        d_w = g2.t().mm(h.view(-1, J)) if need_w else None            # plain library GEMM (rocBLAS)
-        d_b = g2.sum(0) if ctx.needs_input_grad[3] else None
+        d_w = d_b = None
+        if need_w:
+            d_w = torch.empty(V, J, dtype=torch.float32, device=dev)
+            d_b = torch.empty(V, dtype=torch.float32, device=dev)
+            wsb = lib.wr_joint_dw_workspace_bytes(J, V)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                rc = lib.wr_joint_bwd_dw(_lib.ptr(gout), _lib.ptr(h), _lib.ptr(llens), _lib.ptr(tlens), B, T, U1, J, V,
+                                         _lib.ptr(d_w), _lib.ptr(d_b), _lib.ptr(ws), wsb, _lib.current_stream(dev))
+            _lib.check(rc, "wr_joint_bwd_dw")
+        elif ctx.needs_input_grad[3]:
+            g2 = gout.view(-1, V)
+            if llens is not None:
+                tt = torch.arange(T, device=dev)[None, :, None] < llens[:, None, None]
+                uu = torch.arange(U1, device=dev)[None, None, :] <= tlens[:, None, None]
+                g2 = torch.where((tt & uu).view(-1, 1), g2, torch.zeros((), device=dev))
+            d_b = g2.sum(0)
+        if not ctx.needs_input_grad[3]:
+            d_b = None
         return d_ep, d_pp, d_w, d_b, None, None
 
 
