@@ -264,6 +264,28 @@ int wr_predictor_step(wr_decoder *h, const int32_t *tokens_d, const float *cache
                       const float *cache_c_d, int N, float *out_d, float *new_h_d, float *new_c_d,
                       void *stream);
 
+/* ------------------------------------------------------------------------
+ * CTC decode modes, from the ctc_lo output on; the log-softmax is fused.
+ * Replaces ASRModel.ctc_greedy_search (wenet/transformer/asr_model.py:281-324) and
+ * ASRModel._ctc_prefix_beam_search (:326-409; C++ twin runtime/core/decoder/ctc_prefix_beam_search.cc:107-238,
+ * known-answer test runtime/core/test/ctc_prefix_beam_search_test.cc:30-73).
+ * logits [B, T, V] pre-softmax, lens [B].
+ * Greedy: hyps [B, T] / hyp_lens [B] / scores [B].  As in the reference, frames past an utterance's length are
+ * filled with `eos` before duplicate/blank removal, and scores[b] is the maximum over all T frames of the
+ * best log-probability.
+ * Prefix beam: hyps [B, beam, T] (padded with -1), hyp_lens [B, beam], scores [B, beam] float64 (best first),
+ * n_hyps [B]; any number of utterances at once (the reference asserts batch size 1).  beam <= 16.
+ * ---------------------------------------------------------------------- */
+size_t wr_ctc_decode_workspace_bytes(int B, int T, int beam);
+
+int wr_ctc_greedy_search(const float *logits_d, const int32_t *lens_d, int B, int T, int V, int blank, int eos,
+                         int32_t *hyps_d, int32_t *hyp_lens_d, float *scores_d,
+                         void *workspace_d, size_t workspace_bytes, void *stream);
+
+int wr_ctc_prefix_beam_search(const float *logits_d, const int32_t *lens_d, int B, int T, int V, int beam,
+                              int blank, int32_t *hyps_d, int32_t *hyp_lens_d, double *scores_d,
+                              int32_t *n_hyps_d, void *workspace_d, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

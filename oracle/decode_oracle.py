@@ -222,3 +222,60 @@ def prefix_beam_search(pred: Predictor, joint: Joint, ctc_w, enc, T, beam_size=5
         fusion.sort(key=lambda s: s["score"], reverse=True)                 # stable, like list.sort
         beam = fusion[:beam_size]
     return beam
+
+
+# ---------------------------------------------------------------- CTC decode modes --
+def ctc_greedy_search(logits, lens, eos):
+    """ASRModel.ctc_greedy_search, wenet/transformer/asr_model.py:281-324, from the ctc_lo output on.
+    logits (B,T,V).  Returns (hyps, scores): frames past an utterance's length are filled with `eos` BEFORE
+    duplicates/blanks are removed (so shorter utterances of a batch end in one eos), and the score is the
+    maximum over ALL T frames of the best log-probability -- both exactly as the reference does."""
+    lp = log_softmax(np.asarray(logits, F))
+    best = lp.argmax(-1)
+    top = lp.max(-1)
+    B, T = best.shape
+    hyps = []
+    for b in range(B):
+        seq = [int(best[b, t]) if t < lens[b] else eos for t in range(T)]
+        out, cur = [], 0
+        while cur < len(seq):                      # remove_duplicates_and_blank, common.py:256-265
+            if seq[cur] != 0:
+                out.append(seq[cur])
+            prev = cur
+            while cur < len(seq) and seq[cur] == seq[prev]:
+                cur += 1
+        hyps.append(out)
+    return hyps, top.max(1)
+
+
+def ctc_prefix_beam_search(logp, T, beam_size):
+    """ASRModel._ctc_prefix_beam_search, asr_model.py:326-409, for one utterance from its CTC log-probs (T,V).
+    Returns [(prefix tuple, score)] best first."""
+    from collections import defaultdict
+    logp = np.asarray(logp, F)
+    cur_hyps = [(tuple(), (0.0, -float("inf")))]
+    for t in range(T):
+        row = logp[t]
+        next_hyps = defaultdict(lambda: (-float("inf"), -float("inf")))
+        order = np.argsort(-row, kind="stable")[:beam_size]
+        for s in order:
+            s = int(s)
+            ps = float(row[s])
+            for prefix, (pb, pnb) in cur_hyps:
+                last = prefix[-1] if len(prefix) > 0 else None
+                if s == 0:
+                    n_pb, n_pnb = next_hyps[prefix]
+                    next_hyps[prefix] = (log_add([n_pb, pb + ps, pnb + ps]), n_pnb)
+                elif s == last:
+                    n_pb, n_pnb = next_hyps[prefix]
+                    next_hyps[prefix] = (n_pb, log_add([n_pnb, pnb + ps]))
+                    n_prefix = prefix + (s,)
+                    n_pb, n_pnb = next_hyps[n_prefix]
+                    next_hyps[n_prefix] = (n_pb, log_add([n_pnb, pb + ps]))
+                else:
+                    n_prefix = prefix + (s,)
+                    n_pb, n_pnb = next_hyps[n_prefix]
+                    next_hyps[n_prefix] = (n_pb, log_add([n_pnb, pb + ps, pnb + ps]))
+        nh = sorted(next_hyps.items(), key=lambda x: log_add(list(x[1])), reverse=True)
+        cur_hyps = nh[:beam_size]
+    return [(y[0], log_add([y[1][0], y[1][1]])) for y in cur_hyps]

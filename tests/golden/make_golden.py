@@ -296,6 +296,65 @@ def gen_beam():
              **{"ctc_" + k: v for k, v in sd(ctc).items()})
 
 
+def gen_ctc_decode():
+    """ASRModel.ctc_greedy_search / _ctc_prefix_beam_search (wenet/transformer/asr_model.py:281-409), called
+    unbound with a stand-in `self` that supplies the encoder output and the reference CTC module."""
+    from wenet.transformer.asr_model import ASRModel
+    from wenet.transformer.ctc import CTC
+    cases = [dict(seed=300, B=1, T=30, V=20, E=8, beam=4), dict(seed=301, B=1, T=60, V=64, E=16, beam=10),
+             dict(seed=302, B=3, T=25, V=12, E=8, beam=3), dict(seed=303, B=1, T=12, V=5, E=4, beam=5)]
+    for i, c in enumerate(cases):
+        torch.manual_seed(c["seed"])
+        ctc = CTC(c["V"], c["E"]).eval()
+        with torch.no_grad():
+            ctc.ctc_lo.weight.mul_(6.0)
+            ctc.ctc_lo.bias[0] += 1.0
+        enc = torch.randn(c["B"], c["T"], c["E"])
+        lens = torch.randint(c["T"] // 2, c["T"] + 1, (c["B"],))
+        lens[0] = c["T"]
+        mask = (torch.arange(c["T"])[None, :] < lens[:, None]).unsqueeze(1)
+
+        class Self:
+            eos = c["V"] - 1
+
+            def __init__(self, enc, mask):
+                self.enc, self.mask, self.ctc = enc, mask, ctc
+
+            def _forward_encoder(self, speech, speech_lengths, a=-1, b=-1, c=False):
+                return self.enc, self.mask
+
+        with torch.no_grad():
+            st = Self(enc, mask)
+            ghyps, gscores = ASRModel.ctc_greedy_search(st, torch.zeros(c["B"], c["T"], 1), lens)
+            nbest = []
+            for b in range(c["B"]):                      # the prefix beam search asserts batch size 1
+                sb = Self(enc[b:b + 1, :int(lens[b])], mask[b:b + 1, :, :int(lens[b])])
+                hyps, _ = ASRModel._ctc_prefix_beam_search(sb, torch.zeros(1, int(lens[b]), 1), lens[b:b + 1], c["beam"])
+                nbest.append(hyps)
+        gl = max(len(h) for h in ghyps)
+        garr = np.full((c["B"], max(gl, 1)), -1, np.int64)
+        for b, h in enumerate(ghyps):
+            garr[b, :len(h)] = h
+        nb = max(len(h) for h in nbest)
+        ml = max(max((len(p) for p, _ in h), default=0) for h in nbest)
+        parr = np.full((c["B"], nb, max(ml, 1)), -1, np.int64)
+        plen = np.zeros((c["B"], nb), np.int64)
+        psc = np.full((c["B"], nb), -np.inf)
+        for b, h in enumerate(nbest):
+            for k, (pref, sc) in enumerate(h):
+                parr[b, k, :len(pref)] = pref
+                plen[b, k] = len(pref)
+                psc[b, k] = sc
+        logits = (enc @ ctc.ctc_lo.weight.T + ctc.ctc_lo.bias).detach().numpy()
+        save(f"ctc_decode_{i}", logits=logits, lens=lens.numpy(), beam=np.array(c["beam"]),
+             greedy=garr, greedy_lens=np.array([len(h) for h in ghyps]), greedy_scores=gscores.values.squeeze(-1).numpy(),
+             nbest=parr, nbest_lens=plen, nbest_scores=psc, nbest_n=np.array([len(h) for h in nbest]))
+    # the reference's own known-answer test (runtime/core/test/ctc_prefix_beam_search_test.cc:30-73): data only
+    probs = np.array([[0.25, 0.40, 0.35], [0.40, 0.35, 0.25], [0.10, 0.50, 0.40]], np.float32)
+    save("ctc_prefix_kat", probs=probs, beam=np.array(3), nbest=np.array([[2, 1], [1, 2], [1, -1]]),
+         nbest_lens=np.array([2, 2, 1]), likelihood=np.array([0.2185, 0.1550, 0.1525], np.float32))
+
+
 def gen_common():
     from wenet.utils.common import add_blank, log_add
     ys = torch.tensor([[1, 2, 3, 4, 5], [4, 5, 6, -1, -1], [7, 8, 9, -1, -1]])
@@ -324,3 +383,4 @@ if __name__ == "__main__":
     gen_predictor()
     gen_greedy()
     gen_beam()
+    gen_ctc_decode()

@@ -1,0 +1,64 @@
+"""CTC decode modes on the GPU: identical hypotheses to the reference's
+ASRModel.ctc_greedy_search / _ctc_prefix_beam_search outputs (tests/golden/ctc_decode_*.npz) and to the
+reference's own known-answer test (runtime/core/test/ctc_prefix_beam_search_test.cc:30-73)."""
+import glob
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import decode_oracle as do
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "ctc_decode_*.npz"))))
+def test_matches_reference(path):
+    import wenet_celoss_amd as w
+    d = np.load(path)
+    logits = torch.tensor(d["logits"], device=DEV)
+    lens = torch.tensor(d["lens"], device=DEV)
+    hyps, scores = w.ctc_greedy_search(logits, lens)
+    for b, h in enumerate(hyps):
+        assert h == list(d["greedy"][b][: d["greedy_lens"][b]])
+    np.testing.assert_allclose(scores.cpu().numpy(), d["greedy_scores"], rtol=1e-5, atol=1e-6)
+    nbest = w.ctc_prefix_beam_search(logits, lens, int(d["beam"]))          # all utterances in one call
+    for b, hb in enumerate(nbest):
+        assert len(hb) == int(d["nbest_n"][b])
+        for k, (pref, sc) in enumerate(hb):
+            assert list(pref) == list(d["nbest"][b, k][: d["nbest_lens"][b, k]]), (b, k)
+            assert sc == pytest.approx(d["nbest_scores"][b, k], rel=1e-5)
+
+
+def test_known_answer_from_reference_gtest():
+    import wenet_celoss_amd as w
+    d = np.load(os.path.join(GOLDEN, "ctc_prefix_kat.npz"))
+    # the kernel applies log-softmax; log of a probability row is a fixed point of it
+    logits = torch.tensor(np.log(d["probs"]), device=DEV)[None]
+    nb = w.ctc_prefix_beam_search(logits, torch.tensor([3]), int(d["beam"]))[0]
+    for k, (pref, sc) in enumerate(nb):
+        assert list(pref) == list(d["nbest"][k][: d["nbest_lens"][k]])
+        assert math.exp(sc) == pytest.approx(float(d["likelihood"][k]), rel=1e-4)
+
+
+def test_config_scale_against_oracle():
+    import wenet_celoss_amd as w
+    torch.manual_seed(9)
+    B, T, V, beam = 4, 300, 5000, 10
+    logits = torch.randn(B, T, V, device=DEV) * 3
+    logits[:, :, 0] += 6
+    lens = torch.tensor([300, 211, 150, 299], device=DEV)
+    nb = w.ctc_prefix_beam_search(logits, lens, beam)
+    lp = do.log_softmax(logits.cpu().numpy())
+    for b in (1, 2):
+        ref = do.ctc_prefix_beam_search(lp[b], int(lens[b]), beam)
+        assert [p for p, _ in ref] == [p for p, _ in nb[b]]
+        np.testing.assert_allclose([s for _, s in ref], [s for _, s in nb[b]], rtol=1e-6)
+    gh, gs = w.ctc_greedy_search(logits, lens)
+    rh, rs = do.ctc_greedy_search(logits.cpu().numpy(), lens.cpu().numpy(), V - 1)
+    assert gh == rh
+    np.testing.assert_allclose(gs.cpu().numpy(), rs, rtol=1e-5)

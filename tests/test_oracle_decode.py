@@ -3,6 +3,7 @@ the fixtures that tests/golden/make_golden.py produced by running the
 reference's own modules: predictor step, joiner, greedy search, prefix beam
 search, CTC module."""
 import glob
+import math
 import os
 
 import numpy as np
@@ -102,3 +103,31 @@ def test_ctc_module_fixture(name):
     lp = do.log_softmax(logits)
     np.testing.assert_allclose(lp, d["log_softmax"], rtol=1e-5, atol=1e-5)
     assert (logits.argmax(-1) == d["argmax"]).all()
+
+
+@pytest.mark.parametrize("name", names("ctc_decode_*.npz"))
+def test_ctc_decode_modes(name):
+    """oracle restatements of ASRModel.ctc_greedy_search / _ctc_prefix_beam_search vs the reference's outputs."""
+    d = load(name)
+    V = d["logits"].shape[-1]
+    hyps, scores = do.ctc_greedy_search(d["logits"], d["lens"], eos=V - 1)
+    for b, h in enumerate(hyps):
+        assert h == list(d["greedy"][b][: d["greedy_lens"][b]])
+    np.testing.assert_allclose(scores, d["greedy_scores"], rtol=1e-5, atol=1e-6)
+    lp = do.log_softmax(d["logits"])
+    for b in range(d["logits"].shape[0]):
+        nb = do.ctc_prefix_beam_search(lp[b], int(d["lens"][b]), int(d["beam"]))
+        assert len(nb) == int(d["nbest_n"][b])
+        for k, (pref, sc) in enumerate(nb):
+            assert list(pref) == list(d["nbest"][b, k][: d["nbest_lens"][b, k]])
+            assert sc == pytest.approx(d["nbest_scores"][b, k], rel=1e-6)
+
+
+def test_ctc_prefix_known_answer_from_reference_gtest():
+    """runtime/core/test/ctc_prefix_beam_search_test.cc:30-73: n-best [2,1], [1,2], [1] with likelihoods
+    0.2185 / 0.1550 / 0.1525."""
+    d = load("ctc_prefix_kat.npz")
+    nb = do.ctc_prefix_beam_search(np.log(d["probs"]), 3, int(d["beam"]))
+    for k, (pref, sc) in enumerate(nb):
+        assert list(pref) == list(d["nbest"][k][: d["nbest_lens"][k]])
+        assert math.exp(sc) == pytest.approx(float(d["likelihood"][k]), rel=1e-4)

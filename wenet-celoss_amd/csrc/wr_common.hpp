@@ -88,4 +88,48 @@ __device__ __forceinline__ float lane_shift_down(float v, float fill)
                                            0x130 /* wave_shl:1 */, 0xf, 0xf, false));
 }
 
+// block-wide argmax with "first index on ties"
+__device__ __forceinline__ void block_argmax(float &val, int &idx, float *sv, int *si)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(val, o, kWave);
+        const int oi = __shfl_xor(idx, o, kWave);
+        if (ov > val || (ov == val && oi < idx)) { val = ov; idx = oi; }
+    }
+    if (lane == 0) { sv[wave] = val; si[wave] = idx; }
+    __syncthreads();
+    const int nw = blockDim.x >> 6;
+    val = sv[0]; idx = si[0];
+    for (int w = 1; w < nw; ++w)
+        if (sv[w] > val || (sv[w] == val && si[w] < idx)) { val = sv[w]; idx = si[w]; }
+    __syncthreads();
+}
+
+__device__ __forceinline__ float block_max(float v, float *sv)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    v = wave_max(v);
+    if (lane == 0) sv[wave] = v;
+    __syncthreads();
+    float r = sv[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = fmaxf(r, sv[w]);
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ float block_sum(float v, float *sv)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    v = wave_sum(v);
+    if (lane == 0) sv[wave] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += sv[w];
+    __syncthreads();
+    return r;
+}
+
+
 }  // namespace wr

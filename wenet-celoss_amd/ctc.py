@@ -90,6 +90,54 @@ def ctc_loss(logits: torch.Tensor, targets: torch.Tensor, input_lengths: torch.T
     return nll
 
 
+def ctc_greedy_search(logits: torch.Tensor, lens: torch.Tensor, blank: int = 0, eos: int = -1):
+    """ASRModel.ctc_greedy_search (wenet/transformer/asr_model.py:281-324) from the ctc_lo output (B, T, V) on:
+    returns (hyps: List[List[int]], scores (B,)).  eos defaults to V-1 (asr_model.py:52-53)."""
+    if not logits.is_cuda:
+        raise RuntimeError("wenet_celoss_amd.ctc_greedy_search: logits must live on a HIP device (no CPU path)")
+    lib = _lib.load()
+    x = logits.detach().float().contiguous()
+    B, T, V = x.shape
+    dev = x.device
+    ln = lens.to(device=dev, dtype=torch.int32).reshape(-1).contiguous()
+    wsb = lib.wr_ctc_decode_workspace_bytes(B, T, 1)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    hyps = torch.empty(B, T, dtype=torch.int32, device=dev)
+    hl = torch.empty(B, dtype=torch.int32, device=dev)
+    sc = torch.empty(B, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.wr_ctc_greedy_search(_lib.ptr(x), _lib.ptr(ln), B, T, V, int(blank), int(eos if eos >= 0 else V - 1),
+                                      _lib.ptr(hyps), _lib.ptr(hl), _lib.ptr(sc), _lib.ptr(ws), wsb, _lib.current_stream(dev))
+    _lib.check(rc, "wr_ctc_greedy_search")
+    hc, lc = hyps.cpu(), hl.cpu().tolist()
+    return [hc[b, :lc[b]].tolist() for b in range(B)], sc
+
+
+def ctc_prefix_beam_search(logits: torch.Tensor, lens: torch.Tensor, beam_size: int, blank: int = 0):
+    """ASRModel._ctc_prefix_beam_search (asr_model.py:326-409) from the ctc_lo output (B, T, V) on.
+    Per utterance: [(prefix tuple, score)] best first (the reference's `hyps` for batch size 1)."""
+    if not logits.is_cuda:
+        raise RuntimeError("wenet_celoss_amd.ctc_prefix_beam_search: logits must live on a HIP device (no CPU path)")
+    lib = _lib.load()
+    x = logits.detach().float().contiguous()
+    B, T, V = x.shape
+    dev = x.device
+    ln = lens.to(device=dev, dtype=torch.int32).reshape(-1).contiguous()
+    wsb = lib.wr_ctc_decode_workspace_bytes(B, T, beam_size)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    hyps = torch.empty(B, beam_size, T, dtype=torch.int32, device=dev)
+    hl = torch.empty(B, beam_size, dtype=torch.int32, device=dev)
+    sc = torch.empty(B, beam_size, dtype=torch.float64, device=dev)
+    nh = torch.empty(B, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.wr_ctc_prefix_beam_search(_lib.ptr(x), _lib.ptr(ln), B, T, V, int(beam_size), int(blank), _lib.ptr(hyps),
+                                           _lib.ptr(hl), _lib.ptr(sc), _lib.ptr(nh), _lib.ptr(ws), wsb,
+                                           _lib.current_stream(dev))
+    _lib.check(rc, "wr_ctc_prefix_beam_search")
+    hc, lc, scc, nc = hyps.cpu(), hl.cpu().tolist(), sc.cpu().tolist(), nh.cpu().tolist()
+    return [[(tuple(hc[b, e, :lc[b][e]].tolist()), scc[b][e]) for e in range(nc[b])] for b in range(B)]
+
+
 class CTC(torch.nn.Module):
     """CTC module (wenet/transformer/ctc.py:21-84)."""
 

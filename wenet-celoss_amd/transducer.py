@@ -193,6 +193,50 @@ class Transducer(nn.Module):
         r_decoder_out = torch.nn.functional.log_softmax(r_decoder_out, dim=-1).cpu().numpy()
         return decoder_out, r_decoder_out
 
+    # CTC decode modes inherited from ASRModel in the reference (asr_model.py:281-440)
+    def _forward_encoder(self, speech, speech_lengths, decoding_chunk_size: int = -1, num_decoding_left_chunks: int = -1,
+                         simulate_streaming: bool = False):
+        if simulate_streaming and decoding_chunk_size > 0:
+            return self.encoder.forward_chunk_by_chunk(speech, decoding_chunk_size=decoding_chunk_size,
+                                                       num_decoding_left_chunks=num_decoding_left_chunks)
+        return self.encoder(speech, speech_lengths, decoding_chunk_size, num_decoding_left_chunks)
+
+    def ctc_greedy_search(self, speech: torch.Tensor, speech_lengths: torch.Tensor, decoding_chunk_size: int = -1,
+                          num_decoding_left_chunks: int = -1, simulate_streaming: bool = False):
+        """asr_model.py:281-324 -> (hyps, scores)."""
+        from .ctc import ctc_greedy_search
+        assert speech.shape[0] == speech_lengths.shape[0]
+        assert decoding_chunk_size != 0
+        encoder_out, encoder_mask = self._forward_encoder(speech, speech_lengths, decoding_chunk_size,
+                                                          num_decoding_left_chunks, simulate_streaming)
+        encoder_out_lens = encoder_mask.squeeze(1).sum(1)
+        with torch.no_grad():
+            logits = self.ctc.ctc_lo(encoder_out)
+        return ctc_greedy_search(logits, encoder_out_lens, blank=0, eos=self.eos)
+
+    def _ctc_prefix_beam_search(self, speech: torch.Tensor, speech_lengths: torch.Tensor, beam_size: int,
+                                decoding_chunk_size: int = -1, num_decoding_left_chunks: int = -1,
+                                simulate_streaming: bool = False):
+        """asr_model.py:326-409 -> (hyps [(prefix, score)], encoder_out)."""
+        from .ctc import ctc_prefix_beam_search
+        assert speech.shape[0] == speech_lengths.shape[0]
+        assert decoding_chunk_size != 0
+        assert speech.shape[0] == 1
+        encoder_out, encoder_mask = self._forward_encoder(speech, speech_lengths, decoding_chunk_size,
+                                                          num_decoding_left_chunks, simulate_streaming)
+        with torch.no_grad():
+            logits = self.ctc.ctc_lo(encoder_out)
+        lens = torch.tensor([encoder_out.size(1)], dtype=torch.int32)
+        return ctc_prefix_beam_search(logits, lens, beam_size)[0], encoder_out
+
+    def ctc_prefix_beam_search(self, speech: torch.Tensor, speech_lengths: torch.Tensor, beam_size: int,
+                               decoding_chunk_size: int = -1, num_decoding_left_chunks: int = -1,
+                               simulate_streaming: bool = False):
+        """asr_model.py:411-440"""
+        hyps, _ = self._ctc_prefix_beam_search(speech, speech_lengths, beam_size, decoding_chunk_size,
+                                               num_decoding_left_chunks, simulate_streaming)
+        return hyps[0]
+
     def beam_search(self, speech: torch.Tensor, speech_lengths: torch.Tensor, decoding_chunk_size: int = -1,
                     beam_size: int = 5, num_decoding_left_chunks: int = -1, simulate_streaming: bool = False,
                     ctc_weight: float = 0.3, transducer_weight: float = 0.7, **_ignored):
@@ -210,8 +254,7 @@ class Transducer(nn.Module):
                                        ctc_weight: float = 0.0, attn_weight: float = 0.0,
                                        transducer_weight: float = 0.0, search_ctc_weight: float = 1.0,
                                        search_transducer_weight: float = 0.0, beam_search_type: str = "transducer"):
-        """transducer.py:379-513 (transducer n-best; the CTC n-best branch needs the ASRModel CTC prefix beam
-        search)."""
+        """transducer.py:379-513"""
         assert speech.shape[0] == speech_lengths.shape[0]
         assert decoding_chunk_size != 0
         if reverse_weight > 0.0:
@@ -219,15 +262,23 @@ class Transducer(nn.Module):
         device = speech.device
         assert speech.shape[0] == 1
         self.init_bs()
-        if beam_search_type != "transducer":
-            raise NotImplementedError("beam_search_type='ctc' is not built yet (SURVEY.md section 8f item 1)")
-        beam, encoder_out = self.bs.prefix_beam_search(speech, speech_lengths, decoding_chunk_size=decoding_chunk_size,
-                                                       beam_size=beam_size,
-                                                       num_decoding_left_chunks=num_decoding_left_chunks,
-                                                       ctc_weight=search_ctc_weight,
-                                                       transducer_weight=search_transducer_weight)
-        beam_score = [s.score for s in beam]
-        hyps = [s.hyp[1:] for s in beam]
+        if beam_search_type == "transducer":
+            beam, encoder_out = self.bs.prefix_beam_search(speech, speech_lengths, decoding_chunk_size=decoding_chunk_size,
+                                                           beam_size=beam_size,
+                                                           num_decoding_left_chunks=num_decoding_left_chunks,
+                                                           ctc_weight=search_ctc_weight,
+                                                           transducer_weight=search_transducer_weight)
+            beam_score = [s.score for s in beam]
+            hyps = [s.hyp[1:] for s in beam]
+        elif beam_search_type == "ctc":                                     # transducer.py:447-456
+            hyps, encoder_out = self._ctc_prefix_beam_search(speech, speech_lengths, beam_size=beam_size,
+                                                             decoding_chunk_size=decoding_chunk_size,
+                                                             num_decoding_left_chunks=num_decoding_left_chunks,
+                                                             simulate_streaming=simulate_streaming)
+            beam_score = [hyp[1] for hyp in hyps]
+            hyps = [list(hyp[0]) for hyp in hyps]
+        else:
+            raise ValueError(f"unknown beam_search_type {beam_search_type!r}")
         assert len(hyps) == beam_size
         hyps_pad = pad_sequence([torch.tensor(h, device=device, dtype=torch.long) for h in hyps], True, self.ignore_id)
         hyps_lens = torch.tensor([len(h) for h in hyps], device=device, dtype=torch.long)
