@@ -286,6 +286,18 @@ int wr_ctc_prefix_beam_search(const float *logits_d, const int32_t *lens_d, int 
                               int blank, int32_t *hyps_d, int32_t *hyp_lens_d, double *scores_d,
                               int32_t *n_hyps_d, void *workspace_d, size_t workspace_bytes, void *stream);
 
+/* CTC forced alignment: Viterbi over the T x (2S+1) lattice, replacing
+ * forced_align, wenet/utils/ctc_util.py:27-83 (CLI wenet/bin/alignment.py:215).  logits [B, Tmax, V]: pre-softmax
+ * ctc_lo output, or log-posteriors if normalized != 0 (the reference is handed ctc.log_softmax(...)).
+ * alignment [B, Tmax]: the token (blank or label) aligned to each frame, -1 past input_lengths[b].
+ * fp32 scores and first-candidate tie rule as the reference; Smax >= 1. */
+size_t wr_ctc_align_workspace_bytes(int B, int Tmax, int Smax);
+
+int wr_ctc_forced_align(const float *logits_d, int normalized, const int32_t *targets_d,
+                        const int32_t *input_lengths_d, const int32_t *target_lengths_d,
+                        int B, int Tmax, int Smax, int V, int blank, int32_t *alignment_d,
+                        void *workspace_d, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

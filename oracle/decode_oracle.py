@@ -279,3 +279,34 @@ def ctc_prefix_beam_search(logp, T, beam_size):
         nh = sorted(next_hyps.items(), key=lambda x: log_add(list(x[1])), reverse=True)
         cur_hyps = nh[:beam_size]
     return [(y[0], log_add([y[1][0], y[1][1]])) for y in cur_hyps]
+
+
+def forced_align(ctc_probs, y, blank_id=0):
+    """wenet/utils/ctc_util.py:27-83 restated (fp32 scores, torch.argmax = first maximum, and the reference's
+    negative-index quirk: for s = 0 the candidate log_alpha[t-1, s-1] is the LAST state)."""
+    lp = np.asarray(ctc_probs, F)
+    T = lp.shape[0]
+    ext = [blank_id]
+    for tok in y:
+        ext += [int(tok), blank_id]
+    NS = len(ext)
+    alpha = np.full((T, NS), -np.inf, F)
+    path = np.full((T, NS), -1, np.int64)
+    alpha[0, 0] = lp[0, ext[0]]
+    alpha[0, 1] = lp[0, ext[1]]
+    for t in range(1, T):
+        for s in range(NS):
+            if ext[s] == blank_id or s < 2 or ext[s] == ext[s - 2]:
+                prev = [s, s - 1]
+            else:
+                prev = [s, s - 1, s - 2]
+            cands = np.array([alpha[t - 1, p] for p in prev], F)       # p = -1 wraps, as in Python
+            k = int(np.argmax(cands))
+            alpha[t, s] = cands[k] + lp[t, ext[s]]
+            path[t, s] = prev[k]
+    st = [NS - 1, NS - 2][int(np.argmax(np.array([alpha[-1, NS - 1], alpha[-1, NS - 2]], F)))]
+    seq = [0] * T
+    seq[-1] = st
+    for t in range(T - 2, -1, -1):
+        seq[t] = path[t + 1, seq[t + 1]]
+    return [ext[s] for s in seq]

@@ -355,6 +355,20 @@ def gen_ctc_decode():
          nbest_lens=np.array([2, 2, 1]), likelihood=np.array([0.2185, 0.1550, 0.1525], np.float32))
 
 
+def gen_ctc_align():
+    """forced_align (wenet/utils/ctc_util.py:27-83) on seeded log-posteriors."""
+    from wenet.utils.ctc_util import forced_align
+    for i, (seed, T, V, L, rep) in enumerate([(400, 12, 6, 3, False), (401, 40, 20, 9, True), (402, 25, 8, 12, False),
+                                              (403, 60, 30, 20, True)]):
+        g = torch.Generator().manual_seed(seed)
+        lp = torch.log_softmax(torch.randn(T, V, generator=g) * 2, -1)
+        y = torch.randint(1, V, (L,), generator=g)
+        if rep:
+            y[1::3] = y[0::3][: len(y[1::3])]               # repeated neighbours: the s-2 skip must be blocked
+        ali = forced_align(lp, y)
+        save(f"ctc_align_{i}", ctc_probs=lp.numpy(), y=y.numpy(), alignment=np.array([int(a) for a in ali], np.int64))
+
+
 def gen_common():
     from wenet.utils.common import add_blank, log_add
     ys = torch.tensor([[1, 2, 3, 4, 5], [4, 5, 6, -1, -1], [7, 8, 9, -1, -1]])
@@ -384,3 +398,4 @@ if __name__ == "__main__":
     gen_greedy()
     gen_beam()
     gen_ctc_decode()
+    gen_ctc_align()

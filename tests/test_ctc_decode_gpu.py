@@ -62,3 +62,33 @@ def test_config_scale_against_oracle():
     rh, rs = do.ctc_greedy_search(logits.cpu().numpy(), lens.cpu().numpy(), V - 1)
     assert gh == rh
     np.testing.assert_allclose(gs.cpu().numpy(), rs, rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "ctc_align_*.npz"))))
+def test_forced_align_matches_reference(path):
+    import wenet_celoss_amd as w
+    d = np.load(path)
+    ali = w.forced_align(torch.tensor(d["ctc_probs"], device=DEV), torch.tensor(d["y"], device=DEV))
+    assert ali == list(d["alignment"])
+
+
+def test_forced_align_batch_and_scale():
+    import wenet_celoss_amd as w
+    rng = np.random.default_rng(3)
+    B, T, S, V = 3, 400, 120, 500
+    logits = (rng.normal(size=(B, T, V)) * 2).astype(np.float32)
+    y = rng.integers(1, V, size=(B, S))
+    il = np.array([400, 333, 260]); tl = np.array([120, 50, 77])
+    got = w.forced_align_batch(torch.tensor(logits, device=DEV), torch.tensor(y, device=DEV), torch.tensor(il),
+                               torch.tensor(tl))
+    lp = do.log_softmax(logits)
+    for b in range(B):
+        ref = do.forced_align(lp[b, :il[b]], y[b, :tl[b]])
+        assert got[b] == ref
+        # an alignment collapses (duplicates, blanks removed) to the label sequence
+        col, prev = [], None
+        for a in got[b]:
+            if a != prev and a != 0:
+                col.append(a)
+            prev = a
+        assert col == list(y[b, :tl[b]])

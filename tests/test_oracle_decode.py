@@ -131,3 +131,9 @@ def test_ctc_prefix_known_answer_from_reference_gtest():
     for k, (pref, sc) in enumerate(nb):
         assert list(pref) == list(d["nbest"][k][: d["nbest_lens"][k]])
         assert math.exp(sc) == pytest.approx(float(d["likelihood"][k]), rel=1e-4)
+
+
+@pytest.mark.parametrize("name", names("ctc_align_*.npz"))
+def test_forced_align(name):
+    d = load(name)
+    assert do.forced_align(d["ctc_probs"], d["y"]) == list(d["alignment"])

@@ -7,7 +7,7 @@ libwr_mi355x.so (include/wr_api.h).  There is no CPU fallback.
 """
 from . import _lib  # noqa: F401
 from .rnnt_loss import rnnt_loss, RNNTLoss  # noqa: F401
-from .ctc import CTC, ctc_loss, ctc_greedy_search, ctc_prefix_beam_search  # noqa: F401
+from .ctc import CTC, ctc_loss, ctc_greedy_search, ctc_prefix_beam_search, forced_align, forced_align_batch  # noqa: F401
 from .joint import TransducerJoint, joint_logits  # noqa: F401
 from .predictor import RNNPredictor  # noqa: F401
 from .search.greedy_search import basic_greedy_search  # noqa: F401
@@ -17,4 +17,4 @@ from .common import IGNORE_ID, add_blank, log_add  # noqa: F401
 
 __all__ = ["rnnt_loss", "RNNTLoss", "CTC", "ctc_loss", "TransducerJoint", "joint_logits", "RNNPredictor",
            "basic_greedy_search", "PrefixBeamSearch", "Sequence", "Transducer", "IGNORE_ID", "add_blank", "log_add",
-           "ctc_greedy_search", "ctc_prefix_beam_search"]
+           "ctc_greedy_search", "ctc_prefix_beam_search", "forced_align", "forced_align_batch"]

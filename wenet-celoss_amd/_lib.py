@@ -108,6 +108,8 @@ SIGNATURES = {
     "wr_greedy_search_chunk": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "wr_prefix_beam_search": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "wr_predictor_step": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "wr_ctc_align_workspace_bytes": (_sz, [_i, _i, _i]),
+    "wr_ctc_forced_align": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "wr_ctc_decode_workspace_bytes": (_sz, [_i, _i, _i]),
     "wr_ctc_greedy_search": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "wr_ctc_prefix_beam_search": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void ctc_lse_kernel(
     const float *__restrict__ logits, const int32_t *__restrict__ targets,
     const int32_t *__restrict__ ilens, const int32_t *__restrict__ tlens,
     int B, int Tmax, int Smax, int V, int blank,
-    float *__restrict__ denom, float *__restrict__ lp_blank, float *__restrict__ lp_label)
+    float *__restrict__ denom, float *__restrict__ lp_blank, float *__restrict__ lp_label, int normalized = 0)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void ctc_lse_kernel(
         const int t = (int)(r - (long)b * Tmax);
         if (t >= ilens[b]) continue;
         const float *row = logits + (size_t)r * V;
-        const float d = wave_row_lse_cached(row, V, lane);
+        const float d = normalized ? 0.f : wave_row_lse_cached(row, V, lane);
         int S = tlens[b];
         S = S < 0 ? 0 : (S > Smax ? Smax : S);
         if (lane == 0) {
@@ -292,6 +292,69 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
     for (int v = tid; v < V; v += nt) grow[v] = srow[v];
 }
 
+// ------------------------------------------------------- forced alignment --
+// Viterbi over the same T x (2S+1) lattice: wenet/utils/ctc_util.py:27-83.
+// One workgroup per utterance, one lane per state, fp32 like the reference; ties prefer the first candidate
+// [s, s-1, s-2] (torch.argmax).  Quirk kept: for s = 0 the reference reads log_alpha[t-1, s-1] with s-1 = -1,
+// i.e. the LAST state (Python negative index) -- reproduced by wrapping.
+__global__ __launch_bounds__(512) void ctc_viterbi_kernel(
+    const float *__restrict__ lp_blank, const float *__restrict__ lp_label, const int32_t *__restrict__ targets,
+    const int32_t *__restrict__ ilens, const int32_t *__restrict__ tlens, int Tmax, int Smax, int SP, int blank,
+    int16_t *__restrict__ backptr /* [B][Tmax][SP] */, int32_t *__restrict__ align /* [B][Tmax] */)
+{
+    __shared__ float prev[2][512];
+    __shared__ int s_state;
+    const int b = blockIdx.x, s = threadIdx.x;
+    int T = ilens[b], S = tlens[b];
+    T = T < 0 ? 0 : (T > Tmax ? Tmax : T);
+    S = S < 1 ? 1 : (S > Smax ? Smax : S);
+    const int NS = 2 * S + 1;
+    const float NEG = -__builtin_huge_valf();
+    const float *lpb = lp_blank + (size_t)b * Tmax;
+    const float *lpl = lp_label + (size_t)b * Tmax * Smax;
+    int16_t *bp = backptr + (size_t)b * Tmax * SP;
+    for (int t = s; t < Tmax; t += blockDim.x) align[(size_t)b * Tmax + t] = -1;
+    if (T == 0) return;
+    const bool live = s < NS;
+    const bool is_label = live && (s & 1);
+    const int li = is_label ? (s >> 1) : 0;
+    const int my_tok = is_label ? targets[(size_t)b * Smax + li] : blank;
+    // two-candidate rule of the reference: blank, s < 2, or same label as s-2
+    bool two_only = true;
+    if (is_label && s >= 2) two_only = (my_tok == blank) || (my_tok == targets[(size_t)b * Smax + li - 1]);
+    auto lp_at = [&](int t) -> float { return is_label ? lpl[(size_t)t * Smax + li] : lpb[t]; };
+    prev[0][s] = (live && s <= 1) ? lp_at(0) : NEG;
+    __syncthreads();
+    int cur = 0;
+    for (int t = 1; t < T; ++t) {
+        if (live) {
+            const int s1 = (s >= 1) ? s - 1 : NS - 1;              // s-1 = -1 wraps to the last state
+            float best = prev[cur][s];
+            int arg = s;
+            const float c1 = prev[cur][s1];
+            if (c1 > best) { best = c1; arg = s1; }
+            if (!two_only) {
+                const float c2 = prev[cur][s - 2];
+                if (c2 > best) { best = c2; arg = s - 2; }
+            }
+            prev[cur ^ 1][s] = best + lp_at(t);
+            bp[(size_t)t * SP + s] = (int16_t)arg;
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (s == 0) {
+        const float a = prev[cur][NS - 1], c = prev[cur][NS - 2];
+        int st = (c > a) ? NS - 2 : NS - 1;
+        for (int t = T - 1; t >= 0; --t) {
+            const int tok = (st & 1) ? targets[(size_t)b * Smax + (st >> 1)] : blank;
+            align[(size_t)b * Tmax + t] = tok;
+            if (t > 0) st = bp[(size_t)t * SP + st];
+        }
+        s_state = st;
+    }
+}
+
 int ctc_check(int B, int Tmax, int Smax, int V, int blank)
 {
     WR_REQUIRE(B > 0 && Tmax > 0 && Smax >= 0 && V > 0, WR_EINVAL,
@@ -378,5 +441,40 @@ extern "C" int wr_ctc_loss_bwd(const void *logits_d, int dtype, const int32_t *t
                        reinterpret_cast<const double *>(ws + w.beta_off),
                        reinterpret_cast<const double *>(ws + w.nll_off), grad_nll_d, static_cast<float *>(grads_d));
     WR_CHECK_LAUNCH("ctc_grad_kernel");
+    return WR_OK;
+}
+
+extern "C" size_t wr_ctc_align_workspace_bytes(int B, int Tmax, int Smax)
+{
+    if (B <= 0 || Tmax <= 0 || Smax <= 0) return 0;
+    const CtcWs w = ctc_ws_layout(B, Tmax, Smax);
+    return w.total + align_up((size_t)B * Tmax * w.SP * sizeof(int16_t), 256);
+}
+
+extern "C" int wr_ctc_forced_align(const float *logits_d, int normalized, const int32_t *targets_d,
+                                   const int32_t *input_lengths_d, const int32_t *target_lengths_d, int B, int Tmax,
+                                   int Smax, int V, int blank, int32_t *alignment_d, void *workspace_d,
+                                   size_t workspace_bytes, void *stream)
+{
+    if (int rc = ctc_check(B, Tmax, Smax, V, blank)) return rc;
+    WR_REQUIRE(Smax >= 1, WR_EINVAL, "ctc_forced_align: empty label sequences cannot be aligned");
+    WR_REQUIRE(logits_d && targets_d && input_lengths_d && target_lengths_d && alignment_d && workspace_d, WR_EINVAL,
+               "ctc_forced_align: null pointer argument");
+    const CtcWs w = ctc_ws_layout(B, Tmax, Smax);
+    const size_t need = w.total + align_up((size_t)B * Tmax * w.SP * sizeof(int16_t), 256);
+    WR_REQUIRE(workspace_bytes >= need, WR_EWORKSPACE, "ctc_forced_align: workspace %zu < required %zu", workspace_bytes, need);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char *ws = static_cast<char *>(workspace_d);
+    const long nrows = (long)B * Tmax;
+    long blocks = (nrows + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(ctc_lse_kernel, dim3((int)blocks), dim3(256), 0, st, logits_d, targets_d, input_lengths_d,
+                       target_lengths_d, B, Tmax, Smax, V, blank, reinterpret_cast<float *>(ws + w.denom_off),
+                       reinterpret_cast<float *>(ws + w.lpb_off), reinterpret_cast<float *>(ws + w.lpl_off), normalized);
+    WR_CHECK_LAUNCH("ctc_lse_kernel");
+    hipLaunchKernelGGL(ctc_viterbi_kernel, dim3(B), dim3(64 * w.KS), 0, st, reinterpret_cast<const float *>(ws + w.lpb_off),
+                       reinterpret_cast<const float *>(ws + w.lpl_off), targets_d, input_lengths_d, target_lengths_d, Tmax,
+                       Smax, w.SP, blank, reinterpret_cast<int16_t *>(ws + w.total), alignment_d);
+    WR_CHECK_LAUNCH("ctc_viterbi_kernel");
     return WR_OK;
 }

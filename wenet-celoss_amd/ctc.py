@@ -138,6 +138,37 @@ def ctc_prefix_beam_search(logits: torch.Tensor, lens: torch.Tensor, beam_size: 
     return [[(tuple(hc[b, e, :lc[b][e]].tolist()), scc[b][e]) for e in range(nc[b])] for b in range(B)]
 
 
+def forced_align(ctc_probs: torch.Tensor, y: torch.Tensor, blank_id: int = 0) -> list:
+    """wenet/utils/ctc_util.py:27-83: ctc_probs (T, D) log-posteriors, y (L,) label ids -> per-frame token list."""
+    return forced_align_batch(ctc_probs.unsqueeze(0), y.reshape(1, -1), torch.tensor([ctc_probs.size(0)]),
+                              torch.tensor([y.numel()]), blank_id=blank_id, normalized=True)[0]
+
+
+def forced_align_batch(logits: torch.Tensor, targets: torch.Tensor, input_lengths: torch.Tensor,
+                       target_lengths: torch.Tensor, blank_id: int = 0, normalized: bool = False) -> list:
+    """Extension: B utterances at once.  logits (B, T, V) pre-softmax (or log-posteriors with normalized=True)."""
+    if not logits.is_cuda:
+        raise RuntimeError("wenet_celoss_amd.forced_align: tensors must live on a HIP device (no CPU path)")
+    lib = _lib.load()
+    x = logits.detach().float().contiguous()
+    B, T, V = x.shape
+    dev = x.device
+    tg = targets.to(device=dev, dtype=torch.int32)
+    tg = torch.where(tg < 0, torch.zeros_like(tg), tg).contiguous()
+    S = tg.shape[1]
+    il = input_lengths.to(device=dev, dtype=torch.int32).contiguous()
+    tl = target_lengths.to(device=dev, dtype=torch.int32).contiguous()
+    wsb = lib.wr_ctc_align_workspace_bytes(B, T, S)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    ali = torch.empty(B, T, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.wr_ctc_forced_align(_lib.ptr(x), int(normalized), _lib.ptr(tg), _lib.ptr(il), _lib.ptr(tl), B, T, S, V,
+                                     int(blank_id), _lib.ptr(ali), _lib.ptr(ws), wsb, _lib.current_stream(dev))
+    _lib.check(rc, "wr_ctc_forced_align")
+    ac, ilc = ali.cpu(), il.cpu().tolist()
+    return [ac[b, :ilc[b]].tolist() for b in range(B)]
+
+
 class CTC(torch.nn.Module):
     """CTC module (wenet/transformer/ctc.py:21-84)."""
 
