@@ -369,6 +369,49 @@ def gen_ctc_align():
         save(f"ctc_align_{i}", ctc_probs=lp.numpy(), y=y.numpy(), alignment=np.array([int(a) for a in ali], np.int64))
 
 
+def gen_greedy_fork():
+    """The fork's hot-word greedy variants, wenet/transducer/search/greedy_search.py:34-176 (`basic_greedy_search`,
+    loss_mode 'pred') and :297-430 (`basic_greedy_search_both`, the default loss_mode 'both'), context filter on
+    and off, run with the reference's predictor / joiner and the stand-in hot-word module tests/bias_stub.py."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from bias_stub import TinyBias
+    from wenet.transducer.search import greedy_search as gs
+    V, E, P, J, H = 64, 16, 16, 32, 16
+    cases = [dict(seed=500, T=30, mode="both", filt="on", gb=0.0), dict(seed=501, T=40, mode="both", filt="off", gb=0.0),
+             dict(seed=502, T=30, mode="pred", filt="on", gb=0.0), dict(seed=503, T=25, mode="pred", filt="off", gb=0.0),
+             dict(seed=504, T=50, mode="both", filt="on", gb=-0.5), dict(seed=505, T=50, mode="pred", filt="on", gb=0.5)]
+    for i, c in enumerate(cases):
+        for attempt in range(400):
+            seed = c["seed"] + 1000 * attempt
+            pred, joint, _ = build_decode_modules(seed, V, E, P, J, H, 2, blank_bias=10.0, weight_scale=2.0)
+            bias = TinyBias(V, E, P, seed=seed, gate_bias=c["gb"]).eval()
+            model = types.SimpleNamespace(blank=0, predictor=pred, joint=joint, context_bias=bias)
+            g = torch.Generator().manual_seed(seed + 7)
+            enc = dyadic((1, c["T"], E), g, scale=8, lim=2.0)
+            ctx = torch.randint(1, V, (3, 4), generator=g)
+            ctx_len = torch.tensor([4, 4, 4], dtype=torch.int32)
+            labels = torch.randint(0, 2, (1, 12), generator=g)
+            fn = gs.basic_greedy_search_both if c["mode"] == "both" else gs.basic_greedy_search
+            try:
+                with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+                    out = fn(model, enc, torch.tensor(c["T"]), ctx, ctx_len, n_steps=64,
+                             context_filter_state=c["filt"], context_decoder_labels_padded=labels)
+            except IndexError:
+                continue                    # the reference's own go-back bookkeeping can pop from an empty list
+            hyps, dist = out[0], out[1]
+            trace = out[2] if len(out) > 2 else None
+            if len(hyps[0]) >= 4 and (c["filt"] == "off" or attempt > 50 or dist != len(labels[0])):
+                break
+        else:
+            raise AssertionError(f"no usable seed for fork greedy case {i}")
+        print(f"  fork greedy case {i}: seed {seed}, {len(hyps[0])} tokens, dist {dist}")
+        save(f"greedy_fork_{i}", enc=enc.numpy(), T=np.array(c["T"]), mode=np.array(c["mode"]), filt=np.array(c["filt"]),
+             gate_bias=np.array(c["gb"]), seed=np.array(seed), ctx=ctx.numpy(), ctx_len=ctx_len.numpy(), labels=labels.numpy(),
+             hyp=np.array(hyps[0], np.int64), dist=np.array(float(dist)),
+             trace=np.array(trace if trace is not None else [], np.int64), n_layers=np.array(2), hidden=np.array(H),
+             **{"pred_" + k: v for k, v in sd(pred).items()}, **{"joint_" + k: v for k, v in sd(joint).items()})
+
+
 def gen_common():
     from wenet.utils.common import add_blank, log_add
     ys = torch.tensor([[1, 2, 3, 4, 5], [4, 5, 6, -1, -1], [7, 8, 9, -1, -1]])
@@ -399,3 +442,4 @@ if __name__ == "__main__":
     gen_beam()
     gen_ctc_decode()
     gen_ctc_align()
+    gen_greedy_fork()

@@ -218,3 +218,39 @@ def test_streaming_chunks_equal_offline_and_reference_quirk():
         for i in range(3):
             outs[i] += res[i]
     assert outs[0] == list(d["hyp"])
+
+
+@pytest.mark.parametrize("path", names("greedy_fork_*.npz"))
+def test_fork_hotword_greedy_matches_reference(path):
+    """The fork's greedy variants (greedy_search.py:34-176 'pred', :297-430 'both'; context filter on/off):
+    tokens, the edit distance and (for 'pred') the gate trace equal what the reference's loops produced with the
+    same stand-in hot-word module (tests/bias_stub.py)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from bias_stub import TinyBias
+    import wenet_celoss_amd as w
+    d = np.load(path)
+    pred, joint, _ = build_modules(d)
+    bias = TinyBias(64, 16, 16, seed=int(d["seed"]), gate_bias=float(d["gate_bias"])).to(DEV).eval()
+    mode = str(d["mode"])
+    m = w.Transducer(64, 0, torch.nn.Identity(), pred, joint, context_bias=bias, ctc_weight=0.0, transducer_weight=1.0,
+                     loss_mode=mode)
+    enc = torch.tensor(d["enc"], device=DEV)
+    ctx, ctx_len, labels = torch.tensor(d["ctx"]), torch.tensor(d["ctx_len"]), torch.tensor(d["labels"])
+    fn = w.basic_greedy_search_both if mode == "both" else w.basic_greedy_search_hw
+    out = fn(m, enc, torch.tensor(int(d["T"])), ctx, ctx_len, n_steps=64, context_filter_state=str(d["filt"]),
+             context_decoder_labels_padded=labels)
+    assert out[0] == [list(d["hyp"])]
+    assert out[1] == float(d["dist"])
+    if mode == "pred":
+        assert list(out[2]) == list(d["trace"])
+    # through the model entry point (transducer.py:515-598)
+
+    class Enc(torch.nn.Module):
+        def forward(self, speech, lens, a=-1, b=-1):
+            return enc, torch.ones(1, 1, int(d["T"]), dtype=torch.bool, device=DEV)
+    m.encoder = Enc()
+    hyps, dist = m.greedy_search(torch.zeros(1, int(d["T"]), 8, device=DEV), torch.tensor([int(d["T"])]), context_list=ctx,
+                                 context_lengths=ctx_len, context_filter_state=str(d["filt"]),
+                                 context_decoder_labels_padded=labels)
+    assert hyps == [list(d["hyp"])] and dist == float(d["dist"])

@@ -35,3 +35,124 @@ def basic_greedy_search(model: torch.nn.Module, encoder_out: torch.Tensor, encod
             pass
     dec = cache.get(model.predictor, model.joint, lanes=N, utts=N, tmax=T, max_hyp=T * n_steps, beam=1)
     return dec.greedy(encoder_out, lens, n_steps=n_steps, blank=model.blank)
+
+
+# ------------------------------------------------------------------------------------------------
+# The fork's hot-word variants: wenet/transducer/search/greedy_search.py
+#   basic_greedy_search       :34-176   loss_mode 'pred'  -> ([hyps], dist, gate trace)
+#   basic_greedy_search_both  :297-430  loss_mode 'both'  -> ([hyps], dist)
+# Host-driven, one utterance, exactly the reference's control flow: a hot-word gate (top-1 of the ContextBias
+# classifier) per predictor step, and with context_filter_state == 'on' a "go-back" -- when the gate flips
+# 0 -> 1 the decoder rewinds to the frame of the last gate-0 step, drops that step's token and re-decodes with
+# biasing forced on until the frame where the flip was seen.  The per-step arithmetic runs on the HIP step
+# kernels (predictor.forward_step, joint); the ContextBias object is whatever module the caller attached
+# (stock PyTorch).  Differences from the reference: nothing is printed to stdout (:363,:428-429 print tensors).
+def edit_distance(a, b) -> float:
+    """Levenshtein distance (greedy_search.py:6-32), returned as float like the reference's numpy cell."""
+    m, n = len(a), len(b)
+    prev = list(range(n + 1))
+    for i in range(1, m + 1):
+        cur = [i] + [0] * n
+        for j in range(1, n + 1):
+            cost = 0 if int(a[i - 1]) == int(b[j - 1]) else 1
+            cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + cost)
+        prev = cur
+    return float(prev[n])
+
+
+def _hotword_greedy(model, encoder_out, encoder_out_lens, context_list, context_lengths, n_steps, filter_on, labels,
+                    both: bool):
+    dev = encoder_out.device
+    cb = model.context_bias
+    padding = torch.zeros(1, 1, device=dev)
+    tok = torch.tensor([[model.blank]], device=dev)
+    cache = model.predictor.init_state(1, method="zero", device=dev)
+    new_cache = cache
+    hidden = cb.forward_bias_hidden(context_list, context_lengths)
+    hidden_none = cb.forward_bias_hidden(torch.zeros((1, 1), dtype=torch.int), context_lengths[0].unsqueeze(0))
+    enc_plain = encoder_out.clone()
+    enc_hot, enc_hot_feat = cb.forward_encoder_bias(hidden, encoder_out)
+    enc_cold, _ = cb.forward_encoder_bias(hidden_none, enc_plain)
+
+    T = int(encoder_out_lens)
+    t, emitted_in_frame = 0, 0
+    stepped_last = True                    # "previous output was not blank": the predictor must step
+    rewinding, rewind_until, frame_of_last_zero = False, -1, 0
+    hyps, gates = [], []
+    outs, caches, inputs = [], [], []      # one record per predictor step, for the go-back
+    pred_out = None
+    while t < T:
+        if stepped_last:
+            pred_out, new_cache = model.predictor.forward_step(tok, padding, cache)
+            outs.append(pred_out); caches.append(cache); inputs.append(tok)
+            if both:
+                raw = pred_out.clone()
+                pred_out, pred_feat = cb.forward_predictor_bias(hidden, pred_out)
+                gate = int(cb.forward_hw_pred_both(enc_hot_feat[:, t:t + 1, :], pred_feat).squeeze().topk(1).indices.item())
+                use_filter = filter_on
+            else:
+                probe, _ = cb.forward_predictor_bias(hidden, pred_out)
+                use_filter = filter_on
+                gate = int(cb.forward_hw_pred(hidden, probe).squeeze().topk(1).indices.item()) if filter_on else 1
+            if use_filter:
+                if not rewinding:
+                    if gate == 0:
+                        gates.append(0)
+                        frame_of_last_zero = t
+                    elif gates and gates[-1] == 0:
+                        # go back: forget the gate-0 step and its token, resume from its frame with biasing on
+                        rewind_until, t, rewinding = t, frame_of_last_zero, True
+                        gates.pop(); hyps.pop(); inputs.pop()
+                        emitted_in_frame -= 1
+                        outs.pop(); caches.pop()
+                        pred_out, cache, tok = outs[-1], caches[-1], inputs[-1]
+                        continue
+                    else:
+                        gates.append(1)
+                else:
+                    gates.append(1)
+                    if t >= rewind_until:
+                        rewinding = False
+            else:
+                gates.append(1)
+            if both:
+                if gates[-1] == 0:
+                    pred_out, _ = cb.forward_predictor_bias(hidden_none, raw)
+            else:
+                # (sic) the 'pred' variant biases with the EMPTY list when the gate is 1, greedy_search.py:145-148
+                pred_out, _ = cb.forward_predictor_bias(hidden_none if gates[-1] == 1 else hidden, pred_out)
+        enc_step = (enc_hot if gates[-1] == 1 else enc_cold)[:, t:t + 1, :]
+        k = int(model.joint(enc_step.contiguous(), pred_out.contiguous()).log_softmax(dim=-1).argmax(dim=-1).squeeze().item())
+        if k != model.blank:
+            hyps.append(k)
+            stepped_last = True
+            emitted_in_frame += 1
+            tok = torch.tensor([[k]], device=dev)
+            cache = new_cache
+        if k == model.blank or emitted_in_frame >= n_steps:
+            if k == model.blank:
+                stepped_last = False
+            t += 1
+            emitted_in_frame = 0
+    lab = labels.squeeze(0) if torch.is_tensor(labels) else labels
+    return [hyps], edit_distance(lab.tolist() if torch.is_tensor(lab) else lab, gates), gates
+
+
+def basic_greedy_search_both(model, encoder_out, encoder_out_lens, context_list=torch.IntTensor([0]),
+                             context_lengths=torch.IntTensor([0]), n_steps: int = 64,
+                             context_filter_state: str = "off",
+                             context_decoder_labels_padded=torch.IntTensor([0])):
+    """greedy_search.py:297-430 -> ([hyps], dist)"""
+    with torch.no_grad():
+        h, dist, _ = _hotword_greedy(model, encoder_out, encoder_out_lens, context_list, context_lengths, n_steps,
+                                     context_filter_state == "on", context_decoder_labels_padded, both=True)
+    return h, dist
+
+
+def basic_greedy_search_hw(model, encoder_out, encoder_out_lens, context_list=torch.IntTensor([0]),
+                           context_lengths=torch.IntTensor([0]), n_steps: int = 64, context_filter_state: str = "off",
+                           context_decoder_labels_padded=torch.IntTensor([0])):
+    """The fork's `basic_greedy_search` (loss_mode 'pred'), greedy_search.py:34-176 -> ([hyps], dist, gate trace)."""
+    with torch.no_grad():
+        return _hotword_greedy(model, encoder_out, encoder_out_lens, context_list, context_lengths, n_steps,
+                               context_filter_state == "on", context_decoder_labels_padded, both=False)

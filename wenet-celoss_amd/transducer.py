@@ -15,9 +15,9 @@ What runs where
   (stock PyTorch-ROCm; out of scope).
 
 `context_bias` may be None (no hot words); when a ContextBias module is given it
-is called exactly where the reference calls it in `forward`.  The fork's
-hot-word greedy variants are not accelerated yet:
-`greedy_search` with a context_bias raises.
+is called exactly where the reference calls it in `forward`, and `greedy_search`
+dispatches on `loss_mode` to the fork's hot-word variants (host-driven control flow
+over the HIP step kernels).
 """
 from __future__ import annotations
 
@@ -30,7 +30,7 @@ from torch.nn.utils.rnn import pad_sequence
 from .common import IGNORE_ID, LabelSmoothingLoss, add_blank, add_sos_eos, end_blank, reverse_pad_list
 from .decoder import DecoderCache
 from .rnnt_loss import rnnt_loss
-from .search.greedy_search import basic_greedy_search
+from .search.greedy_search import basic_greedy_search, basic_greedy_search_both, basic_greedy_search_hw
 from .search.prefix_beam_search import PrefixBeamSearch
 
 
@@ -315,13 +315,20 @@ class Transducer(nn.Module):
         assert speech.shape[0] == speech_lengths.shape[0]
         assert decoding_chunk_size != 0
         _ = simulate_streaming
-        if self.context_bias is not None:
-            raise NotImplementedError("greedy_search with a ContextBias module (hot-word gating / go-back, "
-                                      "greedy_search.py:34-430) is not built yet: SURVEY.md section 8f item 3")
         encoder_out, encoder_mask = self.encoder(speech, speech_lengths, decoding_chunk_size, num_decoding_left_chunks)
         encoder_out_lens = encoder_mask.squeeze(1).sum()
-        hyps = basic_greedy_search(self, encoder_out, encoder_out_lens, n_steps=n_steps)
-        return hyps, 0
+        if self.context_bias is None:                       # no hot-word module: the variants reduce to the core loop
+            return basic_greedy_search(self, encoder_out, encoder_out_lens, n_steps=n_steps), 0
+        if self.loss_mode == "pred":                        # transducer.py:559-567
+            hyps, dist, _ = basic_greedy_search_hw(self, encoder_out, encoder_out_lens, context_list, context_lengths,
+                                                   n_steps=n_steps, context_filter_state=context_filter_state,
+                                                   context_decoder_labels_padded=context_decoder_labels_padded)
+            return hyps, dist
+        # loss_mode 'both' (the default) -- and the reference's final `else` branch, which calls the same function
+        # but assigns its (hyps, dist) tuple to `hyps` (transducer.py:589-597, a latent bug); we return (hyps, dist)
+        return basic_greedy_search_both(self, encoder_out, encoder_out_lens, context_list, context_lengths,
+                                        n_steps=n_steps, context_filter_state=context_filter_state,
+                                        context_decoder_labels_padded=context_decoder_labels_padded)
 
     def greedy_search_batch(self, speech: torch.Tensor, speech_lengths: torch.Tensor, decoding_chunk_size: int = -1,
                             num_decoding_left_chunks: int = -1, n_steps: int = 64) -> List[List[int]]:
