@@ -91,3 +91,27 @@ def test_transducer_constructor_contract():
     for k in ("joint.enc_ffn.weight", "joint.pred_ffn.bias", "joint.ffn_out.weight", "ctc.ctc_lo.weight",
               "predictor.embed.weight", "predictor.rnn.weight_ih_l0", "predictor.projection.bias"):
         assert k in keys                                   # reference checkpoints' parameter names
+
+
+class _ScriptableEncoder(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.proj = torch.nn.Linear(8, 12)
+
+    def forward(self, xs: torch.Tensor, xs_lens: torch.Tensor, decoding_chunk_size: int = 0,
+                num_decoding_left_chunks: int = -1):
+        mask = (torch.arange(xs.size(1))[None, :] < xs_lens[:, None]).unsqueeze(1)
+        return torch.tanh(self.proj(xs)), mask
+
+
+def test_model_survives_train_py_script_export(tmp_path):
+    """wenet/bin/train.py:203-205 does `torch.jit.script(model).save(init.zip)` on rank 0 before training; the
+    HIP-backed forwards are marked @torch.jit.unused (as the reference's own k2 variant does,
+    transducer_k2_loss.py:80) so that the unchanged train.py gets past this smoke export."""
+    import wenet_celoss_amd as w
+    m = w.Transducer(23, 0, _ScriptableEncoder(), w.RNNPredictor(23, 10, 10, 0.0, 14, 2, dropout=0.0),
+                     w.TransducerJoint(23, 12, 10, 16), ctc=w.CTC(23, 12), ctc_weight=0.3, transducer_weight=0.7,
+                     hw_weight=0.0)
+    sm = torch.jit.script(m)
+    sm.save(str(tmp_path / "init.zip"))
+    assert (tmp_path / "init.zip").stat().st_size > 0

@@ -179,6 +179,7 @@ class CTC(torch.nn.Module):
         self.ctc_lo = torch.nn.Linear(eprojs, odim)
         self.reduction_type = "sum" if reduce else "none"
 
+    @torch.jit.unused      # backed by a ctypes autograd Function: opaque to TorchScript (train.py:203-205 smoke export)
     def forward(self, hs_pad: torch.Tensor, hlens: torch.Tensor, ys_pad: torch.Tensor,
                 ys_lens: torch.Tensor) -> torch.Tensor:
         """hs_pad (B, Tmax, D), hlens (B), ys_pad (B, Lmax) padded with -1, ys_lens (B)."""

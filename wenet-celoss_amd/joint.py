@@ -127,6 +127,7 @@ class TransducerJoint(nn.Module):
         self.post_ffn: Optional[nn.Linear] = None
         self.ffn_out = nn.Linear(join_dim, voca_size)
 
+    @torch.jit.unused      # backed by a ctypes autograd Function: opaque to TorchScript (train.py:203-205 smoke export)
     def forward(self, enc_out: torch.Tensor, pred_out: torch.Tensor,
                 logit_lengths: Optional[torch.Tensor] = None,
                 target_lengths: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -90,7 +90,8 @@ class Transducer(nn.Module):
                          rnnt_text_lengths.contiguous(), blank=self.blank, reduction="mean")
         return joint_out, loss
 
-    def forward(self, speech: torch.Tensor, speech_lengths: torch.Tensor, text: torch.Tensor,
+    @torch.jit.unused      # wenet/bin/train.py:203-205 scripts the model as an export smoke test; the HIP-backed forward
+    def forward(self, speech: torch.Tensor, speech_lengths: torch.Tensor, text: torch.Tensor,  # is opaque to TorchScript
                 text_lengths: torch.Tensor, context_list: torch.Tensor = torch.IntTensor([0]),
                 context_lengths: torch.Tensor = torch.IntTensor([0]), hw_label=torch.IntTensor([0])
                 ) -> Dict[str, Optional[torch.Tensor]]:
