@@ -128,3 +128,27 @@ def test_decode_wrappers_shapes_and_consistency():
     assert o.shape == (1, 1, 10) and c2[0].shape == cache[0].shape
     js = m.forward_joint_step(enc_out[:, :1], o)
     assert js.shape == (1, 1, 1, 23)
+
+
+def test_forward_under_autocast_matches_fp32_within_half_precision():
+    """executor.py:91 runs the forward under torch.cuda.amp.autocast when --use_amp is set: the pre-join / ctc_lo
+    Linear layers then emit fp16; our kernels take fp32 (joiner, CTC: inputs are cast up) or fp16 natively (RNN-T)."""
+    m = build()
+    g = torch.Generator().manual_seed(3)
+    speech = torch.randn(2, 9, 8, generator=g).to(DEV)
+    slen = torch.tensor([9, 6], dtype=torch.int32, device=DEV)
+    text = torch.tensor([[3, 5, 2], [4, 1, -1]], device=DEV)
+    tlen = torch.tensor([3, 2], dtype=torch.int32, device=DEV)
+    ref = m(speech, slen, text, tlen)
+    ref["loss"].backward()
+    gref = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.zero_grad()
+    with torch.autocast(device_type="cuda", dtype=torch.float16):
+        out = m(speech, slen, text, tlen)
+    assert torch.isfinite(out["loss"])
+    out["loss"].float().backward()
+    assert out["loss"].item() == pytest.approx(ref["loss"].item(), rel=5e-3)
+    for n, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+        denom = gref[n].abs().max().item() + 1e-6
+        assert (p.grad.float() - gref[n]).abs().max().item() / denom < 5e-2, n

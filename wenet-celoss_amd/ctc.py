@@ -19,7 +19,9 @@ from . import _lib
 
 
 class _CTCLossFn(torch.autograd.Function):
+    # Under AMP ctc_lo produces fp16/bf16; the reference's log_softmax autocasts to fp32 (ctc.py:60), so do we.
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, logits, targets, input_lengths, target_lengths, blank):
         if not logits.is_cuda:
             raise RuntimeError("wenet_celoss_amd.ctc_loss: logits must live on a HIP device "
@@ -41,6 +43,7 @@ class _CTCLossFn(torch.autograd.Function):
         return nll
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_nll):
         logits, targets, input_lengths, target_lengths, ws = ctx.saved_tensors
         lib = _lib.load()

@@ -26,7 +26,10 @@ from . import _lib
 
 
 class _JointFn(torch.autograd.Function):
+    # Under AMP (executor.py:91 wraps the forward in autocast) the pre-join Linear layers hand over fp16/bf16
+    # activations; the MFMA kernels are exact-fp32, so inputs are cast up and the logits come out fp32.
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, ep, pp, w, b, llens, tlens):
         if not ep.is_cuda:
             raise RuntimeError("wenet_celoss_amd.TransducerJoint: tensors must live on a HIP device "
@@ -49,6 +52,7 @@ class _JointFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, gout):
         ep, pp, w, llens, tlens = ctx.saved_tensors
         lib = _lib.load()
@@ -56,7 +60,7 @@ class _JointFn(torch.autograd.Function):
         U1 = pp.shape[1]
         V = w.shape[0]
         dev = ep.device
-        gout = gout.contiguous()
+        gout = gout.float().contiguous()
         dz = torch.empty(B, T, U1, J, dtype=torch.float32, device=dev)
         need_w = ctx.needs_input_grad[2]
         h = torch.empty_like(dz) if need_w else None

@@ -59,6 +59,7 @@ def _validate(logits, targets, logit_lengths, target_lengths, blank):
 
 class _RNNTLossFn(torch.autograd.Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")          # fp16/bf16 logits are handled natively (fp32 arithmetic inside)
     def forward(ctx, logits, targets, logit_lengths, target_lengths, blank, clamp, inplace_grad):
         if not logits.is_cuda:
             raise RuntimeError("wenet_celoss_amd.rnnt_loss: logits must live on a HIP device "
@@ -79,6 +80,7 @@ class _RNNTLossFn(torch.autograd.Function):
         return costs.to(logits.dtype) if logits.dtype != torch.float32 else costs
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_costs):
         logits, targets, logit_lengths, target_lengths, ws = ctx.saved_tensors
         lib = _lib.load()
