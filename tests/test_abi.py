@@ -72,3 +72,41 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle", src, flags=re.M), f
                 assert "oracle/" not in src, f
+
+
+def test_every_entry_point_rejects_bad_arguments_before_launch(lib):
+    """No GPU needed: argument validation happens before any HIP call, returns a negative code and a message."""
+    import ctypes
+    from wenet_celoss_amd import _lib
+    null = ctypes.c_void_p(None)
+    # CTC: label sequences longer than the sweep supports; vocabulary wider than the gradient kernel's LDS row
+    assert lib.wr_ctc_loss_fwd(null, 0, null, null, null, 2, 10, 300, 50, 0, null, null, 0, null) == -2
+    assert b"255" in lib.wr_last_error()
+    assert lib.wr_ctc_loss_fwd(null, 0, null, null, null, 2, 10, 5, 20000, 0, null, null, 0, null) == -2
+    assert lib.wr_ctc_loss_bwd(null, 0, null, null, null, 2, 10, 5, 50, 0, null, null, null, 0, null) == -1
+    assert lib.wr_ctc_workspace_bytes(2, 10, 5) > 0 and lib.wr_ctc_workspace_bytes(0, 10, 5) == 0
+    # joiner: join_dim limits, missing pointers, half-specified lengths
+    assert lib.wr_joint_fwd(null, null, null, null, null, null, 1, 2, 2, 516, 10, null, null, 0, null) == -2
+    assert b"join_dim" in lib.wr_last_error()
+    assert lib.wr_joint_fwd(null, null, null, null, null, null, 1, 2, 2, 512, 10, null, null, 0, null) == -1
+    assert lib.wr_joint_bwd_dz(null, null, null, null, null, null, 1, 2, 2, 512, 10, null, null, null) == -1
+    assert lib.wr_joint_bwd_dw(null, null, null, null, 1, 2, 2, 512, 10, null, null, null, 0, null) == -1
+    assert lib.wr_joint_workspace_bytes(512, 5000) >= 512 * 5120 * 4
+    assert lib.wr_joint_dw_workspace_bytes(512, 5000) >= 5000 * 512 * 4
+    # decoder: null weights, too many lanes / layers
+    w = _lib.TransducerWeights()
+    assert lib.wr_decoder_workspace_bytes(ctypes.byref(w), 0, 1, 1, 1, 1) == 0
+    handle = ctypes.c_void_p()
+    assert lib.wr_decoder_create(null, 4, 4, 8, 8, 1, null, 0, null, ctypes.byref(handle)) == -1
+    w.vocab_size, w.enc_dim, w.pred_dim, w.embed_dim, w.hidden, w.n_layers, w.join_dim = 50, 8, 8, 8, 8, 9, 16
+    assert lib.wr_decoder_create(ctypes.byref(w), 4, 4, 8, 8, 1, null, 0, null, ctypes.byref(handle)) == -2
+    assert b"n_layers" in lib.wr_last_error()
+    assert lib.wr_decoder_destroy(null) == 0
+    assert lib.wr_greedy_search(null, null, null, 1, 1, 1, 0, null, null, null) == -1
+    assert lib.wr_prefix_beam_search(null, null, null, null, 1, 1, 1, 0.3, 0.7, 0, null, null, null, null, null) == -1
+    assert lib.wr_predictor_step(null, null, null, null, 1, null, null, null, null) == -1
+    # CTC decode modes
+    assert lib.wr_ctc_greedy_search(null, null, 1, 4, 1, 0, 0, null, null, null, null, 0, null) == -1      # V must be > 1
+    assert lib.wr_ctc_prefix_beam_search(null, null, 1, 4, 8, 0, 0, null, null, null, null, null, 0, null) == -1
+    assert lib.wr_ctc_forced_align(null, 0, null, null, null, 1, 4, 0, 8, 0, null, null, 0, null) == -1
+    assert lib.wr_tune_set(99, 1) == -1

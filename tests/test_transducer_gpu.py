@@ -2,6 +2,8 @@
 encoder: the forward dict and every gradient agree with an independent float64
 evaluation (torch autograd for the dense parts, CPU oracle for RNN-T / CTC), and
 the decode wrappers return the reference's shapes."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -152,3 +154,35 @@ def test_forward_under_autocast_matches_fp32_within_half_precision():
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
         denom = gref[n].abs().max().item() + 1e-6
         assert (p.grad.float() - gref[n]).abs().max().item() / denom < 5e-2, n
+
+
+def test_ddp_wrapped_training_step_single_rank_rccl():
+    """Config 4 plumbing: wenet/bin/train.py:227-240 wraps the model in DistributedDataParallel(find_unused_parameters=True)
+    over the nccl (= RCCL) backend.  One rank here (the box has one GPU): the ctypes-backed autograd Functions must
+    work under DDP's reducer hooks and give the same gradients as the bare model."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 1000))
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        m = build()
+        g = torch.Generator().manual_seed(4)
+        speech = torch.randn(2, 10, 8, generator=g).to(DEV)
+        slen = torch.tensor([10, 7], dtype=torch.int32, device=DEV)
+        text = torch.tensor([[3, 5, 2], [4, 1, -1]], device=DEV)
+        tlen = torch.tensor([3, 2], dtype=torch.int32, device=DEV)
+        m(speech, slen, text, tlen)["loss"].backward()
+        ref = {n: p.grad.clone() for n, p in m.named_parameters()}
+        m.zero_grad()
+        ddp = torch.nn.parallel.DistributedDataParallel(m, find_unused_parameters=True)
+        with ddp.join():                                       # executor.py:48-53 uses the uneven-input join context
+            out = ddp(speech, slen, text, tlen)
+            out["loss"].backward()
+        for n, p in m.named_parameters():
+            torch.testing.assert_close(p.grad, ref[n], rtol=1e-5, atol=1e-7, msg=n)
+        # gradient accumulation path (executor.py:81-86)
+        with ddp.no_sync():
+            ddp(speech, slen, text, tlen)["loss"].backward()
+    finally:
+        dist.destroy_process_group()
