@@ -16,15 +16,19 @@
 // (v_mfma_f32_32x32x2_f32) fragments of both operands are plain coalesced 128-byte
 // reads from L2 -- no LDS staging, no transposes between stages:
 //
-//   embed_gather_kernel     xT[k][lane] = embed[token[lane]][k]
-//   lane_gemm_kernel        C^T = A^T-segments x k-major weights (+bias): LSTM gates
-//                           (x W_ih^T + h W_hh^T), projection, pred_ffn, and the joiner
-//                           output ffn_out (row-major logits); 32 output columns per
-//                           workgroup, K split over the 4 waves, LDS only for the final
-//                           4-way reduction
-//   lstm_cell_kernel        gates -> (c, h), predicated per lane ("predictor steps only
-//                           after a non-blank")
-//   joint_act_kernel        ht[j][lane] = tanh(enc_ffn(enc)[utt, t_lane, j] + pp[j][lane])
+//   lane_gemm_kernel        C^T = A^T-segments x k-major weights (+bias), 32 output columns per
+//                           workgroup, K split over the 4 waves, register ping-pong on the L2
+//                           fragment loads, LDS only for the final 4-way reduction.  Five launches
+//                           per micro-step, the elementwise stages fused as epilogues:
+//                             LSTM layer l   gates = x W_ih^T + h W_hh^T -> cell update (c, h),
+//                                            predicated per lane ("predictor steps only after a
+//                                            non-blank"); gate columns permuted so one tile holds
+//                                            i,f,g,o of 8 hidden units
+//                             projection     k-major store
+//                             pred_ffn       -> joiner activation tanh(enc_ffn(enc)[utt,t] + .)
+//                             ffn_out        row-major logits
+//                           (the embedding of a lane's next token is written by the kernel that
+//                           decides the token)
 //   greedy_update_kernel    log-softmax + argmax (first index on ties) + the
 //                           frame/emission state machine + cache commit
 //   beam_topk_kernel /      log-softmax, CTC mixture, top-k in LDS; per-utterance
@@ -79,9 +83,7 @@ struct DevState {
     float *cache_hT, *cache_cT;   // [L][Hp][NLp]  committed LSTM state
     float *new_hT, *new_cT;       // [L][Hp][NLp]  output of the last predictor step
     float *alt_hT, *alt_cT;       // [L][Hp][NLp]  staging for beam reordering
-    float *gatesT;                // [G4p][NLp]
     float *outT;                  // [Pp][NLp]     projected predictor output
-    float *ppT;                   // [Jp][NLp]     pred_ffn(predictor output)
     float *ht;                    // [Jp][NLp]     joiner activation
     float *logits;                // [NL, V]
     int32_t *active_count;        // lanes still decoding
@@ -110,7 +112,17 @@ struct GemmArgs {
     const float *bias;            // [N] or null
     float *C;
     int ldc, N, n_lanes;
+    // epilogues that need lane state (LSTM cell, joiner activation): workspace pointers by value, so that the
+    // kernel reads them from its argument segment instead of chasing them through the device-side state
+    const DevState *st;           // per-call scalars (T, lanes_per_utt)
+    const int32_t *lane_active, *need_pred, *lane_t;
+    const float *cache_cT;        // this layer's committed cell state   [Hp][NLp]
+    float *new_cT, *new_hT;       // this layer's new state
+    const float *ep_all;          // [n_utt, T, J]
+    int H, J;
 };
+
+enum GemmEpilogue { kEpiKMajor = 0, kEpiRowMajor = 1, kEpiLstmCell = 2, kEpiJointAct = 3 };
 
 // ----------------------------------------------------------------- setup --
 // src [R][C] row-major -> dst [C][Rp] (zero padded columns R..Rp-1 and rows C..Cp-1)
@@ -167,122 +179,208 @@ __global__ __launch_bounds__(256) void ep_all_kernel(DevState *s)
 // --------------------------------------------------------- predictor step --
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
-// xT[k][lane] = embed[token[lane]][k]
-__global__ void embed_gather_kernel(DevState *s)
+// LSTM weights: w [4H][K] (nn.LSTM layout, gate-major rows i,f,g,o) -> k-major [Kp][4*Hp] with the gate
+// columns permuted so that every 32-column tile holds i,f,g,o of 8 consecutive hidden units
+// (column c' -> unit (c'/32)*8 + c'%8, gate (c'%32)/8); padded rows/columns are zero.
+__global__ void lstm_weight_prep_kernel(const float *__restrict__ w, int H, int Hp, int K, int Kp, float *__restrict__ dst)
 {
-    const Dims &d = s->d;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = idx % d.NLp, k = idx / d.NLp;
-    if (k >= d.D || lane >= s->n_lanes) return;
-    s->xT[(size_t)k * d.NLp + lane] = s->embed[(size_t)s->token[lane] * d.D + k];
+    const int G4p = 4 * Hp;
+    const long total = (long)Kp * G4p;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i / G4p), c = (int)(i % G4p);
+        const int unit = (c >> 5) * 8 + (c & 7), gate = (c & 31) >> 3;
+        dst[i] = (k < K && unit < H) ? w[(size_t)(gate * H + unit) * K + k] : 0.f;
+    }
+}
+__global__ void lstm_bias_prep_kernel(const float *__restrict__ b_ih, const float *__restrict__ b_hh, int H, int Hp,
+                                      float *__restrict__ dst)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 4 * Hp) return;
+    const int unit = (c >> 5) * 8 + (c & 7), gate = (c & 31) >> 3;
+    dst[c] = unit < H ? b_ih[gate * H + unit] + b_hh[gate * H + unit] : 0.f;
 }
 
-// C = sum over segments of A^T B (+ bias).  grid.x = column tiles of 32; 256 threads = 4 waves, each
-// takes a quarter of every segment's K; MT 32-lane tiles.  ROWMAJOR: C[lane][n] else C^T[n][lane].
-template <int MT, bool ROWMAJOR>
-__global__ __launch_bounds__(256) void lane_gemm_kernel(GemmArgs g)
+// C = sum over segments of A^T B (+ bias).  grid = (column tiles of 32, lane tiles of 32*MT); 512 threads = 8
+// waves, each takes an eighth of every segment's K.  Both operands come straight from L2 / Infinity Cache
+// (k-major, coalesced 128-byte fragments) through a register ping-pong of CH k-steps; with the shipped sizes
+// (K <= 512 per segment) the whole K slice of a wave is in flight before its first MFMA, so a launch pays one
+// memory latency.  Loads are unconditional (clamped rows, masked by a 0/1 factor) so the waits stay counted.
+// Epilogues: k-major store, row-major store (logits), LSTM cell (gate columns are permuted at create time so a
+// 32-column tile holds i,f,g,o of 8 hidden units), joiner activation tanh(enc_ffn(enc)[t] + pred_ffn(pred)).
+constexpr int kGemmWaves = 8;
+constexpr int kMaxVocabPerThread = 160;                 // greedy_update keeps a logits row in registers: V <= 40960
+template <int MT, int EPI>
+__global__ __launch_bounds__(64 * kGemmWaves) void lane_gemm_kernel(GemmArgs g)
 {
-    __shared__ float red[4][MT][32 * 32];
+    __shared__ float red[kGemmWaves][MT][32 * 32];
     const int n0 = blockIdx.x * 32;
+    const int lane0 = blockIdx.y * (32 * MT);                          // first decode lane of this workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
+    constexpr int CH = 16;
+    constexpr int NT = 64 * kGemmWaves;
     f32x16 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = (f32x16){0};
-#pragma unroll
-    for (int seg = 0; seg < 2; ++seg) {
-        const float *__restrict__ As = seg ? g.A1 : g.A0;
-        const float *__restrict__ Bs = seg ? g.B1 : g.B0;
-        const int K = seg ? g.K1 : g.K0;
-        if (As == nullptr || K == 0) continue;
-        const int kq = K / 4, kb = wave * kq;
-        const float *__restrict__ A = As + (size_t)(kb + half) * g.lda + l31;
+    const int kq0 = g.K0 / kGemmWaves, kq1 = (g.A1 != nullptr) ? g.K1 / kGemmWaves : 0;
+    const int nch0 = (kq0 + 2 * CH - 1) / (2 * CH), nch1 = (kq1 + 2 * CH - 1) / (2 * CH);
+    const int nch = nch0 + nch1;
+
+    auto load_chunk = [&](int ci, float (&bv)[CH], float (&av)[MT][CH]) {
+        const bool s1 = ci >= nch0;
+        const int cj = s1 ? ci - nch0 : ci;
+        const int kq = s1 ? kq1 : kq0;
+        const float *__restrict__ As = s1 ? g.A1 : g.A0;
+        const float *__restrict__ Bs = s1 ? g.B1 : g.B0;
+        const int kb = wave * kq;
+        const float *__restrict__ A = As + (size_t)(kb + half) * g.lda + lane0 + l31;
         const float *__restrict__ Bm = Bs + (size_t)(kb + half) * g.ldb + n0 + l31;
-        // The operands come straight from L2: issue a whole chunk of fragment loads before the first MFMA
-        // of the chunk so that ~CH*(MT+1) loads are in flight per lane instead of one dependent load per step.
-        constexpr int CH = (MT <= 2) ? 16 : 8;
-        for (int k0 = 0; k0 < kq; k0 += 2 * CH) {
-            float bv[CH], av[MT][CH];
 #pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                const int k = k0 + 2 * i;
-                const bool ok = k < kq;
-                bv[i] = ok ? Bm[(size_t)k * g.ldb] : 0.f;
+        for (int i = 0; i < CH; ++i) {
+            const int k = cj * 2 * CH + 2 * i;
+            const int kc = k < kq ? k : kq - 2;                         // K >= 16: kq - 2 is a valid row pair
+            const float keep = k < kq ? 1.f : 0.f;
+            bv[i] = Bm[(size_t)kc * g.ldb] * keep;
 #pragma unroll
-                for (int m = 0; m < MT; ++m) av[m][i] = ok ? A[(size_t)k * g.lda + m * 32] : 0.f;
-            }
-#pragma unroll
-            for (int i = 0; i < CH; ++i)
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][i], bv[i], acc[m], 0, 0, 0);
+            for (int m = 0; m < MT; ++m) av[m][i] = A[(size_t)kc * g.lda + m * 32];
         }
+    };
+    auto mfma_chunk = [&](const float (&bv)[CH], const float (&av)[MT][CH]) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][i], bv[i], acc[m], 0, 0, 0);
+    };
+    float pb[CH], pa[MT][CH], qb[CH], qa[MT][CH];
+    load_chunk(0, pb, pa);
+    load_chunk(nch > 1 ? 1 : 0, qb, qa);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // Epilogue operands that do not depend on the GEMM are requested right behind the first two chunks (memory
+    // returns in order, so they must not sit in front of them) and are consumed after the K loop.
+    constexpr int kItems = MT * 1024 / NT;                                // outputs per thread of the 32 x 32*MT tile
+    float bias_v[kItems > 4 ? kItems : 4];
+    bool cell_on = false;
+    int cell_j = 0;
+    size_t cell_o = 0;
+    float cell_c = 0.f;
+    bool act_on[kItems];
+    float act_ep[kItems];
+    if (EPI == kEpiRowMajor) {
+        const int v = n0 + l31;                                          // the column of every item of this thread
+        bias_v[0] = g.bias ? g.bias[v < g.N ? v : g.N - 1] : 0.f;
+    } else if (EPI == kEpiKMajor || EPI == kEpiJointAct) {
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            const int v = n0 + (((tid + it * NT) & 1023) >> 5);
+            bias_v[it] = g.bias ? g.bias[v < g.N ? v : g.N - 1] : 0.f;
+        }
+    }
+    if (EPI == kEpiLstmCell) {
+        const int q = tid & 255;
+        cell_j = q >> 5;
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt) bias_v[gt] = g.bias[n0 + gt * 8 + cell_j];   // bias is padded to 4*Hp
+        const int n = lane0 + ((tid >> 8) % MT) * 32 + l31, unit = (n0 >> 5) * 8 + cell_j;
+        const bool in = tid < MT * 256 && n < g.n_lanes && unit < g.H;
+        cell_o = in ? (size_t)unit * g.lda + n : 0;                     // lda = NLp
+        const int la = g.lane_active[in ? n : 0], np = g.need_pred[in ? n : 0];
+        cell_c = g.cache_cT[cell_o];
+        cell_on = in && la && np;
+    } else if (EPI == kEpiJointAct) {
+        const int T = g.st->T, lpu = g.st->lanes_per_utt;
+        int tt[kItems];
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            const int i = tid + it * NT;
+            const int v = n0 + ((i & 1023) >> 5), n = lane0 + (i >> 10) * 32 + (i & 31);
+            const bool in = n < g.n_lanes && v < g.N;
+            act_on[it] = in && g.lane_active[in ? n : 0];
+            tt[it] = g.lane_t[in ? n : 0];
+        }
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            const int i = tid + it * NT;
+            const int v = n0 + ((i & 1023) >> 5), n = lane0 + (i >> 10) * 32 + (i & 31);
+            const int t = tt[it] < T ? tt[it] : T - 1;
+            act_ep[it] = act_on[it] ? g.ep_all[((size_t)(n / lpu) * T + t) * g.J + v] : 0.f;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int ci = 0;; ci += 2) {
+        mfma_chunk(pb, pa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ci + 1 >= nch) break;
+        load_chunk(ci + 2 < nch ? ci + 2 : ci + 1, pb, pa);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk(qb, qa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ci + 2 >= nch) break;
+        load_chunk(ci + 3 < nch ? ci + 3 : ci + 2, qb, qa);
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * half;       // C/D layout of the 32x32 MFMA
-            red[wave][m][row * 32 + l31] = acc[m][r];
+            red[wave][m][row * 32 + (l31 ^ row)] = acc[m][r];      // XOR swizzle: both epilogue orders are conflict-free
         }
     __syncthreads();
-    if (ROWMAJOR) {
-        for (int i = tid; i < MT * 1024; i += 256) {
-            const int m = i >> 10, rc = i & 1023;
-            const int n = m * 32 + (rc >> 5), v = n0 + (rc & 31);
-            if (n < g.n_lanes && v < g.N) {
-                const float bias = g.bias ? g.bias[v] : 0.f;
-                g.C[(size_t)n * g.ldc + v] = (red[0][m][rc] + red[1][m][rc]) + (red[2][m][rc] + red[3][m][rc]) + bias;
-            }
+    auto total = [&](int m, int ln, int col) {
+        const int rc = ln * 32 + (col ^ ln);
+        return ((red[0][m][rc] + red[1][m][rc]) + (red[2][m][rc] + red[3][m][rc])) +
+               ((red[4][m][rc] + red[5][m][rc]) + (red[6][m][rc] + red[7][m][rc]));
+    };
+    if (EPI == kEpiRowMajor) {
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            const int i = tid + it * NT;
+            const int m = i >> 10, ln = (i & 1023) >> 5, col = i & 31;
+            const int n = lane0 + m * 32 + ln, v = n0 + col;
+            if (n < g.n_lanes && v < g.N) g.C[(size_t)n * g.ldc + v] = total(m, ln, col) + bias_v[0];
         }
-    } else {
-        for (int i = tid; i < MT * 1024; i += 256) {
-            const int m = i >> 10, q = i & 1023;
-            const int col = q >> 5, ln = q & 31;                      // consecutive threads -> consecutive lanes
-            const int rc = ln * 32 + col;
-            const int v = n0 + col, n = m * 32 + ln;
-            if (v < g.N) {
-                const float bias = g.bias ? g.bias[v] : 0.f;
-                g.C[(size_t)v * g.ldc + n] = (red[0][m][rc] + red[1][m][rc]) + (red[2][m][rc] + red[3][m][rc]) + bias;
-            }
+    } else if (EPI == kEpiKMajor) {
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            const int i = tid + it * NT;
+            const int m = i >> 10, col = (i & 1023) >> 5, ln = i & 31;   // consecutive threads -> consecutive lanes
+            const int v = n0 + col, n = lane0 + m * 32 + ln;
+            if (v < g.N) g.C[(size_t)v * g.ldc + n] = total(m, ln, col) + bias_v[it];
+        }
+    } else if (EPI == kEpiLstmCell) {
+        // tile columns: [i x8 | f x8 | g x8 | o x8] of hidden units u0 .. u0+7; only lanes whose predictor steps are
+        // written.  One (lane, unit) per thread.
+        if (cell_on) {
+            const int j = cell_j, ln = l31;
+            const int m = (tid >> 8) % MT;
+            const float ig = sigmoidf_(total(m, ln, j) + bias_v[0]);
+            const float fg = sigmoidf_(total(m, ln, 8 + j) + bias_v[1]);
+            const float gg = tanhf(total(m, ln, 16 + j) + bias_v[2]);
+            const float og = sigmoidf_(total(m, ln, 24 + j) + bias_v[3]);
+            const float c = fg * cell_c + ig * gg;
+            g.new_cT[cell_o] = c;
+            g.new_hT[cell_o] = og * tanhf(c);
+        }
+    } else {   // kEpiJointAct: ht[j][lane] = tanh(ep_all[utt, t_lane, j] + pp[j][lane]); zero for idle lanes
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            const int i = tid + it * NT;
+            const int m = i >> 10, col = (i & 1023) >> 5, ln = i & 31;
+            const int v = n0 + col, n = lane0 + m * 32 + ln;
+            if (v >= g.N) continue;
+            g.C[(size_t)v * g.ldc + n] = act_on[it] ? tanhf(act_ep[it] + total(m, ln, col) + bias_v[it]) : 0.f;
         }
     }
 }
 
-// gates (i, f, g, o rows of gatesT) -> new cell / hidden state; only lanes whose predictor steps are written
-__global__ void lstm_cell_kernel(DevState *s, int layer)
+// xT[:, n] = embed[tok] for one lane (called by the kernels that decide a lane's next token)
+__device__ __forceinline__ void write_embedding_column(DevState *s, int n, int tok)
 {
     const Dims &d = s->d;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = idx % d.NLp, unit = idx / d.NLp;
-    if (unit >= d.H || lane >= s->n_lanes) return;
-    if (!(s->lane_active[lane] && s->need_pred[lane])) return;
-    const float *gt = s->gatesT;
-    const float ig = sigmoidf_(gt[(size_t)unit * d.NLp + lane]);
-    const float fg = sigmoidf_(gt[(size_t)(d.H + unit) * d.NLp + lane]);
-    const float gg = tanhf(gt[(size_t)(2 * d.H + unit) * d.NLp + lane]);
-    const float og = sigmoidf_(gt[(size_t)(3 * d.H + unit) * d.NLp + lane]);
-    const size_t o = ((size_t)layer * d.Hp + unit) * d.NLp + lane;
-    const float c = fg * s->cache_cT[o] + ig * gg;
-    s->new_cT[o] = c;
-    s->new_hT[o] = og * tanhf(c);
-}
-
-// ht[j][lane] = tanh(enc_ffn(enc)[utt, t_lane, j] + pp[j][lane]); zero for idle lanes
-__global__ void joint_act_kernel(DevState *s)
-{
-    const Dims &d = s->d;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = idx % d.NLp, j = idx / d.NLp;
-    if (j >= d.J || lane >= d.NLp) return;
-    float v = 0.f;
-    if (lane < s->n_lanes && s->lane_active[lane]) {
-        const int utt = lane / s->lanes_per_utt;
-        int t = s->lane_t[lane];
-        t = t < s->T ? t : s->T - 1;
-        v = tanhf(s->ep_all[((size_t)utt * s->T + t) * d.J + j] + s->ppT[(size_t)j * d.NLp + lane]);
-    }
-    s->ht[(size_t)j * d.NLp + lane] = v;
+    for (int k = threadIdx.x; k < d.D; k += blockDim.x) s->xT[(size_t)k * d.NLp + n] = s->embed[(size_t)tok * d.D + k];
 }
 
 // ---------------------------------------------------------------- greedy --
@@ -295,7 +393,6 @@ __global__ void greedy_init_kernel(DevState *s)
         const size_t o = (size_t)i * d.NLp + n;
         s->cache_hT[o] = 0.f; s->cache_cT[o] = 0.f; s->new_hT[o] = 0.f; s->new_cT[o] = 0.f;
     }
-    for (int j = tid; j < d.Jp; j += blockDim.x) s->ppT[(size_t)j * d.NLp + n] = 0.f;
     if (tid == 0) {
         const int T = s->enc_lens[n] < s->T ? s->enc_lens[n] : s->T;
         s->token[n] = s->blank;
@@ -308,6 +405,7 @@ __global__ void greedy_init_kernel(DevState *s)
         s->lane_active[n] = act;
         if (act) atomicAdd(s->active_count, 1);
     }
+    write_embedding_column(s, n, s->blank);
 }
 
 // Streaming: start the next chunk of every stream with the state the previous chunk left behind
@@ -334,64 +432,84 @@ __global__ void greedy_chunk_init_kernel(DevState *s, int ref_new_cache)
     }
 }
 
-__global__ __launch_bounds__(256) void greedy_update_kernel(DevState *s)
+// NV = logits held per thread (V <= 256 * NV): the row is read once, all loads in flight together.  The lane's
+// scalars are fetched up front and the state machine runs redundantly in every thread (thread 0 stores), so the
+// kernel has one memory round trip before the reductions and one after.
+template <int NV>
+__global__ __launch_bounds__(256) void greedy_update_kernel(DevState *sp)
 {
     __shared__ float sv[4];
     __shared__ int si[4];
-    __shared__ int s_commit;
-    const Dims &d = s->d;
+    const DevState S = *sp;                         // by value: no reloads of the pointers after the stores below
+    const Dims &d = S.d;
     const int n = blockIdx.x, tid = threadIdx.x;
-    if (!s->lane_active[n]) return;
-    const float *x = s->logits + (size_t)n * d.V;
+    if (!S.lane_active[n]) return;
+    int t = S.lane_t[n], nb = S.noblk[n];
+    const int need = S.need_pred[n];
+    int nic = S.new_is_cache[n];
+    const int len = S.hyp_lens[n];
+    const int enc_len = S.enc_lens[n];
+    const float *x = S.logits + (size_t)n * d.V;
     // log_softmax as the reference evaluates it: (x - max) - log(sum(exp(x - max)))
+    float xv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * 256;
+        xv[i] = v < d.V ? x[v] : -3.0e38f;
+    }
     float m = -3.0e38f;
-    for (int v = tid; v < d.V; v += 256) m = fmaxf(m, x[v]);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) m = fmaxf(m, xv[i]);
     m = block_max(m, sv);
     float sum = 0.f;
-    for (int v = tid; v < d.V; v += 256) sum += expf(x[v] - m);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) sum += (tid + i * 256 < d.V) ? expf(xv[i] - m) : 0.f;
     sum = block_sum(sum, sv);
     const float ls = logf(sum);
     float best = -3.0e38f;
     int bi = 0x7fffffff;
-    for (int v = tid; v < d.V; v += 256) {
-        const float lp = (x[v] - m) - ls;
-        if (lp > best) { best = lp; bi = v; }      // strided ascending scan keeps the lowest index per thread
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * 256;
+        const float lp = (xv[i] - m) - ls;
+        if (v < d.V && lp > best) { best = lp; bi = v; }   // strided ascending scan keeps the lowest index per thread
     }
     block_argmax(best, bi, sv, si);
     const int k = bi;
-    if (tid == 0) {
-        int t = s->lane_t[n], nb = s->noblk[n];
-        int commit = 0;
-        if (s->need_pred[n]) s->new_is_cache[n] = 0;      // the predictor stepped in this micro-step
-        if (k != s->blank) {
-            const int len = s->hyp_lens[n];
-            if (len < s->max_hyp) s->hyps[(size_t)n * s->max_hyp + len] = k;
-            s->hyp_lens[n] = len + 1;
-            s->need_pred[n] = 1;
-            nb += 1;
-            s->token[n] = k;
-            commit = s->new_is_cache[n] ? 0 : 1;
-        }
-        if (k == s->blank || nb >= s->n_steps) {
-            if (k == s->blank) s->need_pred[n] = 0;
-            t += 1;
-            nb = 0;
-        }
-        s->lane_t[n] = t;
-        s->noblk[n] = nb;
-        const int T = s->enc_lens[n] < s->T ? s->enc_lens[n] : s->T;
-        if (t >= T) {
-            s->lane_active[n] = 0;
-            atomicSub(s->active_count, 1);
-        }
-        s_commit = commit;
+    const bool emit = (k != S.blank);
+    if (need) nic = 0;                             // the predictor stepped in this micro-step
+    const bool commit = emit && !nic;
+    int need_next = need;
+    if (emit) { need_next = 1; nb += 1; }
+    if (!emit || nb >= S.n_steps) {
+        if (!emit) need_next = 0;
+        t += 1;
+        nb = 0;
     }
-    __syncthreads();
-    if (s_commit) {                                // cache = new_cache (greedy_search copy.py:52)
+    const int T = enc_len < S.T ? enc_len : S.T;
+    if (tid == 0) {
+        if (need) S.new_is_cache[n] = 0;
+        if (emit) {
+            if (len < S.max_hyp) S.hyps[(size_t)n * S.max_hyp + len] = k;
+            S.hyp_lens[n] = len + 1;
+            S.token[n] = k;
+        }
+        S.need_pred[n] = need_next;
+        S.lane_t[n] = t;
+        S.noblk[n] = nb;
+        if (t >= T) {
+            S.lane_active[n] = 0;
+            atomicSub(S.active_count, 1);
+        }
+    }
+    if (emit) {                                    // next predictor input
+        for (int q = tid; q < d.D; q += 256) S.xT[(size_t)q * d.NLp + n] = S.embed[(size_t)k * d.D + q];
+    }
+    if (commit) {                                  // cache = new_cache (greedy_search copy.py:52)
         for (int i = tid; i < d.L * d.Hp; i += 256) {
             const size_t o = (size_t)i * d.NLp + n;
-            s->cache_hT[o] = s->new_hT[o];
-            s->cache_cT[o] = s->new_cT[o];
+            S.cache_hT[o] = S.new_hT[o];
+            S.cache_cT[o] = S.new_cT[o];
         }
     }
 }
@@ -407,7 +525,6 @@ __global__ void beam_init_kernel(DevState *s)
         s->cache_hT[o] = 0.f; s->cache_cT[o] = 0.f; s->alt_hT[o] = 0.f; s->alt_cT[o] = 0.f;
         s->new_hT[o] = 0.f; s->new_cT[o] = 0.f;
     }
-    for (int q = tid; q < d.Jp; q += blockDim.x) s->ppT[(size_t)q * d.NLp + n] = 0.f;
     if (tid == 0) {
         const int T = s->enc_lens[b] < s->T ? s->enc_lens[b] : s->T;
         s->token[n] = s->blank;
@@ -423,6 +540,7 @@ __global__ void beam_init_kernel(DevState *s)
             s->bscores[(size_t)b * s->beam] = 0.0;
         }
     }
+    write_embedding_column(s, n, s->blank);
 }
 
 // per lane: log-softmax, mixture with the CTC posterior of this frame, top-`beam`
@@ -579,6 +697,7 @@ __global__ __launch_bounds__(256) void beam_update_kernel(DevState *s)
             if (!blank_ext && lb < s->Lmax) hy2[(size_t)e * s->Lmax + lb] = tok;
             hl2[e] = c_len[f];
         }
+        write_embedding_column(s, dst, c_last[f]);   // next frame's predictor input: last token of the hypothesis (:78-80)
     }
     __syncthreads();
     if (tid == 0) {
@@ -681,11 +800,11 @@ size_t carve(const wr_transducer_weights *w, int max_lanes, int max_utt, int Tma
     d.V = w->vocab_size; d.E = w->enc_dim; d.P = w->pred_dim; d.D = w->embed_dim; d.H = w->hidden; d.L = w->n_layers;
     d.J = w->join_dim;
     auto up = [](int x, int m) { return (x + m - 1) / m * m; };
-    d.Dp = up(d.D, 8); d.Hp = up(d.H, 8); d.Pp = up(d.P, 8); d.Jp = up(d.J, 8);
-    d.G4p = up(4 * d.H, 32);
+    d.Dp = up(d.D, 16); d.Hp = up(d.H, 16); d.Pp = up(d.P, 16); d.Jp = up(d.J, 16);   // K: 8 waves x k-pairs
+    d.G4p = 4 * d.Hp;                                      // 32-column tiles = i,f,g,o of 8 hidden units
     d.Vp = up(d.V, 256);
     d.NL = max_lanes;
-    d.NLp = up(max_lanes, 32);
+    d.NLp = max_lanes <= 32 ? 32 : up(max_lanes, 64);     // lane tiles of the GEMM: 32, or pairs of 32
     DevState s;
     memset(&s, 0, sizeof(s));
     s.d = d;
@@ -707,9 +826,7 @@ size_t carve(const wr_transducer_weights *w, int max_lanes, int max_utt, int Tma
     s.cache_hT = c.take<float>(cs); s.cache_cT = c.take<float>(cs);
     s.new_hT = c.take<float>(cs); s.new_cT = c.take<float>(cs);
     s.alt_hT = c.take<float>(cs); s.alt_cT = c.take<float>(cs);
-    s.gatesT = c.take<float>((size_t)d.G4p * d.NLp);
     s.outT = c.take<float>((size_t)d.Pp * d.NLp);
-    s.ppT = c.take<float>((size_t)d.Jp * d.NLp);
     s.ht = c.take<float>((size_t)d.Jp * d.NLp);
     const size_t zero_end = align_up(c.off, 256);
     s.ep_all = c.take<float>((size_t)max_utt * Tmax * d.J);
@@ -756,59 +873,58 @@ void launch_transpose(const float *src, int R, int C, int Rp, int Cp, float *dst
     hipLaunchKernelGGL(transpose_pad_kernel, dim3((Rp + 31) / 32, (Cp + 31) / 32), dim3(256), 0, st, src, R, C, Rp, Cp, dst);
 }
 
-template <bool ROWMAJOR>
+// Exact-fp32 MFMA runs at 256 flop/clk/CU, so a 64-lane x 32-column x 512-deep tile already costs 3.4 us on its
+// CU: lane tiles of 32 (more, smaller workgroups) whenever they all fit on the chip at once.
+template <int EPI>
 void launch_gemm(const GemmArgs &g, int n_cols_padded, int n_lanes, hipStream_t st)
 {
-    const int mt = (n_lanes + 31) / 32;
-    const dim3 grid(n_cols_padded / 32);
-    switch (mt) {
-        case 1: hipLaunchKernelGGL((lane_gemm_kernel<1, ROWMAJOR>), grid, dim3(256), 0, st, g); break;
-        case 2: hipLaunchKernelGGL((lane_gemm_kernel<2, ROWMAJOR>), grid, dim3(256), 0, st, g); break;
-        case 3: hipLaunchKernelGGL((lane_gemm_kernel<3, ROWMAJOR>), grid, dim3(256), 0, st, g); break;
-        default: hipLaunchKernelGGL((lane_gemm_kernel<4, ROWMAJOR>), grid, dim3(256), 0, st, g); break;
+    const int mt = (n_lanes + 31) / 32, ct = n_cols_padded / 32;
+    if (mt == 1 || ct * mt <= 256) {
+        hipLaunchKernelGGL((lane_gemm_kernel<1, EPI>), dim3(ct, mt), dim3(64 * kGemmWaves), 0, st, g);
+    } else {
+        hipLaunchKernelGGL((lane_gemm_kernel<2, EPI>), dim3(ct, (mt + 1) / 2), dim3(64 * kGemmWaves), 0, st, g);
     }
 }
 
-// predictor step (predicated per lane) up to and including pred_ffn
+// predictor step (predicated per lane): L LSTM layers (cell fused) + projection
 void launch_predictor(wr_decoder *h, int n_lanes, hipStream_t st)
 {
     const Dims &d = h->d;
     const DevState &s = h->host;
     auto up = [](int x, int m) { return (x + m - 1) / m * m; };
-    hipLaunchKernelGGL(embed_gather_kernel, dim3((d.D * d.NLp + 255) / 256), dim3(256), 0, st, h->dev);
     const size_t ls = (size_t)d.Hp * d.NLp;
     for (int l = 0; l < d.L; ++l) {
         GemmArgs g{};
         g.A0 = l == 0 ? s.xT : s.new_hT + (size_t)(l - 1) * ls;  g.B0 = s.wt_ih[l];  g.K0 = l == 0 ? d.Dp : d.Hp;
         g.A1 = s.cache_hT + (size_t)l * ls;                       g.B1 = s.wt_hh[l];  g.K1 = d.Hp;
-        g.lda = d.NLp; g.ldb = d.G4p; g.bias = s.bsum[l]; g.C = s.gatesT; g.ldc = d.NLp; g.N = 4 * d.H; g.n_lanes = n_lanes;
-        launch_gemm<false>(g, d.G4p, n_lanes, st);
-        hipLaunchKernelGGL(lstm_cell_kernel, dim3((d.H * d.NLp + 255) / 256), dim3(256), 0, st, h->dev, l);
+        g.lda = d.NLp; g.ldb = d.G4p; g.bias = s.bsum[l]; g.C = nullptr; g.ldc = d.NLp; g.N = d.G4p; g.n_lanes = n_lanes;
+        g.lane_active = s.lane_active; g.need_pred = s.need_pred; g.H = d.H;
+        g.cache_cT = s.cache_cT + (size_t)l * ls; g.new_cT = s.new_cT + (size_t)l * ls; g.new_hT = s.new_hT + (size_t)l * ls;
+        launch_gemm<kEpiLstmCell>(g, d.G4p, n_lanes, st);
     }
-    {
-        GemmArgs g{};
-        g.A0 = s.new_hT + (size_t)(d.L - 1) * ls; g.B0 = s.proj_wt; g.K0 = d.Hp;
-        g.lda = d.NLp; g.ldb = up(d.P, 32); g.bias = s.proj_b; g.C = s.outT; g.ldc = d.NLp; g.N = d.P; g.n_lanes = n_lanes;
-        launch_gemm<false>(g, up(d.P, 32), n_lanes, st);
-    }
-    {
-        GemmArgs g{};
-        g.A0 = s.outT; g.B0 = s.predffn_wt; g.K0 = d.Pp;
-        g.lda = d.NLp; g.ldb = up(d.J, 32); g.bias = s.predffn_b; g.C = s.ppT; g.ldc = d.NLp; g.N = d.J; g.n_lanes = n_lanes;
-        launch_gemm<false>(g, up(d.J, 32), n_lanes, st);
-    }
+    GemmArgs g{};
+    g.A0 = s.new_hT + (size_t)(d.L - 1) * ls; g.B0 = s.proj_wt; g.K0 = d.Hp;
+    g.lda = d.NLp; g.ldb = up(d.P, 32); g.bias = s.proj_b; g.C = s.outT; g.ldc = d.NLp; g.N = d.P; g.n_lanes = n_lanes;
+    launch_gemm<kEpiKMajor>(g, up(d.P, 32), n_lanes, st);
 }
 
 void launch_predictor_and_joint(wr_decoder *h, int n_lanes, hipStream_t st)
 {
     const Dims &d = h->d;
     const DevState &s = h->host;
+    auto up = [](int x, int m) { return (x + m - 1) / m * m; };
     launch_predictor(h, n_lanes, st);
-    hipLaunchKernelGGL(joint_act_kernel, dim3((d.J * d.NLp + 255) / 256), dim3(256), 0, st, h->dev);
+    {   // pred_ffn with the joiner activation as epilogue
+        GemmArgs g{};
+        g.A0 = s.outT; g.B0 = s.predffn_wt; g.K0 = d.Pp;
+        g.lda = d.NLp; g.ldb = up(d.J, 32); g.bias = s.predffn_b; g.C = s.ht; g.ldc = d.NLp; g.N = d.J; g.n_lanes = n_lanes;
+        g.st = h->dev; g.lane_active = s.lane_active; g.lane_t = s.lane_t; g.ep_all = s.ep_all; g.J = d.J;
+        launch_gemm<kEpiJointAct>(g, up(d.J, 32), n_lanes, st);
+    }
     GemmArgs g{};
     g.A0 = s.ht; g.B0 = s.out_wt; g.K0 = d.Jp;
     g.lda = d.NLp; g.ldb = d.Vp; g.bias = s.out_b; g.C = s.logits; g.ldc = d.V; g.N = d.V; g.n_lanes = n_lanes;
-    launch_gemm<true>(g, d.Vp, n_lanes, st);
+    launch_gemm<kEpiRowMajor>(g, d.Vp, n_lanes, st);
 }
 
 }  // namespace
@@ -828,6 +944,8 @@ extern "C" int wr_decoder_create(const wr_transducer_weights *w, int max_lanes, 
     WR_REQUIRE(max_lanes > 0 && max_lanes <= 128, WR_EUNSUPPORTED, "decoder_create: max_lanes=%d (1..128)", max_lanes);
     WR_REQUIRE(max_utt > 0 && max_utt <= max_lanes && Tmax > 0 && max_hyp >= 0, WR_EINVAL, "decoder_create: bad sizes");
     if (max_beam <= 0) max_beam = 1;
+    WR_REQUIRE(w->vocab_size <= 256 * kMaxVocabPerThread, WR_EUNSUPPORTED, "decoder_create: vocabulary %d exceeds %d",
+               w->vocab_size, 256 * kMaxVocabPerThread);
     WR_REQUIRE(max_beam <= kMaxBeam, WR_EUNSUPPORTED, "decoder_create: beam %d exceeds %d", max_beam, kMaxBeam);
     {
         const size_t hyp_lds = (size_t)max_beam * (Tmax + 1) * sizeof(int32_t);
@@ -871,9 +989,9 @@ extern "C" int wr_decoder_create(const wr_transducer_weights *w, int max_lanes, 
     auto up = [](int x, int m) { return (x + m - 1) / m * m; };
     for (int l = 0; l < d.L; ++l) {
         const int in_dim = l == 0 ? d.D : d.H, in_p = l == 0 ? d.Dp : d.Hp;
-        launch_transpose(w->w_ih[l], 4 * d.H, in_dim, d.G4p, in_p, s.wt_ih[l], st);
-        launch_transpose(w->w_hh[l], 4 * d.H, d.H, d.G4p, d.Hp, s.wt_hh[l], st);
-        hipLaunchKernelGGL(add_bias_kernel, dim3((4 * d.H + 255) / 256), dim3(256), 0, st, w->b_ih[l], w->b_hh[l], 4 * d.H,
+        hipLaunchKernelGGL(lstm_weight_prep_kernel, dim3(256), dim3(256), 0, st, w->w_ih[l], d.H, d.Hp, in_dim, in_p, s.wt_ih[l]);
+        hipLaunchKernelGGL(lstm_weight_prep_kernel, dim3(256), dim3(256), 0, st, w->w_hh[l], d.H, d.Hp, d.H, d.Hp, s.wt_hh[l]);
+        hipLaunchKernelGGL(lstm_bias_prep_kernel, dim3((d.G4p + 255) / 256), dim3(256), 0, st, w->b_ih[l], w->b_hh[l], d.H, d.Hp,
                            s.bsum[l]);
     }
     launch_transpose(w->proj_w, d.P, d.H, up(d.P, 32), d.Hp, s.proj_wt, st);
@@ -924,7 +1042,11 @@ int upload_state(wr_decoder *h, hipStream_t st)
 void greedy_micro_step(wr_decoder *h, int n_lanes, hipStream_t st)
 {
     launch_predictor_and_joint(h, n_lanes, st);
-    hipLaunchKernelGGL(greedy_update_kernel, dim3(n_lanes), dim3(256), 0, st, h->dev);
+    const int V = h->d.V;
+    if (V <= 256 * 8) hipLaunchKernelGGL(greedy_update_kernel<8>, dim3(n_lanes), dim3(256), 0, st, h->dev);
+    else if (V <= 256 * 24) hipLaunchKernelGGL(greedy_update_kernel<24>, dim3(n_lanes), dim3(256), 0, st, h->dev);
+    else if (V <= 256 * 64) hipLaunchKernelGGL(greedy_update_kernel<64>, dim3(n_lanes), dim3(256), 0, st, h->dev);
+    else hipLaunchKernelGGL(greedy_update_kernel<kMaxVocabPerThread>, dim3(n_lanes), dim3(256), 0, st, h->dev);
 }
 
 void beam_frame(wr_decoder *h, int n_lanes, int n_utt, hipStream_t st)
@@ -1101,14 +1223,16 @@ __global__ void cache_from_kmajor_kernel(const float *__restrict__ src, int N, i
 
 __global__ void step_setup_kernel(DevState *s, const int32_t *tokens, int N)
 {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n < s->d.NLp) {
-        const int on = n < N;
+    const int n = blockIdx.x;                      // one workgroup per lane slot
+    const int on = n < N;
+    const int tok = on ? tokens[n] : 0;
+    if (threadIdx.x == 0) {
         s->lane_active[n] = on;
         s->need_pred[n] = on;
         s->lane_t[n] = 0;
-        s->token[n] = on ? tokens[n] : 0;
+        s->token[n] = tok;
     }
+    write_embedding_column(s, n, tok);
 }
 }  // namespace
 
@@ -1126,7 +1250,7 @@ extern "C" int wr_predictor_step(wr_decoder *h, const int32_t *tokens_d, const f
     DevState &s = h->host;
     s.n_utt = 1; s.T = 1; s.lanes_per_utt = d.NL; s.n_lanes = N; s.enc = nullptr; s.enc_lens = nullptr;
     if (int rc = upload_state(h, st)) return rc;
-    hipLaunchKernelGGL(step_setup_kernel, dim3((d.NLp + 63) / 64), dim3(64), 0, st, h->dev, tokens_d, N);
+    hipLaunchKernelGGL(step_setup_kernel, dim3(d.NLp), dim3(64), 0, st, h->dev, tokens_d, N);
     hipLaunchKernelGGL(cache_to_kmajor_kernel, dim3(64), dim3(256), 0, st, cache_h_d, N, d.L, d.H, d.Hp, d.NLp, s.cache_hT);
     hipLaunchKernelGGL(cache_to_kmajor_kernel, dim3(64), dim3(256), 0, st, cache_c_d, N, d.L, d.H, d.Hp, d.NLp, s.cache_cT);
     launch_predictor(h, N, st);
