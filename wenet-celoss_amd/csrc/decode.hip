@@ -31,7 +31,7 @@
 //                           decides the token)
 //   greedy_update_kernel    log-softmax + argmax (first index on ties) + the
 //                           frame/emission state machine + cache commit
-//   beam_topk_kernel /      log-softmax, CTC mixture, top-k in LDS; per-utterance
+//   beam_topk_kernel /      log-softmax, CTC mixture, top-k from registers; per-utterance
 //   beam_update_kernel      expansion, prefix fusion (float64 log_add), stable prune --
 //                           one candidate per thread
 //
@@ -82,7 +82,6 @@ struct DevState {
     float *xT;                    // [Dp][NLp]     embedding of each lane's token
     float *cache_hT, *cache_cT;   // [L][Hp][NLp]  committed LSTM state
     float *new_hT, *new_cT;       // [L][Hp][NLp]  output of the last predictor step
-    float *alt_hT, *alt_cT;       // [L][Hp][NLp]  staging for beam reordering
     float *outT;                  // [Pp][NLp]     projected predictor output
     float *ht;                    // [Jp][NLp]     joiner activation
     float *logits;                // [NL, V]
@@ -99,6 +98,7 @@ struct DevState {
     int32_t *bhyps;               // [2, n_utt, beam, Lmax]
     int32_t *bhyp_lens;           // [2, n_utt, beam]
     double *bscores;              // [n_utt, beam]
+    unsigned long long *bhash;    // [n_utt, beam]   running hash of each hypothesis' tokens
     int32_t *n_hyps;              // [n_utt]
     int32_t *frame;               // [n_utt]
     int32_t *hyp_sel;             // [n_utt]
@@ -209,7 +209,6 @@ __global__ void lstm_bias_prep_kernel(const float *__restrict__ b_ih, const floa
 // Epilogues: k-major store, row-major store (logits), LSTM cell (gate columns are permuted at create time so a
 // 32-column tile holds i,f,g,o of 8 hidden units), joiner activation tanh(enc_ffn(enc)[t] + pred_ffn(pred)).
 constexpr int kGemmWaves = 8;
-constexpr int kMaxVocabPerThread = 160;                 // greedy_update keeps a logits row in registers: V <= 40960
 template <int MT, int EPI>
 __global__ __launch_bounds__(64 * kGemmWaves) void lane_gemm_kernel(GemmArgs g)
 {
@@ -515,6 +514,12 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(DevState *sp)
 }
 
 // ------------------------------------------------------------------ beam --
+// 64-bit running hash of a hypothesis' token sequence (kept per hypothesis, extended by one token per emission)
+__device__ __forceinline__ unsigned long long hyp_hash_push(unsigned long long h, int tok)
+{
+    return (h ^ (unsigned long long)(unsigned)(tok + 1)) * 0x100000001b3ull + 0x9e3779b97f4a7c15ull;
+}
+
 __global__ void beam_init_kernel(DevState *s)
 {
     const Dims &d = s->d;
@@ -522,7 +527,7 @@ __global__ void beam_init_kernel(DevState *s)
     const int b = n / s->beam, j = n % s->beam;
     for (int i = tid; i < d.L * d.Hp; i += blockDim.x) {
         const size_t o = (size_t)i * d.NLp + n;
-        s->cache_hT[o] = 0.f; s->cache_cT[o] = 0.f; s->alt_hT[o] = 0.f; s->alt_cT[o] = 0.f;
+        s->cache_hT[o] = 0.f; s->cache_cT[o] = 0.f;
         s->new_hT[o] = 0.f; s->new_cT[o] = 0.f;
     }
     if (tid == 0) {
@@ -533,6 +538,7 @@ __global__ void beam_init_kernel(DevState *s)
         s->lane_active[n] = (j == 0 && T > 0);
         s->bhyp_lens[(size_t)b * s->beam + j] = (j == 0) ? 1 : 0;
         s->bhyps[((size_t)b * s->beam + j) * s->Lmax] = s->blank;
+        s->bhash[n] = hyp_hash_push(0ull, s->blank);
         if (j == 0) {
             s->n_hyps[b] = 1;
             s->frame[b] = 0;
@@ -543,46 +549,61 @@ __global__ void beam_init_kernel(DevState *s)
     write_embedding_column(s, n, s->blank);
 }
 
-// per lane: log-softmax, mixture with the CTC posterior of this frame, top-`beam`
-__global__ __launch_bounds__(256) void beam_topk_kernel(DevState *s)
+// per lane: log-softmax, mixture with the CTC posterior of this frame, top-`beam`.  The row lives in registers
+// (NV values per thread, V <= 256 * NV); each selection round is one block-wide argmax, after which the thread
+// that owns the winner retires it and rescans its own values.
+template <int NV>
+__global__ __launch_bounds__(256) void beam_topk_kernel(DevState *sp)
 {
-    extern __shared__ float lp[];                  // [V]
     __shared__ float sv[4];
     __shared__ int si[4];
-    const Dims &d = s->d;
+    const DevState S = *sp;
+    const Dims &d = S.d;
     const int n = blockIdx.x, tid = threadIdx.x;
-    if (!s->lane_active[n]) return;
-    const int b = n / s->beam;
-    const int fr = s->frame[b];
-    const float *x = s->logits + (size_t)n * d.V;
-    const float *cp = s->ctc_logp + ((size_t)b * s->T + fr) * d.V;
+    if (!S.lane_active[n]) return;
+    const int b = n / S.beam;
+    const int fr = S.frame[b];
+    const float *x = S.logits + (size_t)n * d.V;
+    const float *cp = S.ctc_logp + ((size_t)b * S.T + fr) * d.V;
+    const float ninf = -__builtin_huge_valf();
+    float xv[NV], cv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * 256;
+        xv[i] = v < d.V ? x[v] : -3.0e38f;
+        cv[i] = v < d.V ? cp[v] : 0.f;
+    }
     float m = -3.0e38f;
-    for (int v = tid; v < d.V; v += 256) m = fmaxf(m, x[v]);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) m = fmaxf(m, xv[i]);
     m = block_max(m, sv);
     float sum = 0.f;
-    for (int v = tid; v < d.V; v += 256) sum += expf(x[v] - m);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) sum += (tid + i * 256 < d.V) ? expf(xv[i] - m) : 0.f;
     sum = block_sum(sum, sv);
     const float ls = logf(sum);
-    for (int v = tid; v < d.V; v += 256) {
-        const float l = (x[v] - m) - ls;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float l = (xv[i] - m) - ls;
         // prefix_beam_search.py:99-101: log(tw * exp(logp) + cw * exp(ctc[i]))
-        lp[v] = logf(s->tr_weight * expf(l) + s->ctc_weight * expf(cp[v]));
+        xv[i] = (tid + i * 256 < d.V) ? logf(S.tr_weight * expf(l) + S.ctc_weight * expf(cv[i])) : ninf;
     }
-    __syncthreads();
-    for (int k = 0; k < s->beam; ++k) {
-        float best = -__builtin_huge_valf();
+    for (int k = 0; k < S.beam; ++k) {
+        float best = ninf;
         int bi = 0x7fffffff;
-        for (int v = tid; v < d.V; v += 256) {
-            const float val = lp[v];
-            if (val > best) { best = val; bi = v; }     // ascending scan: lowest index wins ties
-        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (xv[i] > best) { best = xv[i]; bi = tid + i * 256; }   // ascending scan: lowest index wins ties
         block_argmax(best, bi, sv, si);
         if (tid == 0) {
-            s->topv[(size_t)n * s->beam + k] = best;
-            s->topi[(size_t)n * s->beam + k] = (bi < d.V) ? bi : 0;
-            if (bi >= 0 && bi < d.V) lp[bi] = -__builtin_huge_valf();   // taken
+            S.topv[(size_t)n * S.beam + k] = best;
+            S.topi[(size_t)n * S.beam + k] = (bi < d.V) ? bi : 0;
         }
-        __syncthreads();
+        if ((bi & 255) == tid) {                   // taken
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (i == (bi >> 8)) xv[i] = ninf;
+        }
     }
 }
 
@@ -595,140 +616,208 @@ __device__ __forceinline__ double log_add2(double a, double b)
     return mx + log(exp(a - mx) + exp(b - mx));
 }
 
-// one workgroup per utterance: expansion, prefix fusion, stable prune (prefix_beam_search.py:107-146),
-// one candidate (hypothesis j, rank t) per thread.
-__global__ __launch_bounds__(256) void beam_update_kernel(DevState *s)
+// one workgroup per utterance: expansion, prefix fusion, stable prune (prefix_beam_search.py:107-146).
+// One candidate (hypothesis j, rank t) per thread; the all-pairs steps (which candidates spell the same token
+// sequence, where a class ranks) run pair-per-thread.  Sequences are compared through their running hashes and
+// verified token by token only when the hashes agree, so fusion is exact.  Then the survivors' hypotheses,
+// predictor caches and next input embeddings are moved into place (rows of the k-major caches are independent,
+// so each batch of rows is read into registers, synchronised and written back in place).
+__global__ __launch_bounds__(256) void beam_update_kernel(DevState *sp)
 {
     constexpr int MC = kMaxBeam * kMaxBeam;
-    __shared__ int c_base[MC], c_tok[MC], c_len[MC], c_last[MC], c_rep[MC], order[kMaxBeam];
+    __shared__ int c_base[MC], c_tok[MC], c_len[MC], c_last[MC], c_rep[MC], c_rank[MC], order[kMaxBeam];
+    __shared__ unsigned long long c_hash[MC];
+    __shared__ int e_src[kMaxBeam], e_blank[kMaxBeam], e_tok[kMaxBeam], e_last[kMaxBeam], e_lb[kMaxBeam];
     __shared__ double c_score[MC], f_score[MC];
     __shared__ int s_keep;
-    extern __shared__ int32_t hyl[];              // [beam][Lmax] this utterance's hypotheses, staged once
-    const Dims &d = s->d;
+    const DevState S = *sp;
+    const Dims &d = S.d;
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int beam = s->beam;
-    const int T = s->enc_lens[b] < s->T ? s->enc_lens[b] : s->T;
-    const int fr = s->frame[b];
+    const int beam = S.beam;
+    const int T = S.enc_lens[b] < S.T ? S.enc_lens[b] : S.T;
+    const int fr = S.frame[b];
     if (fr >= T) return;
-    const int N = s->n_hyps[b];
+    const int N = S.n_hyps[b];
     const int C = N * beam;
-    const int sel = s->hyp_sel[b];
-    const size_t hstride = (size_t)s->n_utt * beam * s->Lmax;
-    const int32_t *hy = s->bhyps + sel * hstride + (size_t)b * beam * s->Lmax;
-    int32_t *hy2 = s->bhyps + (1 - sel) * hstride + (size_t)b * beam * s->Lmax;
-    const int32_t *hl = s->bhyp_lens + (size_t)sel * s->n_utt * beam + (size_t)b * beam;
-    int32_t *hl2 = s->bhyp_lens + (size_t)(1 - sel) * s->n_utt * beam + (size_t)b * beam;
-
-    for (int j = 0; j < N; ++j) {
-        const int lb = hl[j];
-        for (int q = tid; q < lb; q += 256) hyl[j * s->Lmax + q] = hy[(size_t)j * s->Lmax + q];
-    }
-    __syncthreads();
+    const int sel = S.hyp_sel[b];
+    const size_t hstride = (size_t)S.n_utt * beam * S.Lmax;
+    const int32_t *__restrict__ hy = S.bhyps + sel * hstride + (size_t)b * beam * S.Lmax;
+    int32_t *__restrict__ hy2 = S.bhyps + (1 - sel) * hstride + (size_t)b * beam * S.Lmax;
+    const int32_t *__restrict__ hl = S.bhyp_lens + (size_t)sel * S.n_utt * beam + (size_t)b * beam;
+    int32_t *__restrict__ hl2 = S.bhyp_lens + (size_t)(1 - sel) * S.n_utt * beam + (size_t)b * beam;
     // phase 1: candidates in the reference's order (hypothesis-major, then top-k rank; :109-127)
+    if (tid < kMaxBeam) e_lb[tid] = tid < N ? hl[tid] : 0;
+    if (tid == 0) s_keep = 0;
     if (tid < C) {
         const int j = tid / beam, t = tid - j * beam;
         const int n = b * beam + j;
-        const int tok = s->topi[(size_t)n * beam + t];
+        const int tok = S.topi[(size_t)n * beam + t];
         // scores tensor is fp32 built from Python floats (:86); add in fp32 (:105); .item() -> float64 (:116)
-        const float sj = (float)s->bscores[(size_t)b * beam + j];
-        c_score[tid] = (double)(sj + s->topv[(size_t)n * beam + t]);
+        const float sj = (float)S.bscores[(size_t)b * beam + j];
+        const float tv = S.topv[(size_t)n * beam + t];
+        const int lb = hl[j];
+        const int last = S.token[n];               // last token of hypothesis j (this frame's predictor input)
+        const unsigned long long hh = S.bhash[n];
+        c_score[tid] = (double)(sj + tv);
         c_base[tid] = j;
         c_tok[tid] = tok;
-        const int lb = hl[j];
-        c_len[tid] = lb + (tok != s->blank ? 1 : 0);
-        c_last[tid] = (tok != s->blank) ? tok : hyl[j * s->Lmax + lb - 1];
+        c_len[tid] = lb + (tok != S.blank ? 1 : 0);
+        c_last[tid] = (tok != S.blank) ? tok : last;
+        c_hash[tid] = (tok != S.blank) ? hyp_hash_push(hh, tok) : hh;
+        c_rep[tid] = tid;
+        c_rank[tid] = 0;
     }
     __syncthreads();
     // phase 2: class representative = the first candidate with the same token sequence (:130-142)
-    if (tid < C) {
-        int rep = tid;
-        const int j = c_base[tid], tok = c_tok[tid], len = c_len[tid], lbj = hl[j];
-        for (int f = 0; f < tid && rep == tid; ++f) {
-            if (c_len[f] != len || c_last[f] != c_last[tid]) continue;
-            const int bj = c_base[f], bt = c_tok[f], lb = hl[bj];
-            bool same = true;
-            for (int q = len - 2; q >= 0 && same; --q) {
-                const int x = (q < lbj) ? hyl[j * s->Lmax + q] : tok;
-                const int y = (q < lb) ? hyl[bj * s->Lmax + q] : bt;
-                same = (x == y);
+    for (int p = tid; p < C * C; p += 256) {
+        const int i = p / C, f = p - i * C;
+        if (f >= i || c_hash[f] != c_hash[i] || c_len[f] != c_len[i] || c_last[f] != c_last[i]) continue;
+        // equal hashes, lengths and last tokens: the sequences are equal iff the first len-1 tokens of the two base
+        // hypotheses are (both bases hold at least that many); compared in batches of independent loads
+        const int32_t *__restrict__ pi = hy + (size_t)c_base[i] * S.Lmax;
+        const int32_t *__restrict__ pf = hy + (size_t)c_base[f] * S.Lmax;
+        const int ncmp = c_len[i] - 1;
+        bool same = true;
+        constexpr int UC = 16;
+        for (int q0 = 0; q0 < ncmp && same; q0 += UC) {
+            int xa[UC], ya[UC];
+#pragma unroll
+            for (int u = 0; u < UC; ++u) {
+                const int q = q0 + u < ncmp ? q0 + u : ncmp - 1;
+                xa[u] = pi[q];
+                ya[u] = pf[q];
             }
-            if (same) rep = f;
+#pragma unroll
+            for (int u = 0; u < UC; ++u) same = same && (xa[u] == ya[u]);
         }
-        c_rep[tid] = rep;
+        if (same) atomicMin(&c_rep[i], f);
     }
     __syncthreads();
     // phase 3: a representative accumulates its duplicates' scores in candidate order with float64 log_add
     if (tid < C) {
         double sc = c_score[tid];
-        if (c_rep[tid] == tid)
+        if (c_rep[tid] == tid) {
+#pragma unroll 8
             for (int f = tid + 1; f < C; ++f)
                 if (c_rep[f] == tid) sc = log_add2(sc, c_score[f]);
+        }
         f_score[tid] = sc;
     }
     __syncthreads();
     // phase 4: stable descending sort position among representatives (list.sort(reverse=True) keeps order on ties)
-    if (tid == 0) s_keep = 0;
+    for (int p = tid; p < C * C; p += 256) {
+        const int i = p / C, f = p - i * C;
+        if (c_rep[i] != i || c_rep[f] != f) continue;
+        const double me = f_score[i], ot = f_score[f];
+        if (ot > me || (ot == me && f < i)) atomicAdd(&c_rank[i], 1);
+    }
     __syncthreads();
     if (tid < C && c_rep[tid] == tid) {
-        int rank = 0;
-        const double me = f_score[tid];
-        for (int f = 0; f < C; ++f)
-            if (c_rep[f] == f && (f_score[f] > me || (f_score[f] == me && f < tid))) ++rank;
-        if (rank < beam) order[rank] = tid;
+        if (c_rank[tid] < beam) order[c_rank[tid]] = tid;
         atomicAdd(&s_keep, 1);
     }
     __syncthreads();
     const int keep = s_keep < beam ? s_keep : beam;
-    // phase 5: write the pruned beam (other hypothesis buffer) and the caches that go with it (staging buffer)
-    for (int e = 0; e < keep; ++e) {
-        const int f = order[e];
-        const int j = c_base[f], tok = c_tok[f];
-        const int lb = hl[j];
-        for (int q = tid; q < lb; q += 256) hy2[(size_t)e * s->Lmax + q] = hyl[j * s->Lmax + q];
-        const int src = b * beam + j, dst = b * beam + e;
-        // blank keeps the base hypothesis' cache, a label takes the predictor's new cache (:111-124)
-        const bool blank_ext = (tok == s->blank);
-        for (int i = tid; i < d.L * d.Hp; i += 256) {
-            const size_t so = (size_t)i * d.NLp + src, dst_o = (size_t)i * d.NLp + dst;
-            s->alt_hT[dst_o] = blank_ext ? s->cache_hT[so] : s->new_hT[so];
-            s->alt_cT[dst_o] = blank_ext ? s->cache_cT[so] : s->new_cT[so];
-        }
-        if (tid == 0) {
-            if (!blank_ext && lb < s->Lmax) hy2[(size_t)e * s->Lmax + lb] = tok;
-            hl2[e] = c_len[f];
-        }
-        write_embedding_column(s, dst, c_last[f]);   // next frame's predictor input: last token of the hypothesis (:78-80)
+    if (tid < keep) {
+        const int f = order[tid];
+        e_src[tid] = c_base[f];
+        e_tok[tid] = c_tok[f];
+        e_blank[tid] = (c_tok[f] == S.blank);
+        e_last[tid] = c_last[f];
+        hl2[tid] = c_len[f];
+        S.bscores[(size_t)b * beam + tid] = f_score[f];
+        S.bhash[b * beam + tid] = c_hash[f];
+        S.token[b * beam + tid] = c_last[f];       // next frame's predictor input: last token of the hypothesis (:78-80)
     }
     __syncthreads();
-    if (tid == 0) {
-        for (int e = 0; e < keep; ++e) {
-            const int f = order[e];
-            s->bscores[(size_t)b * beam + e] = f_score[f];
-            s->token[b * beam + e] = c_last[f];      // next frame's predictor input: last token of the hypothesis (:78-80)
+    // phase 5: the pruned beam -- hypotheses into the other buffer, (survivor, position) pairs in flight together
+    {
+        int maxlb = 0;
+        for (int e = 0; e < keep; ++e) maxlb = e_lb[e_src[e]] > maxlb ? e_lb[e_src[e]] : maxlb;
+        constexpr int UN = 4;
+        for (int i0 = 0; i0 < keep * maxlb; i0 += 256 * UN) {
+            int val[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int i = i0 + u * 256 + tid;
+                const int e = i / maxlb, q = i - e * maxlb;
+                const bool in = e < keep && q < e_lb[e_src[e < keep ? e : 0]];
+                val[u] = in ? hy[(size_t)e_src[e] * S.Lmax + q] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int i = i0 + u * 256 + tid;
+                const int e = i / maxlb, q = i - e * maxlb;
+                if (e < keep && q < e_lb[e_src[e]]) hy2[(size_t)e * S.Lmax + q] = val[u];
+            }
         }
-        const int nfr = fr + 1;
-        for (int e = 0; e < beam; ++e) {
-            const int n = b * beam + e;
-            s->lane_active[n] = (e < keep) && (nfr < T);
-            s->lane_t[n] = nfr;
-            s->need_pred[n] = 1;
+        if (tid < keep) {
+            const int lb = e_lb[e_src[tid]];
+            if (!e_blank[tid] && lb < S.Lmax) hy2[(size_t)tid * S.Lmax + lb] = e_tok[tid];
         }
-        s->n_hyps[b] = keep;
-        s->frame[b] = nfr;
-        s->hyp_sel[b] = 1 - sel;
     }
-}
-
-// the pruned beam's caches were staged in alt_*: make them the committed caches of the next frame
-__global__ void beam_cache_commit_kernel(DevState *s)
-{
-    const Dims &d = s->d;
-    const long total = (long)d.L * d.Hp * d.NLp;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int lane = (int)(i % d.NLp);
-        if (lane < s->n_lanes) {
-            s->cache_hT[i] = s->alt_hT[i];
-            s->cache_cT[i] = s->alt_cT[i];
+    // next predictor inputs
+    {
+        constexpr int UN = 4;
+        const float *__restrict__ emb = S.embed;
+        for (int i0 = 0; i0 < keep * d.D; i0 += 256 * UN) {
+            float val[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int i = i0 + u * 256 + tid;
+                const int e = i / d.D, k = i - e * d.D;
+                val[u] = e < keep ? emb[(size_t)e_last[e] * d.D + k] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int i = i0 + u * 256 + tid;
+                const int e = i / d.D, k = i - e * d.D;
+                if (e < keep) S.xT[(size_t)k * d.NLp + b * beam + e] = val[u];
+            }
+        }
+    }
+    // predictor caches: a blank extension keeps the base hypothesis' cache, a label takes the predictor's new
+    // cache (:111-124).  Rows i of [L*Hp][NLp]; a thread owns (row, survivor) pairs, `beam` survivors per row.
+    {
+        constexpr int UN = 8;
+        const int rows = d.L * d.Hp, per_it = 256 / beam;           // rows per pass of the workgroup
+        const int e = tid % beam, r0 = tid / beam;
+        const bool on = e < keep && r0 < per_it;
+        const int src = b * beam + (on ? e_src[e] : 0), dst = b * beam + e;
+        const bool bl = on ? e_blank[e] != 0 : true;
+        const float *hsrc = bl ? S.cache_hT : S.new_hT;
+        const float *csrc = bl ? S.cache_cT : S.new_cT;
+        for (int rb = 0; rb < rows; rb += per_it * UN) {
+            float hv[UN], cw[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int r = rb + u * per_it + r0;
+                const size_t so = (size_t)(r < rows ? r : 0) * d.NLp + src;
+                hv[u] = hsrc[so];
+                cw[u] = csrc[so];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int r = rb + u * per_it + r0;
+                if (on && r < rows) {
+                    const size_t dst_o = (size_t)r * d.NLp + dst;
+                    S.cache_hT[dst_o] = hv[u];
+                    S.cache_cT[dst_o] = cw[u];
+                }
+            }
+        }
+    }
+    if (tid < beam) {
+        const int nfr = fr + 1;
+        const int n = b * beam + tid;
+        S.lane_active[n] = (tid < keep) && (nfr < T);
+        S.lane_t[n] = nfr;
+        S.need_pred[n] = 1;
+        if (tid == 0) {
+            S.n_hyps[b] = keep;
+            S.frame[b] = nfr;
+            S.hyp_sel[b] = 1 - sel;
         }
     }
 }
@@ -825,7 +914,6 @@ size_t carve(const wr_transducer_weights *w, int max_lanes, int max_utt, int Tma
     const size_t cs = (size_t)d.L * d.Hp * d.NLp;
     s.cache_hT = c.take<float>(cs); s.cache_cT = c.take<float>(cs);
     s.new_hT = c.take<float>(cs); s.new_cT = c.take<float>(cs);
-    s.alt_hT = c.take<float>(cs); s.alt_cT = c.take<float>(cs);
     s.outT = c.take<float>((size_t)d.Pp * d.NLp);
     s.ht = c.take<float>((size_t)d.Jp * d.NLp);
     const size_t zero_end = align_up(c.off, 256);
@@ -842,6 +930,7 @@ size_t carve(const wr_transducer_weights *w, int max_lanes, int max_utt, int Tma
     s.bhyps = c.take<int32_t>((size_t)2 * max_utt * max_beam * Lmax);
     s.bhyp_lens = c.take<int32_t>((size_t)2 * max_utt * max_beam);
     s.bscores = c.take<double>((size_t)max_utt * max_beam);
+    s.bhash = c.take<unsigned long long>((size_t)max_utt * max_beam);
     s.Lmax = Lmax;
     s.max_hyp = max_hyp;
     if (zero_range) { zero_range[0] = zero_begin; zero_range[1] = zero_end; }
@@ -944,17 +1033,7 @@ extern "C" int wr_decoder_create(const wr_transducer_weights *w, int max_lanes, 
     WR_REQUIRE(max_lanes > 0 && max_lanes <= 128, WR_EUNSUPPORTED, "decoder_create: max_lanes=%d (1..128)", max_lanes);
     WR_REQUIRE(max_utt > 0 && max_utt <= max_lanes && Tmax > 0 && max_hyp >= 0, WR_EINVAL, "decoder_create: bad sizes");
     if (max_beam <= 0) max_beam = 1;
-    WR_REQUIRE(w->vocab_size <= 256 * kMaxVocabPerThread, WR_EUNSUPPORTED, "decoder_create: vocabulary %d exceeds %d",
-               w->vocab_size, 256 * kMaxVocabPerThread);
     WR_REQUIRE(max_beam <= kMaxBeam, WR_EUNSUPPORTED, "decoder_create: beam %d exceeds %d", max_beam, kMaxBeam);
-    {
-        const size_t hyp_lds = (size_t)max_beam * (Tmax + 1) * sizeof(int32_t);
-        WR_REQUIRE(max_beam == 1 || hyp_lds <= 140 * 1024, WR_EUNSUPPORTED,
-                   "decoder_create: beam %d x (Tmax %d + 1) hypotheses do not fit the beam-update kernel's LDS", max_beam, Tmax);
-        if (hyp_lds > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(beam_update_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)hyp_lds);
-    }
     const size_t need = carve(w, max_lanes, max_utt, Tmax, max_hyp, max_beam, nullptr, nullptr, nullptr);
     WR_REQUIRE(workspace_bytes >= need, WR_EWORKSPACE, "decoder_create: workspace %zu < required %zu", workspace_bytes, need);
     wr_decoder *h = new (std::nothrow) wr_decoder();
@@ -1045,17 +1124,17 @@ void greedy_micro_step(wr_decoder *h, int n_lanes, hipStream_t st)
     const int V = h->d.V;
     if (V <= 256 * 8) hipLaunchKernelGGL(greedy_update_kernel<8>, dim3(n_lanes), dim3(256), 0, st, h->dev);
     else if (V <= 256 * 24) hipLaunchKernelGGL(greedy_update_kernel<24>, dim3(n_lanes), dim3(256), 0, st, h->dev);
-    else if (V <= 256 * 64) hipLaunchKernelGGL(greedy_update_kernel<64>, dim3(n_lanes), dim3(256), 0, st, h->dev);
-    else hipLaunchKernelGGL(greedy_update_kernel<kMaxVocabPerThread>, dim3(n_lanes), dim3(256), 0, st, h->dev);
+    else hipLaunchKernelGGL(greedy_update_kernel<64>, dim3(n_lanes), dim3(256), 0, st, h->dev);   // V <= 16384 (check_weights)
 }
 
 void beam_frame(wr_decoder *h, int n_lanes, int n_utt, hipStream_t st)
 {
     launch_predictor_and_joint(h, n_lanes, st);
-    hipLaunchKernelGGL(beam_topk_kernel, dim3(n_lanes), dim3(256), (size_t)h->d.V * sizeof(float), st, h->dev);
-    hipLaunchKernelGGL(beam_update_kernel, dim3(n_utt), dim3(256), (size_t)h->host.beam * h->host.Lmax * sizeof(int32_t), st,
-                       h->dev);
-    hipLaunchKernelGGL(beam_cache_commit_kernel, dim3(64), dim3(256), 0, st, h->dev);
+    const int V = h->d.V;                           // <= 16384 (check_weights)
+    if (V <= 256 * 8) hipLaunchKernelGGL(beam_topk_kernel<8>, dim3(n_lanes), dim3(256), 0, st, h->dev);
+    else if (V <= 256 * 24) hipLaunchKernelGGL(beam_topk_kernel<24>, dim3(n_lanes), dim3(256), 0, st, h->dev);
+    else hipLaunchKernelGGL(beam_topk_kernel<64>, dim3(n_lanes), dim3(256), 0, st, h->dev);
+    hipLaunchKernelGGL(beam_update_kernel, dim3(n_utt), dim3(256), 0, st, h->dev);
 }
 
 // Order the decoder's work stream after everything already enqueued on the caller's stream ...
