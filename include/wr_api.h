@@ -230,7 +230,10 @@ int wr_decoder_create(const wr_transducer_weights *w, int max_lanes, int max_utt
                       int max_beam, void *workspace_d, size_t workspace_bytes, void *stream,
                       wr_decoder **out);
 int wr_decoder_destroy(wr_decoder *h);
-int wr_decoder_set_graph(wr_decoder *h, int enable /* 0: plain launches instead of hipGraph replay */);
+/* hipGraph replay of the per-step kernel sequence.  Default: on for greedy search (the host polls a "lanes still
+ * active" word once per replay), off for prefix beam search (fixed frame count, plain launches measured faster).
+ * enable = 0 / 1 forces both off / on. */
+int wr_decoder_set_graph(wr_decoder *h, int enable);
 
 /* enc_out [N, T, E] fp32, enc_lens [N]; hyps [N, max_hyp] / hyp_lens [N] out (tokens beyond
  * max_hyp are counted in hyp_lens but not stored).  Each lane follows the reference loop exactly:

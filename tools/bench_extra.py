@@ -181,5 +181,9 @@ if __name__ == "__main__":
     ap.add_argument("--V", type=int, default=5000)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--dw", action="store_true")
+    ap.add_argument("--tile", type=int, default=0, help="lane-GEMM tile policy of the decoders (wr_tune_set key 6)")
     a = ap.parse_args()
+    if a.tile:
+        from wenet_celoss_amd import _lib
+        _lib.load().wr_tune_set(6, a.tile)
     {"joint": bench_joint, "ctc": bench_ctc, "greedy": bench_greedy, "beam": bench_beam}[a.what](a)

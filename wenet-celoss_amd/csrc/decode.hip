@@ -442,24 +442,27 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(DevState *sp)
     const DevState S = *sp;                         // by value: no reloads of the pointers after the stores below
     const Dims &d = S.d;
     const int n = blockIdx.x, tid = threadIdx.x;
-    if (!S.lane_active[n]) return;
+    // no branch before the loads: everything this lane needs is requested in one batch (idle lanes leave after
+    // the first reduction)
+    const int act = S.lane_active[n];
     int t = S.lane_t[n], nb = S.noblk[n];
     const int need = S.need_pred[n];
     int nic = S.new_is_cache[n];
     const int len = S.hyp_lens[n];
     const int enc_len = S.enc_lens[n];
-    const float *x = S.logits + (size_t)n * d.V;
+    const float *__restrict__ x = S.logits + (size_t)n * d.V;
     // log_softmax as the reference evaluates it: (x - max) - log(sum(exp(x - max)))
     float xv[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int v = tid + i * 256;
-        xv[i] = v < d.V ? x[v] : -3.0e38f;
+        xv[i] = x[v < d.V ? v : d.V - 1];
     }
     float m = -3.0e38f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) m = fmaxf(m, xv[i]);
+    for (int i = 0; i < NV; ++i) m = fmaxf(m, (tid + i * 256 < d.V) ? xv[i] : -3.0e38f);
     m = block_max(m, sv);
+    if (!act) return;
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) sum += (tid + i * 256 < d.V) ? expf(xv[i] - m) : 0.f;
@@ -560,23 +563,27 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(DevState *sp)
     const DevState S = *sp;
     const Dims &d = S.d;
     const int n = blockIdx.x, tid = threadIdx.x;
-    if (!S.lane_active[n]) return;
+    // no branch before the loads: the lane's scalars and both rows are requested in one batch (idle lanes leave
+    // after the first reduction)
+    const int act = S.lane_active[n];
     const int b = n / S.beam;
-    const int fr = S.frame[b];
-    const float *x = S.logits + (size_t)n * d.V;
-    const float *cp = S.ctc_logp + ((size_t)b * S.T + fr) * d.V;
+    int fr = S.frame[b];
+    fr = fr < S.T ? fr : S.T - 1;
+    const float *__restrict__ x = S.logits + (size_t)n * d.V;
+    const float *__restrict__ cp = S.ctc_logp + ((size_t)b * S.T + fr) * d.V;
     const float ninf = -__builtin_huge_valf();
     float xv[NV], cv[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int v = tid + i * 256;
-        xv[i] = v < d.V ? x[v] : -3.0e38f;
-        cv[i] = v < d.V ? cp[v] : 0.f;
+        xv[i] = x[v < d.V ? v : d.V - 1];
+        cv[i] = cp[v < d.V ? v : d.V - 1];
     }
     float m = -3.0e38f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) m = fmaxf(m, xv[i]);
+    for (int i = 0; i < NV; ++i) m = fmaxf(m, (tid + i * 256 < d.V) ? xv[i] : -3.0e38f);
     m = block_max(m, sv);
+    if (!act) return;
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) sum += (tid + i * 256 < d.V) ? expf(xv[i] - m) : 0.f;
@@ -588,21 +595,45 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(DevState *sp)
         // prefix_beam_search.py:99-101: log(tw * exp(logp) + cw * exp(ctc[i]))
         xv[i] = (tid + i * 256 < d.V) ? logf(S.tr_weight * expf(l) + S.ctc_weight * expf(cv[i])) : ninf;
     }
+    // selection: every wave extracts the top-`beam` of its quarter of the row with wave-local argmax rounds (DPP,
+    // no barriers); wave 0 then merges the 4 x beam survivors.  Ties go to the lowest index throughout.
+    __shared__ float wv[4 * kMaxBeam];
+    __shared__ int wi[4 * kMaxBeam];
+    const int lane = tid & 63, wave = tid >> 6;
     for (int k = 0; k < S.beam; ++k) {
         float best = ninf;
         int bi = 0x7fffffff;
 #pragma unroll
         for (int i = 0; i < NV; ++i)
             if (xv[i] > best) { best = xv[i]; bi = tid + i * 256; }   // ascending scan: lowest index wins ties
-        block_argmax(best, bi, sv, si);
-        if (tid == 0) {
-            S.topv[(size_t)n * S.beam + k] = best;
-            S.topi[(size_t)n * S.beam + k] = (bi < d.V) ? bi : 0;
-        }
+        wave_argmax_dpp(best, bi);
+        if (lane == 0) { wv[wave * S.beam + k] = best; wi[wave * S.beam + k] = bi; }
         if ((bi & 255) == tid) {                   // taken
 #pragma unroll
             for (int i = 0; i < NV; ++i)
                 if (i == (bi >> 8)) xv[i] = ninf;
+        }
+    }
+    // touch the next frame's CTC row (one word per 128-byte line) so that it is already in the Infinity Cache and
+    // its translation cached when the next micro-step asks for it
+    if (fr + 1 < S.T && tid * 32 < d.V) {
+        const float touch = cp[(size_t)d.V + tid * 32];
+        asm volatile("" ::"v"(touch));
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const bool in = lane < 4 * S.beam;
+        float cv0 = in ? wv[lane] : ninf;
+        const int ci = in ? wi[lane] : 0x7fffffff;
+        for (int k = 0; k < S.beam; ++k) {
+            float best = cv0;
+            int bi = ci;
+            wave_argmax_dpp(best, bi);
+            if (lane == 0) {
+                S.topv[(size_t)n * S.beam + k] = best;
+                S.topi[(size_t)n * S.beam + k] = (bi < d.V) ? bi : 0;
+            }
+            if (ci == bi) cv0 = ninf;
         }
     }
 }
@@ -863,7 +894,8 @@ struct wr_decoder {
     hipGraphExec_t beam_graph;
     int greedy_graph_lanes, beam_graph_lanes;
     int stream_lanes;             // lanes whose streaming state (cache, token, flags) is live; -1: none
-    bool use_graph;
+    bool use_graph;               // greedy micro-steps replayed from a hipGraph (default on)
+    bool use_graph_beam;          // beam frames: plain launches measured faster (no host polling to amortise), default off
 };
 
 namespace {
@@ -968,7 +1000,8 @@ template <int EPI>
 void launch_gemm(const GemmArgs &g, int n_cols_padded, int n_lanes, hipStream_t st)
 {
     const int mt = (n_lanes + 31) / 32, ct = n_cols_padded / 32;
-    if (mt == 1 || ct * mt <= 256) {
+    const int policy = tune_get(kTuneLaneGemmTile);               // 0: by occupancy, 1: 32-lane tiles, 2: 64-lane tiles
+    if (mt == 1 || policy == 1 || (policy == 0 && ct * mt <= 256)) {
         hipLaunchKernelGGL((lane_gemm_kernel<1, EPI>), dim3(ct, mt), dim3(64 * kGemmWaves), 0, st, g);
     } else {
         hipLaunchKernelGGL((lane_gemm_kernel<2, EPI>), dim3(ct, (mt + 1) / 2), dim3(64 * kGemmWaves), 0, st, g);
@@ -1045,6 +1078,7 @@ extern "C" int wr_decoder_create(const wr_transducer_weights *w, int max_lanes, 
     h->max_utt = max_utt; h->Tmax = Tmax; h->max_hyp = max_hyp; h->max_beam = max_beam;
     h->greedy_graph = nullptr; h->beam_graph = nullptr; h->greedy_graph_lanes = h->beam_graph_lanes = -1;
     h->use_graph = true;
+    h->use_graph_beam = false;
     h->stream_lanes = -1;
     h->h_active = nullptr;
     if (hipHostMalloc(reinterpret_cast<void **>(&h->h_active), 64, hipHostMallocDefault) != hipSuccess) {
@@ -1105,7 +1139,7 @@ extern "C" int wr_decoder_destroy(wr_decoder *h)
 extern "C" int wr_decoder_set_graph(wr_decoder *h, int enable)
 {
     WR_REQUIRE(h != nullptr, WR_EINVAL, "decoder_set_graph: null handle");
-    h->use_graph = enable != 0;
+    h->use_graph = h->use_graph_beam = enable != 0;
     return WR_OK;
 }
 
@@ -1262,13 +1296,13 @@ extern "C" int wr_prefix_beam_search(wr_decoder *h, const float *enc_out_d, cons
     hipLaunchKernelGGL(beam_init_kernel, dim3(NLn), dim3(128), 0, st, h->dev);
     WR_CHECK_LAUNCH("beam_init");
     const int key = NLn * 1000 + beam;
-    if (h->use_graph && h->beam_graph_lanes != key) {
+    if (h->use_graph_beam && h->beam_graph_lanes != key) {
         if (h->beam_graph) { (void)hipGraphExecDestroy(h->beam_graph); h->beam_graph = nullptr; }
         if (int rc = capture(st, kStepsPerGraph, [&] { beam_frame(h, NLn, B, st); }, &h->beam_graph)) return rc;
         h->beam_graph_lanes = key;
     }
     for (int f = 0; f < T; f += kStepsPerGraph) {
-        if (h->use_graph) {
+        if (h->use_graph_beam) {
             hipError_t e = hipGraphLaunch(h->beam_graph, st);
             if (e != hipSuccess) { set_error("prefix_beam_search: hipGraphLaunch failed: %s", hipGetErrorString(e)); return WR_ELAUNCH; }
         } else {

@@ -41,7 +41,7 @@ void set_error(const char *fmt, ...);
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- process-wide tuning knobs (wr_tune_set; defaults are the measured best) ----
-enum TuneKey { kTuneLseBlocksPerCu = 0, kTuneGradBlocksPerCu = 1, kTuneNonTemporal = 2, kTuneGradUnroll = 3, kTuneLseUnroll = 4, kTuneJointFwdVariant = 5, kTuneCount = 8 };
+enum TuneKey { kTuneLseBlocksPerCu = 0, kTuneGradBlocksPerCu = 1, kTuneNonTemporal = 2, kTuneGradUnroll = 3, kTuneLseUnroll = 4, kTuneJointFwdVariant = 5, kTuneLaneGemmTile = 6, kTuneCount = 8 };
 int tune_get(int key);
 
 // ---- device helpers ---------------------------------------------------------
@@ -86,6 +86,43 @@ __device__ __forceinline__ float lane_shift_down(float v, float fill)
     return __builtin_bit_cast(
         float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v),
                                            0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+
+// All-lanes max / min through DPP butterflies inside each row of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror,
+// row_mirror: four VALU ops, no LDS crossbar) and four readlanes across the rows.
+__device__ __forceinline__ float wave_allmax_dpp(float v)
+{
+#define WR_DPP_F(x, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, false))
+    v = fmaxf(v, WR_DPP_F(v, 0xB1));               // quad_perm:[1,0,3,2]
+    v = fmaxf(v, WR_DPP_F(v, 0x4E));               // quad_perm:[2,3,0,1]
+    v = fmaxf(v, WR_DPP_F(v, 0x141));              // row_half_mirror
+    v = fmaxf(v, WR_DPP_F(v, 0x140));              // row_mirror
+#undef WR_DPP_F
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+__device__ __forceinline__ int wave_allmin_dpp(int v)
+{
+#define WR_DPP_I(x, ctrl) __builtin_amdgcn_update_dpp(0, x, ctrl, 0xf, 0xf, false)
+    v = min(v, WR_DPP_I(v, 0xB1));
+    v = min(v, WR_DPP_I(v, 0x4E));
+    v = min(v, WR_DPP_I(v, 0x141));
+    v = min(v, WR_DPP_I(v, 0x140));
+#undef WR_DPP_I
+    const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    return min(min(r0, r1), min(r2, r3));
+}
+// wave-wide argmax with "first index on ties"; result in every lane
+__device__ __forceinline__ void wave_argmax_dpp(float &val, int &idx)
+{
+    const float m = wave_allmax_dpp(val);
+    idx = wave_allmin_dpp(val == m ? idx : 0x7fffffff);
+    val = m;
 }
 
 // block-wide argmax with "first index on ties"
