@@ -164,6 +164,21 @@ int wr_joint_bwd_dz(const float *gout_d /* [B,T,U1,V] */, const float *ep_d, con
                     int B, int T, int U1, int J, int V,
                     float *dz_d /* [B,T,U1,J] */, float *h_d /* [B,T,U1,J] or NULL */, void *stream);
 
+/* Split-precision joiner on the bf16 matrix cores (opt-in; the exact-fp32 entry points above stay the default).
+ * Same operator and arguments as wr_joint_fwd; every fp32 operand is split into bf16 hi + lo parts and
+ *   terms = 3:  a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulation -- logits within 1e-4 (relative to
+ *               their scale) of the fp32 result, at several times the rate of the exact-fp32 MFMA;
+ *   terms = 1:  a_hi*b_hi only: the AMP path (the reference under --use_amp, executor.py:91, runs ffn_out in
+ *               fp16 with fp32 accumulation).
+ * out_d has out_dtype (WR_F32 / WR_F16 / WR_BF16).  J even, at most 512. */
+size_t wr_joint_split_workspace_bytes(int J, int V);
+
+int wr_joint_fwd_split(const float *ep_d, const float *pp_d, const float *w_out_d, const float *b_out_d,
+                       const int32_t *logit_lengths_d /* nullable */, const int32_t *target_lengths_d /* nullable */,
+                       int B, int T, int U1, int J, int V, int terms,
+                       void *out_d /* [B,T,U1,V] */, int out_dtype,
+                       void *workspace_d, size_t workspace_bytes, void *stream);
+
 /* Weight gradient of ffn_out:  dw[v, :] = sum over lattice cells of gout[cell, v] * h[cell, :],
  * db[v] = sum of gout[cell, v]  (h = tanh(ep+pp) as written by wr_joint_bwd_dz).  With lengths, cells in the
  * padded region do not contribute.  db_d may be NULL.  Deterministic (partial slabs + ordered reduction). */

@@ -112,3 +112,77 @@ def test_unsupported_configuration_raises():
     m = w.TransducerJoint(10, 8, 8, 516).to(DEV)
     with pytest.raises(RuntimeError, match="join_dim"):
         m(torch.zeros(1, 2, 8, device=DEV), torch.zeros(1, 2, 8, device=DEV))
+
+
+# ---- split-precision forward on the bf16 matrix cores (wr_joint_fwd_split) ---------------------------------
+# Tolerances, relative to the r.m.s. of the logits: "bf16x3" (three split terms, fp32 accumulation) 1e-4 -- the
+# north-star bar of the fp32 path; "bf16" (single term, the AMP mode) 3e-2, the rounding of bf16 operands.
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 1e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("B,T,U1,E,P,J,V", [
+    (2, 9, 5, 32, 24, 128, 300),      # V not a multiple of 64: a partial last column pair
+    (1, 70, 3, 16, 16, 256, 1000),    # M = 210: a partial last 64-cell tile
+    (3, 11, 7, 64, 64, 512, 517),     # the shipped join_dim; odd V
+    (2, 13, 4, 8, 8, 36, 64),         # J not a multiple of 64 (zero-padded k depth), one column pair
+    (1, 40, 9, 16, 16, 512, 5000),    # the shipped vocabulary: 79 column pairs over 4 waves
+])
+def test_split_forward_parity_float64(precision, tol, B, T, U1, E, P, J, V):
+    g = torch.Generator().manual_seed(B * 100 + T + J + V)
+    import wenet_celoss_amd as w
+    m = w.TransducerJoint(V, E, P, J, precision=precision)
+    sd = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+    m = m.to(DEV)
+    enc = torch.randn(B, T, E, generator=g); pred = torch.randn(B, U1, P, generator=g)
+    gout = torch.randn(B, T, U1, V, generator=g)
+    ro, rg = ref64(enc.numpy(), pred.numpy(), sd, gout.numpy())
+    e = enc.to(DEV).requires_grad_(True); p = pred.to(DEV).requires_grad_(True)
+    out = m(e, p)
+    assert out.dtype == torch.float32
+    rms = float(np.sqrt((ro ** 2).mean()))
+    err = float(np.abs(out.detach().cpu().numpy() - ro).max())
+    assert err <= tol * rms, (err, rms)
+    # the backward kernels are the exact-fp32 ones in every mode
+    out.backward(gout.to(DEV))
+    scale = lambda a: 1e-4 * max(1.0, float(np.abs(a).max()))
+    np.testing.assert_allclose(e.grad.cpu().numpy(), rg["enc"], rtol=1e-4, atol=scale(rg["enc"]))
+    np.testing.assert_allclose(m.ffn_out.weight.grad.cpu().numpy(), rg["ffn_out.weight"], rtol=1e-4,
+                               atol=scale(rg["ffn_out.weight"]))
+
+
+def test_split_forward_lengths_and_loss():
+    """bf16x3 logits fed to the RNN-T loss: loss within 1e-5 relative of the exact-fp32 joiner's, padded tiles
+    skipped when lengths are given."""
+    import wenet_celoss_amd as w
+    torch.manual_seed(5)
+    B, T, U, E, P, J, V = 3, 80, 70, 16, 16, 128, 200
+    m = w.TransducerJoint(V, E, P, J).to(DEV)
+    enc = torch.randn(B, T, E, device=DEV); pred = torch.randn(B, U + 1, P, device=DEV)
+    y = torch.randint(1, V, (B, U), dtype=torch.int32, device=DEV)
+    ll = torch.tensor([80, 20, 5], dtype=torch.int32, device=DEV)
+    tl = torch.tensor([10, 70, 3], dtype=torch.int32, device=DEV)
+    losses = {}
+    for prec in ("fp32", "bf16x3"):
+        m.precision = prec
+        for lens in (False, True):
+            logits = m(enc, pred, ll, tl) if lens else m(enc, pred)
+            losses[prec, lens] = w.rnnt_loss(logits, y, ll, tl, blank=0, reduction="none").cpu()
+    torch.testing.assert_close(losses["bf16x3", False], losses["fp32", False], rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(losses["bf16x3", True], losses["bf16x3", False], rtol=1e-6, atol=1e-5)
+
+
+def test_split_forward_amp_dtype_and_errors():
+    import wenet_celoss_amd as w
+    torch.manual_seed(6)
+    m = w.TransducerJoint(96, 16, 16, 64, precision="bf16").to(DEV)
+    enc = torch.randn(2, 7, 16, device=DEV); pred = torch.randn(2, 4, 16, device=DEV)
+    ref = w.joint_logits(m.enc_ffn(enc), m.pred_ffn(pred), m.ffn_out.weight, m.ffn_out.bias)
+    for dt in (torch.float16, torch.bfloat16):
+        with torch.autocast("cuda", dtype=dt):
+            out = m(enc, pred)
+        assert out.dtype == dt                     # as the reference's Linear under autocast
+        assert float((out.detach().float() - ref.detach()).abs().max()) <= 5e-2 * float(ref.detach().std())
+    with pytest.raises(ValueError, match="precision"):
+        w.joint_logits(enc, pred, m.ffn_out.weight, m.ffn_out.bias, precision="fp8")
+    from wenet_celoss_amd import _lib
+    lib = _lib.load()
+    assert lib.wr_joint_fwd_split(None, None, None, None, None, None, 1, 1, 1, 64, 10, 2, None, 0, None, 0, None) != 0
+    assert b"terms" in lib.wr_last_error()

@@ -44,6 +44,25 @@ def bench_joint(args):
                           "TFLOPs": round(flops / ms / 1e9, 2), "peak_f32_mfma": 157.3,
                           "frac": round(flops / ms / 1e9 / 157.3, 4), "probe": chk}), flush=True)
     lib.wr_tune_set(5, 2)
+    f()
+    # split-precision variants on the bf16 matrix cores, checked against the exact-fp32 logits just computed
+    wsb_s = lib.wr_joint_split_workspace_bytes(J, V)
+    ws_s = torch.empty(wsb_s, dtype=torch.uint8, device=dev)
+    scale = float(out[0, :8].std())
+    for terms, odt, code, parts in ((3, torch.float32, 0, 1), (3, torch.float32, 0, 2), (3, torch.float32, 0, 4),
+                                    (1, torch.float32, 0, 1), (1, torch.float32, 0, 2), (1, torch.bfloat16, 2, 1), (1, torch.bfloat16, 2, 2)):
+        lib.wr_tune_set(7, parts)
+        out_s = torch.empty(B, T, U1, V, dtype=odt, device=dev)
+        fs = lambda: _lib.check(lib.wr_joint_fwd_split(P(ep), P(pp), P(w), P(b), None, None, B, T, U1, J, V, terms,
+                                                       P(out_s), code, P(ws_s), wsb_s, st))
+        ms = timeit(fs, args.steps)
+        err = float((out_s[:1].float() - out[:1]).abs().max())
+        print(json.dumps({"what": "joint_fwd_split", "terms": terms, "parts": parts, "out": str(odt).split(".")[-1],
+                          "shape": [B, T, U1, J, V], "ms": round(ms, 3), "TFLOPs_fp32_equiv": round(flops / ms / 1e9, 2),
+                          "bf16_TFLOPs": round(terms * flops / ms / 1e9, 1), "frac_of_2500": round(terms * flops / ms / 1e9 / 2500, 4),
+                          "max_abs_err_vs_fp32": err, "logit_std": scale, "rel_to_scale": err / scale}), flush=True)
+        del out_s
+    lib.wr_tune_set(7, 0)
     dz = torch.empty(B, T, U1, J, device=dev); h = torch.empty_like(dz)
     g = lambda: _lib.check(lib.wr_joint_bwd_dz(P(out), P(ep), P(pp), P(w), None, None, B, T, U1, J, V, P(dz), P(h), st))
     ms = timeit(g, args.steps)

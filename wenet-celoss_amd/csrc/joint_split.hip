@@ -1,0 +1,366 @@
+// Transducer joint network on the bf16 matrix cores of MI355X (gfx950), split precision.
+//
+// Same operator as joint.hip (TransducerJoint.forward, wenet/transducer/joint.py:60-69, from the point where
+// ep = enc_ffn(enc) [B,T,J] and pp = pred_ffn(pred) [B,U1,J] exist):
+//     out[m, v] = sum_k tanh(ep[bt(m),k] + pp[bu(m),k]) * W[v,k] + bias[v]
+// but the 512 -> V contraction runs on v_mfma_f32_32x32x16_bf16 (16x the rate of the exact-fp32 MFMA) with
+// every fp32 operand x split into two bf16 numbers  x = hi + lo + O(2^-17 |x|):
+//     terms = 3:  a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi      (dropped: a_lo*b_lo ~ 2^-16 |a*b|)
+//                 fp32 accumulation; |error| of a logit ~ 1e-5 of its scale -- inside the 1e-4 parity bar
+//                 of the fp32 path (tests/test_joint_gpu.py states the tolerance);
+//     terms = 1:  a_hi*b_hi only -- the AMP path: the reference under --use_amp (executor.py:91 autocast)
+//                 runs this Linear in fp16 with fp32 accumulation; bf16 operands, fp32 accumulate here.
+// The exact-fp32 kernels of joint.hip stay the default; this file is opt-in (precision argument of
+// wenet_celoss_amd.TransducerJoint / joint_logits, or WR_JOINT_PRECISION).
+//
+// Forward  joint_fwd_split_kernel: one workgroup (4 waves, one per SIMD, 512 registers each) owns 64 consecutive
+//   lattice cells and all V columns.  H = tanh(ep + pp) (64 x J; tanh through v_exp/v_rcp) is computed once,
+//   split, and kept in LDS as bf16 hi / lo images (row-major, 16-byte padded rows: conflict-free ds_read_b128
+//   fragments, read one k-step ahead of their MFMAs); W is re-laid once per call into MFMA fragment order (hi
+//   and lo images; each (32 columns x 16 k) fragment = 1 KB contiguous) and streamed from L2 / Infinity Cache
+//   straight into three rotating register sets of 4 k-steps (two in flight, 32 KB per wave).  A wave owns 64
+//   columns (2 tiles) per round: 2 row tiles x 2 column tiles x `terms` MFMAs per k-step; logits leave with
+//   non-temporal stores.  Measured (B=8, T=1000, U1=151, J=512, V=5000): terms=3 20.8 ms = 297 TFLOP/s
+//   fp32-equivalent (892 TFLOP/s of bf16 MFMA, 2.7x the exact-fp32 kernel), terms=1 13.8 ms; matrix cores 40 %
+//   busy (SQ_VALU_MFMA_BUSY_CYCLES) -- with one wave per SIMD the tile build, the k-loop and the epilogue of a
+//   workgroup do not overlap, and 138 KB of LDS per workgroup rules out a second one per CU.
+#include "wr_common.hpp"
+
+namespace wr {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kSM = 64;          // lattice cells per workgroup
+constexpr int kSCT = 2;          // 32-column tiles per wave per round
+constexpr int kSWaves = 4;       // one per SIMD, 512 registers each: three fragment sets without register reuse stalls
+constexpr int kSPF = 4;          // k-steps (of 16) per register set; three sets rotate, two are in flight
+
+inline int split_jpad(int J) { return (J + 16 * kSPF - 1) / (16 * kSPF) * (16 * kSPF); }
+inline int split_vpad(int V) { return (V + 32 * kSCT - 1) / (32 * kSCT) * (32 * kSCT); }
+
+// round-to-nearest-even bf16 of a finite float
+__device__ __forceinline__ unsigned bf16_bits(float x)
+{
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void split_bf16(float x, unsigned &hi, unsigned &lo)
+{
+    hi = bf16_bits(x);
+    lo = bf16_bits(x - __builtin_bit_cast(float, hi << 16));
+}
+
+// tanh through the hardware exp2 / rcp (|error| ~ 1e-7 absolute: below the split's own 2^-17 operand error)
+__device__ __forceinline__ float tanh_fast(float x)
+{
+    const float t = __builtin_amdgcn_exp2f(fabsf(x) * 2.885390082f);      // e^{2|x|}
+    const float r = 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
+    return __builtin_copysignf(r, x);
+}
+
+// W [V, J] (nn.Linear weight) -> fragment-major hi / lo images:
+//   frag[(ct * S + s) * 64 + l][j] = W[ct*32 + (l & 31)][s*16 + 8*(l >> 5) + j]      (zero outside V x J)
+__global__ void split_w_kernel(const float *__restrict__ w, int V, int J, int Vp, int Jp, unsigned short *__restrict__ wh,
+                               unsigned short *__restrict__ wl)
+{
+    const int S = Jp / 16;
+    const long total = (long)(Vp / 32) * S * 64;
+    for (long f = (long)blockIdx.x * blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
+        const int l = (int)(f & 63);
+        const long cs = f >> 6;
+        const int s = (int)(cs % S), ct = (int)(cs / S);
+        const int v = ct * 32 + (l & 31), k0 = s * 16 + 8 * (l >> 5);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = (v < V && k0 + j < J) ? w[(size_t)v * J + k0 + j] : 0.f;
+            unsigned hi, lo;
+            split_bf16(x, hi, lo);
+            wh[f * 8 + j] = (unsigned short)hi;
+            wl[f * 8 + j] = (unsigned short)lo;
+        }
+    }
+}
+
+template <typename OutT> __device__ __forceinline__ OutT to_out(float x);
+template <> __device__ __forceinline__ float to_out<float>(float x) { return x; }
+template <> __device__ __forceinline__ _Float16 to_out<_Float16>(float x) { return (_Float16)x; }
+template <> __device__ __forceinline__ __bf16 to_out<__bf16>(float x) { return (__bf16)x; }
+
+template <int TERMS, typename OutT>
+__global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
+    const float *__restrict__ ep, const float *__restrict__ pp, const u32x4 *__restrict__ wh, const u32x4 *__restrict__ wl,
+    const float *__restrict__ bias, const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens, int B, int T,
+    int U1, int J, int Jp, int V, int Vp, int npart, OutT *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds_s[];
+    const int JS = Jp + 8;                                 // padded row stride (bf16 elements): 16-byte pad
+    unsigned short *Ahi = lds_s;                            // [64][JS]
+    unsigned short *Alo = lds_s + (size_t)kSM * JS;         // [64][JS]   (TERMS == 3)
+    float *bias_s = reinterpret_cast<float *>(lds_s + (size_t)(TERMS == 3 ? 2 : 1) * kSM * JS);   // this part's bias
+    const long M = (long)B * T * U1;
+    // consecutive workgroups land on consecutive XCDs: part = blockIdx % npart keeps each XCD on one column slab of W
+    // (<= ~2.5 MB of fragments, resident in its 4 MB L2) for the whole launch
+    const int part = blockIdx.x % npart;
+    const long m0 = (long)(blockIdx.x / npart) * kSM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    if (llens != nullptr && tlens != nullptr) {
+        int valid = 0;
+        const long m = m0 + tid;
+        if (tid < kSM && m < M) {
+            const long bt = m / U1;
+            const int u = (int)(m - bt * U1);
+            const int b = (int)(bt / T), t = (int)(bt - (long)b * T);
+            valid = (t < llens[b]) && (u <= tlens[b]);
+        }
+        if (!__syncthreads_or(valid)) return;
+    }
+    const int S = Jp / 16;                                  // k-steps per column tile; Jp is a multiple of 16 * kSPF
+    const int cpr = S / kSPF;                               // register sets ("chunks") per round
+    const int n_ct = Vp / 32;                               // column tiles
+    const int pairs = n_ct / kSCT;                          // a wave's unit of work: 64 columns
+    const int ppp = (pairs + npart - 1) / npart;            // pairs per part
+    const int pair0 = part * ppp;
+    const int npairs = pairs - pair0 < ppp ? pairs - pair0 : ppp;
+    if (npairs <= 0) return;
+    const int rounds = (npairs + kSWaves - 1) / kSWaves;
+    const int total = rounds * cpr;
+
+    // fragment pointers of this lane
+    const u32x4 *__restrict__ whl = wh + lane;
+    const u32x4 *__restrict__ wll = wl + lane;
+
+    auto load_set = [&](int ci, u32x4 (&bh)[kSPF][kSCT], u32x4 (&bl)[kSPF][kSCT]) {
+        const int cc = ci < total ? ci : total - 1;
+        const int r = cc / cpr, c0 = cc - r * cpr;
+        const int pr = r * kSWaves + wave;
+        const int ct0 = (pair0 + (pr < npairs ? pr : npairs - 1)) * kSCT;   // waves past the last pair reload it (results dropped)
+#pragma unroll
+        for (int i = 0; i < kSPF; ++i) {
+            const int s = c0 * kSPF + i;
+#pragma unroll
+            for (int c = 0; c < kSCT; ++c) {
+                const size_t f = ((size_t)(ct0 + c) * S + s) * 64;
+                bh[i][c] = whl[f];
+                if (TERMS == 3) bl[i][c] = wll[f];
+            }
+        }
+    };
+    u32x4 pbh[kSPF][kSCT], pbl[kSPF][kSCT], qbh[kSPF][kSCT], qbl[kSPF][kSCT], rbh[kSPF][kSCT], rbl[kSPF][kSCT];
+
+    // bias of this part's columns -> LDS (read back per round without touching the vector-memory counter)
+    for (int i = tid; i < npairs * 32 * kSCT; i += 64 * kSWaves) {
+        const int col = pair0 * 32 * kSCT + i;
+        bias_s[i] = col < V ? bias[col] : 0.f;
+    }
+    // activation tile: a wave takes rows wave, wave+4, ...; four rows (32 loads per lane) in flight at a time;
+    // a lane owns the k pairs 2*lane + 128*i (packed 32-bit LDS writes)
+    constexpr int KI = 4;                                   // Jp <= 512: at most 4 k pairs per lane per row
+    static_assert(kSM / kSWaves % 4 == 0, "rows per wave");
+    for (int rb = 0; rb < kSM / kSWaves; rb += 4) {
+        float2 ev[4][KI], pv[4][KI];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = wave + kSWaves * (rb + q);
+            const long m = m0 + row < M ? m0 + row : M - 1;
+            const long bt = m / U1;
+            const int u = (int)(m - bt * U1);
+            const long b = bt / T;
+            const float *__restrict__ e = ep + (size_t)bt * J;
+            const float *__restrict__ p = pp + ((size_t)b * U1 + u) * J;
+#pragma unroll
+            for (int i = 0; i < KI; ++i) {
+                const int k = 2 * lane + 128 * i;
+                const int kc = k < J ? k : J - 2;           // J is even
+                ev[q][i] = *reinterpret_cast<const float2 *>(e + kc);
+                pv[q][i] = *reinterpret_cast<const float2 *>(p + kc);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = wave + kSWaves * (rb + q);
+            const bool in = m0 + row < M;
+#pragma unroll
+            for (int i = 0; i < KI; ++i) {
+                const int k = 2 * lane + 128 * i;
+                if (k >= Jp) continue;
+                const bool kin = in && k < J;
+                const float x0 = kin ? tanh_fast(ev[q][i].x + pv[q][i].x) : 0.f;
+                const float x1 = kin ? tanh_fast(ev[q][i].y + pv[q][i].y) : 0.f;
+                unsigned h0, l0, h1, l1;
+                split_bf16(x0, h0, l0);
+                split_bf16(x1, h1, l1);
+                *reinterpret_cast<unsigned *>(Ahi + (size_t)row * JS + k) = h0 | (h1 << 16);
+                if (TERMS == 3) *reinterpret_cast<unsigned *>(Alo + (size_t)row * JS + k) = l0 | (l1 << 16);
+            }
+        }
+    }
+    __syncthreads();
+
+    const unsigned short *a_hi = Ahi + (size_t)l31 * JS + 8 * half;
+    const unsigned short *a_lo = Alo + (size_t)l31 * JS + 8 * half;
+    f32x16 acc[2][kSCT];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < kSCT; ++c) acc[r][c] = (f32x16){0};
+
+    // A fragments (LDS) run one k-step ahead of the MFMAs that consume them
+    bf16x8 ah[2][2], al[2][2];                              // [buffer][row tile]
+    auto read_a = [&](int s, int buf) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            ah[buf][r] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(a_hi + (size_t)(32 * r) * JS + 16 * s));
+            if (TERMS == 3)
+                al[buf][r] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(a_lo + (size_t)(32 * r) * JS + 16 * s));
+        }
+    };
+    load_set(0, pbh, pbl);
+    load_set(1, qbh, qbl);
+    read_a(0, 0);
+    auto mfma_set = [&](int ci, const u32x4 (&bh)[kSPF][kSCT], const u32x4 (&bl)[kSPF][kSCT]) {
+        const int c0 = ci % cpr;
+        const int cn = (c0 + 1 == cpr) ? 0 : c0 + 1;        // next chunk's first step (wraps to the next round)
+#pragma unroll
+        for (int i = 0; i < kSPF; ++i) {
+            const int buf = i & 1;                          // kSPF is even: every chunk starts on buffer 0
+            read_a(i + 1 < kSPF ? c0 * kSPF + i + 1 : cn * kSPF, buf ^ 1);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int c = 0; c < kSCT; ++c) {
+                    const bf16x8 bhv = __builtin_bit_cast(bf16x8, bh[i][c]);
+                    if (TERMS == 3) {
+                        const bf16x8 blv = __builtin_bit_cast(bf16x8, bl[i][c]);
+                        acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[buf][r], bhv, acc[r][c], 0, 0, 0);   // small terms first
+                        acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[buf][r], blv, acc[r][c], 0, 0, 0);
+                    }
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[buf][r], bhv, acc[r][c], 0, 0, 0);
+                }
+        }
+    };
+    auto finish_round = [&](int ci) {                       // after the last chunk of a round: bias, store, reset
+        if ((ci + 1) % cpr != 0) return;
+        const int r = ci / cpr;
+        const int pr = r * kSWaves + wave;
+        const int ct0 = (pair0 + pr) * kSCT;
+#pragma unroll
+        for (int c = 0; c < kSCT; ++c) {
+            const int col = (ct0 + c) * 32 + l31;
+            const bool colin = pr < npairs && col < V;
+            const float bv = colin ? bias_s[(pr * kSCT + c) * 32 + l31] : 0.f;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int row = 32 * rt + (q & 3) + 8 * (q >> 2) + 4 * half;   // C/D layout of the 32x32 MFMA
+                    const long m = m0 + row;
+                    // streaming store: the logits must not push the W slab out of L2
+                    if (m < M && colin) __builtin_nontemporal_store(to_out<OutT>(acc[rt][c][q] + bv), out + (size_t)m * V + col);
+                }
+                acc[rt][c] = (f32x16){0};
+            }
+        }
+    };
+
+    for (int ci = 0; ci < total; ci += 3) {
+        load_set(ci + 2, rbh, rbl);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_set(ci, pbh, pbl);
+        finish_round(ci);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ci + 1 >= total) break;
+        load_set(ci + 3, pbh, pbl);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_set(ci + 1, qbh, qbl);
+        finish_round(ci + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ci + 2 >= total) break;
+        load_set(ci + 4, qbh, qbl);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_set(ci + 2, rbh, rbl);
+        finish_round(ci + 2);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+int split_check(int B, int T, int U1, int J, int V, int terms, int out_dtype)
+{
+    WR_REQUIRE(B > 0 && T > 0 && U1 > 0 && J > 0 && V > 0, WR_EINVAL,
+               "joint_split: B, T, U1, J, V must be positive (got %d,%d,%d,%d,%d)", B, T, U1, J, V);
+    WR_REQUIRE(J % 2 == 0 && J <= 512, WR_EUNSUPPORTED, "joint_split: join_dim=%d not supported (even, at most 512)", J);
+    WR_REQUIRE(terms == 1 || terms == 3, WR_EINVAL, "joint_split: terms must be 1 (bf16) or 3 (split fp32), got %d", terms);
+    WR_REQUIRE(out_dtype >= 0 && out_dtype <= 2, WR_EINVAL, "joint_split: bad output dtype code %d", out_dtype);
+    WR_REQUIRE(((long)B * T * U1 + kSM - 1) / kSM < (1L << 31), WR_EUNSUPPORTED, "joint_split: too many lattice cells");
+    return WR_OK;
+}
+
+}  // namespace
+}  // namespace wr
+
+using namespace wr;
+
+extern "C" size_t wr_joint_split_workspace_bytes(int J, int V)
+{
+    if (J <= 0 || V <= 0) return 0;
+    return 2 * align_up((size_t)split_jpad(J) * split_vpad(V) * sizeof(unsigned short), 256);
+}
+
+extern "C" int wr_joint_fwd_split(const float *ep_d, const float *pp_d, const float *w_out_d, const float *b_out_d,
+                                  const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B, int T, int U1,
+                                  int J, int V, int terms, void *out_d, int out_dtype, void *workspace_d,
+                                  size_t workspace_bytes, void *stream)
+{
+    if (int rc = split_check(B, T, U1, J, V, terms, out_dtype)) return rc;
+    WR_REQUIRE(ep_d && pp_d && w_out_d && b_out_d && out_d && workspace_d, WR_EINVAL,
+               "joint_fwd_split: null pointer argument");
+    WR_REQUIRE((logit_lengths_d == nullptr) == (target_lengths_d == nullptr), WR_EINVAL,
+               "joint_fwd_split: pass both length arrays or neither");
+    const int Vp = split_vpad(V), Jp = split_jpad(J);
+    const size_t img = align_up((size_t)Jp * Vp * sizeof(unsigned short), 256);
+    WR_REQUIRE(workspace_bytes >= 2 * img, WR_EWORKSPACE, "joint_fwd_split: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned short *wh = static_cast<unsigned short *>(workspace_d);
+    unsigned short *wl = reinterpret_cast<unsigned short *>(static_cast<char *>(workspace_d) + img);
+    hipLaunchKernelGGL(split_w_kernel, dim3(512), dim3(256), 0, st, w_out_d, V, J, Vp, Jp, wh, wl);
+    WR_CHECK_LAUNCH("split_w_kernel");
+    const long M = (long)B * T * U1;
+    // Column slabs per XCD (part = blockIdx % npart) would keep W in each XCD's L2; measured (B=8: 20.8 / 21.5 / 23.0 ms
+    // for 1 / 2 / 4 parts) the Infinity Cache already feeds the fragments fast enough and the extra activation tiles
+    // cost more, so one part is the default; wr_tune_set(7, n) overrides for experiments.
+    int npart = 1;
+    if (const int forced = tune_get(kTuneSplitParts)) npart = forced;
+    const size_t tile_lds = (size_t)(terms == 3 ? 2 : 1) * kSM * (Jp + 8) * sizeof(unsigned short);
+    while (npart < 64 && tile_lds + (size_t)((Vp / (32 * kSCT) + npart - 1) / npart) * 32 * kSCT * sizeof(float) > 160 * 1024)
+        npart *= 2;                                         // large vocabularies: the bias slab must fit beside the tile
+    WR_REQUIRE((M + kSM - 1) / kSM * npart < (1L << 31), WR_EUNSUPPORTED, "joint_fwd_split: too many lattice cells");
+    const int pairs_per_part = (Vp / (32 * kSCT) + npart - 1) / npart;
+    const size_t lds = (size_t)(terms == 3 ? 2 : 1) * kSM * (Jp + 8) * sizeof(unsigned short) +
+                       (size_t)pairs_per_part * 32 * kSCT * sizeof(float);
+    WR_REQUIRE(lds <= 160 * 1024, WR_EUNSUPPORTED, "joint_fwd_split: V=%d needs %zu bytes of LDS", V, lds);
+    const dim3 grid((unsigned)((M + kSM - 1) / kSM * npart));
+#define WR_LAUNCH_SPLIT(TERMS, OutT)                                                                                  \
+    do {                                                                                                              \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_fwd_split_kernel<TERMS, OutT>),                  \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+        hipLaunchKernelGGL((joint_fwd_split_kernel<TERMS, OutT>), grid, dim3(64 * kSWaves), lds, st, ep_d, pp_d,       \
+                           reinterpret_cast<const u32x4 *>(wh), reinterpret_cast<const u32x4 *>(wl), b_out_d,          \
+                           logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, npart, static_cast<OutT *>(out_d));     \
+    } while (0)
+    if (terms == 3) {
+        if (out_dtype == 0) WR_LAUNCH_SPLIT(3, float);
+        else if (out_dtype == 1) WR_LAUNCH_SPLIT(3, _Float16);
+        else WR_LAUNCH_SPLIT(3, __bf16);
+    } else {
+        if (out_dtype == 0) WR_LAUNCH_SPLIT(1, float);
+        else if (out_dtype == 1) WR_LAUNCH_SPLIT(1, _Float16);
+        else WR_LAUNCH_SPLIT(1, __bf16);
+    }
+#undef WR_LAUNCH_SPLIT
+    WR_CHECK_LAUNCH("joint_fwd_split_kernel");
+    return WR_OK;
+}
