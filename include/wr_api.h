@@ -179,6 +179,18 @@ int wr_joint_fwd_split(const float *ep_d, const float *pp_d, const float *w_out_
                        void *out_d /* [B,T,U1,V] */, int out_dtype,
                        void *workspace_d, size_t workspace_bytes, void *stream);
 
+/* wr_joint_bwd_dz on the bf16 matrix cores, same split as wr_joint_fwd_split (terms = 3: gout and w_out split into
+ * bf16 hi + lo, three MFMA terms, fp32 accumulation; terms = 1: single bf16 product).  Same outputs as
+ * wr_joint_bwd_dz (H = tanh(ep+pp) recomputed with the exact tanhf).  V a multiple of 4, at least 32. */
+size_t wr_joint_dz_split_workspace_bytes(int J, int V);
+
+int wr_joint_bwd_dz_split(const float *gout_d /* [B,T,U1,V] */, const float *ep_d, const float *pp_d,
+                          const float *w_out_d,
+                          const int32_t *logit_lengths_d /* nullable */, const int32_t *target_lengths_d /* nullable */,
+                          int B, int T, int U1, int J, int V, int terms,
+                          float *dz_d /* [B,T,U1,J] */, float *h_d /* [B,T,U1,J] or NULL */,
+                          void *workspace_d, size_t workspace_bytes, void *stream);
+
 /* Weight gradient of ffn_out:  dw[v, :] = sum over lattice cells of gout[cell, v] * h[cell, :],
  * db[v] = sum of gout[cell, v]  (h = tanh(ep+pp) as written by wr_joint_bwd_dz).  With lengths, cells in the
  * padded region do not contribute.  db_d may be NULL.  Deterministic (partial slabs + ordered reduction). */

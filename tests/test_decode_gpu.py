@@ -254,3 +254,26 @@ def test_fork_hotword_greedy_matches_reference(path):
                                  context_lengths=ctx_len, context_filter_state=str(d["filt"]),
                                  context_decoder_labels_padded=labels)
     assert hyps == [list(d["hyp"])] and dist == float(d["dist"])
+
+
+def test_stream_state_is_invalidated_by_other_searches_on_the_handle():
+    """A chunk continuation after the handle's lanes were reused (predictor step / beam search) must be refused,
+    not decoded from clobbered caches."""
+    from wenet_celoss_amd.decoder import DeviceDecoder
+    d = np.load(names("greedy_core_1.npz")[0])
+    pred, joint, _ = build_modules(d)
+    dec = DeviceDecoder(pred, joint, max_lanes=4, max_utt=2, tmax=32, max_hyp=256, max_beam=2)
+    enc = torch.tensor(d["enc"], device=DEV)[:, :16].contiguous()
+    lens = torch.tensor([16])
+    first = dec.greedy_chunk(enc, lens, n_steps=4, reset=True)
+    again = dec.greedy_chunk(enc, lens, n_steps=4, reset=False)          # a legal continuation
+    assert isinstance(first, list) and isinstance(again, list)
+    L, H = dec.dims["L"], dec.dims["H"]
+    dec.predictor_step(torch.tensor([1]), torch.zeros(L, 1, H, device=DEV), torch.zeros(L, 1, H, device=DEV))
+    with pytest.raises(RuntimeError, match="no stream state"):
+        dec.greedy_chunk(enc, lens, n_steps=4, reset=False)
+    dec.greedy_chunk(enc, lens, n_steps=4, reset=True)
+    V = dec.dims["V"]
+    dec.prefix_beam(enc, lens, torch.log_softmax(torch.randn(1, 16, V, device=DEV), -1), 2, 0.3, 0.7)
+    with pytest.raises(RuntimeError, match="no stream state"):
+        dec.greedy_chunk(enc, lens, n_steps=4, reset=False)

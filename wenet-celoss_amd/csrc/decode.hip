@@ -1281,6 +1281,7 @@ extern "C" int wr_prefix_beam_search(wr_decoder *h, const float *enc_out_d, cons
                "prefix_beam_search: B*beam=%d exceeds the decoder's capacity", B * beam);
     WR_REQUIRE(T > 0 && T <= h->Tmax, WR_EINVAL, "prefix_beam_search: T=%d exceeds the decoder's Tmax=%d", T, h->Tmax);
     WR_REQUIRE(blank >= 0 && blank < h->d.V, WR_EINVAL, "prefix_beam_search: bad blank");
+    h->stream_lanes = -1;                         // the lanes' streaming state (caches, tokens) is overwritten
     hipStream_t caller = static_cast<hipStream_t>(stream);
     hipStream_t st = enter(h, caller);
     DevState &s = h->host;
@@ -1357,6 +1358,7 @@ extern "C" int wr_predictor_step(wr_decoder *h, const int32_t *tokens_d, const f
     WR_REQUIRE(h && tokens_d && cache_h_d && cache_c_d && out_d && new_h_d && new_c_d, WR_EINVAL,
                "predictor_step: null pointer argument");
     WR_REQUIRE(N > 0 && N <= h->d.NL, WR_EINVAL, "predictor_step: N=%d exceeds the decoder's capacity %d", N, h->d.NL);
+    h->stream_lanes = -1;                         // the lanes' streaming state (caches, tokens) is overwritten
     hipStream_t caller = static_cast<hipStream_t>(stream);
     hipStream_t st = enter(h, caller);
     const Dims &d = h->d;

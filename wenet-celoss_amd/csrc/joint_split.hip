@@ -288,6 +288,215 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
     }
 }
 
+// ------------------------------------------------------------- backward, dZ --
+// dZ[m, j] = (sum_v dY[m, v] * W[v, j]) * (1 - H[m, j]^2),  H = tanh(ep + pp) recomputed (exact tanhf).
+// One workgroup (4 waves) owns 64 cells and all J columns: a wave holds 2 row tiles x 4 column tiles of fp32
+// accumulators (128 registers).  The reduction runs over the vocabulary in double steps of 32: lane half h reads
+// 16 consecutive floats dY[row][32 d + 16 h ...] (64 bytes; a row's two halves make one 128-byte line), splits
+// them into bf16 hi / lo in registers and feeds two MFMAs (elements 0-7, then 8-15); W is re-laid once per call
+// into fragments that follow the same k permutation (k = 32 d + 16 h + 8 t + e), hi and lo images, and streamed
+// from L2 / Infinity Cache.  Three rotating register sets (dY + W of one double step each), two in flight.
+constexpr int kZWaves = 4;
+constexpr int kZCT = 4;          // column tiles per wave: 4 waves x 4 x 32 = 512 = the largest join_dim
+
+// frag[((jt * D + d) * 2 + t) * 64 + l][e] = W[32 d + 16 (l >> 5) + 8 t + e][jt * 32 + (l & 31)]   (zero outside V x J)
+__global__ void split_w_dz_kernel(const float *__restrict__ w, int V, int J, int D, int n_jt, unsigned short *__restrict__ wh,
+                                  unsigned short *__restrict__ wl)
+{
+    const long total = (long)n_jt * D * 2 * 64;
+    for (long f = (long)blockIdx.x * blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
+        const int l = (int)(f & 63);
+        const long r = f >> 6;
+        const int t = (int)(r & 1);
+        const long jd = r >> 1;
+        const int d = (int)(jd % D), jt = (int)(jd / D);
+        const int j = jt * 32 + (l & 31), v0 = 32 * d + 16 * (l >> 5) + 8 * t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = (j < J && v0 + e < V) ? w[(size_t)(v0 + e) * J + j] : 0.f;
+            unsigned hi, lo;
+            split_bf16(x, hi, lo);
+            wh[f * 8 + e] = (unsigned short)hi;
+            wl[f * 8 + e] = (unsigned short)lo;
+        }
+    }
+}
+
+// eight floats -> bf16x8 hi (and lo) fragments
+__device__ __forceinline__ void split8(const f32x4 &a, const f32x4 &b, bf16x8 &hi, bf16x8 &lo, bool want_lo)
+{
+    unsigned h[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        split_bf16(a[i], h[i], l[i]);
+        split_bf16(b[i], h[4 + i], l[4 + i]);
+    }
+    u32x4 ph, pl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ph[i] = h[2 * i] | (h[2 * i + 1] << 16);
+        pl[i] = l[2 * i] | (l[2 * i + 1] << 16);
+    }
+    hi = __builtin_bit_cast(bf16x8, ph);
+    if (want_lo) lo = __builtin_bit_cast(bf16x8, pl);
+}
+
+template <int TERMS>
+__global__ __launch_bounds__(64 * kZWaves) void joint_bwd_dz_split_kernel(
+    const float *__restrict__ gout /* [M, V] */, const float *__restrict__ ep, const float *__restrict__ pp,
+    const u32x4 *__restrict__ wh, const u32x4 *__restrict__ wl, const int32_t *__restrict__ llens,
+    const int32_t *__restrict__ tlens, int B, int T, int U1, int J, int V, int D, int n_jt,
+    float *__restrict__ dz /* [M, J] */, float *__restrict__ hout /* [M, J] or null */)
+{
+    __shared__ long row_e[kSM], row_p[kSM];                 // offsets of the rows' ep / pp vectors
+    __shared__ int row_ok[kSM];
+    const long M = (long)B * T * U1;
+    const long m0 = (long)blockIdx.x * kSM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    int valid = 0;
+    if (tid < kSM) {
+        const long m = m0 + tid < M ? m0 + tid : M - 1;
+        const long bt = m / U1;
+        const int u = (int)(m - bt * U1);
+        const long b = bt / T;
+        valid = m0 + tid < M;
+        if (valid && llens != nullptr && tlens != nullptr) {
+            const int t = (int)(bt - b * T);
+            valid = (t < llens[b]) && (u <= tlens[b]);
+        }
+        row_e[tid] = bt * J;
+        row_p[tid] = (b * U1 + u) * J;
+        row_ok[tid] = valid;
+    }
+    const bool any = __syncthreads_or(valid);               // also publishes the row tables
+    if (!any) {                                             // wholly padded tile: zeros, no arithmetic
+        for (int i = tid; i < kSM * J; i += 64 * kZWaves) {
+            const long m = m0 + i / J;
+            if (m < M) {
+                dz[(size_t)m * J + i % J] = 0.f;
+                if (hout) hout[(size_t)m * J + i % J] = 0.f;
+            }
+        }
+        return;
+    }
+
+    f32x16 acc[2][kZCT];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < kZCT; ++c) acc[r][c] = (f32x16){0};
+
+    // this lane's dY rows (clamped to the tensor) and W fragments (column tiles past join_dim reload the last one)
+    const float *__restrict__ arow[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const long m = m0 + 32 * r + l31 < M ? m0 + 32 * r + l31 : M - 1;
+        arow[r] = gout + (size_t)m * V + 16 * half;
+    }
+    int jt_w[kZCT];
+#pragma unroll
+    for (int c = 0; c < kZCT; ++c) jt_w[c] = wave * kZCT + c < n_jt ? wave * kZCT + c : n_jt - 1;
+    const u32x4 *__restrict__ whl = wh + lane;
+    const u32x4 *__restrict__ wll = wl + lane;
+    const int Dfull = V / 32;                               // double steps that lie wholly inside a row (V >= 32)
+
+    struct Set { f32x4 a[2][4]; u32x4 bh[kZCT][2], bl[kZCT][2]; };
+    auto load_b = [&](int dd, Set &z) {
+#pragma unroll
+        for (int c = 0; c < kZCT; ++c)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const size_t f = (((size_t)jt_w[c] * D + dd) * 2 + t) * 64;
+                z.bh[c][t] = whl[f];
+                if (TERMS == 3) z.bl[c][t] = wll[f];
+            }
+    };
+    auto load_set = [&](int d, Set &z) {                    // prefetches past the end reload the last full step
+        const int dd = d < Dfull ? d : Dfull - 1;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z.a[r][i] = *reinterpret_cast<const f32x4 *>(arow[r] + 32 * dd + 4 * i);
+        load_b(dd, z);
+    };
+    auto mfma_set = [&](Set &z) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            bf16x8 ah[2], al[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) split8(z.a[r][2 * t], z.a[r][2 * t + 1], ah[r], al[r], TERMS == 3);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int c = 0; c < kZCT; ++c) {
+                    const bf16x8 bhv = __builtin_bit_cast(bf16x8, z.bh[c][t]);
+                    if (TERMS == 3) {
+                        const bf16x8 blv = __builtin_bit_cast(bf16x8, z.bl[c][t]);
+                        acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[r], bhv, acc[r][c], 0, 0, 0);
+                        acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[r], blv, acc[r][c], 0, 0, 0);
+                    }
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[r], bhv, acc[r][c], 0, 0, 0);
+                }
+        }
+    };
+    Set s0, s1, s2;
+    load_set(0, s0);
+    load_set(1, s1);
+    for (int d = 0; d < Dfull; d += 3) {
+        load_set(d + 2, s2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_set(s0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (d + 1 >= Dfull) break;
+        load_set(d + 3, s0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_set(s1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (d + 2 >= Dfull) break;
+        load_set(d + 4, s1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_set(s2);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (Dfull < D) {                                        // the row's tail (V % 32 values): guarded scalar reads
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int v = 32 * Dfull + 16 * half + 4 * i + e;
+                    s0.a[r][i][e] = v < V ? arow[r][32 * Dfull + 4 * i + e] : 0.f;
+                }
+        load_b(Dfull, s0);
+        mfma_set(s0);
+    }
+
+    // epilogue: dZ = dH * (1 - H^2), H recomputed per element; padded cells give zeros
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = 32 * r + (q & 3) + 8 * (q >> 2) + 4 * half;
+            const long m = m0 + row;
+            if (m >= M) continue;
+            const bool ok = row_ok[row] != 0;
+            const float *__restrict__ e = ep + row_e[row];
+            const float *__restrict__ p = pp + row_p[row];
+#pragma unroll
+            for (int c = 0; c < kZCT; ++c) {
+                const int k = (wave * kZCT + c) * 32 + l31;
+                if (k >= J) continue;
+                const float h = tanhf(e[k] + p[k]);
+                dz[(size_t)m * J + k] = ok ? acc[r][c][q] * (1.f - h * h) : 0.f;
+                if (hout) hout[(size_t)m * J + k] = ok ? h : 0.f;
+            }
+        }
+    }
+}
+
 int split_check(int B, int T, int U1, int J, int V, int terms, int out_dtype)
 {
     WR_REQUIRE(B > 0 && T > 0 && U1 > 0 && J > 0 && V > 0, WR_EINVAL,
@@ -362,5 +571,45 @@ extern "C" int wr_joint_fwd_split(const float *ep_d, const float *pp_d, const fl
     }
 #undef WR_LAUNCH_SPLIT
     WR_CHECK_LAUNCH("joint_fwd_split_kernel");
+    return WR_OK;
+}
+
+extern "C" size_t wr_joint_dz_split_workspace_bytes(int J, int V)
+{
+    if (J <= 0 || V <= 0) return 0;
+    const size_t n_jt = (size_t)(J + 31) / 32, D = (size_t)(V + 31) / 32;
+    return 2 * align_up(n_jt * D * 2 * 64 * 8 * sizeof(unsigned short), 256);
+}
+
+extern "C" int wr_joint_bwd_dz_split(const float *gout_d, const float *ep_d, const float *pp_d, const float *w_out_d,
+                                     const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B, int T, int U1,
+                                     int J, int V, int terms, float *dz_d, float *h_d, void *workspace_d,
+                                     size_t workspace_bytes, void *stream)
+{
+    if (int rc = split_check(B, T, U1, J, V, terms, 0)) return rc;
+    WR_REQUIRE(V % 4 == 0 && V >= 32, WR_EUNSUPPORTED,
+               "joint_bwd_dz_split: V=%d not supported (16-byte aligned gradient rows: V a multiple of 4, at least 32)", V);
+    WR_REQUIRE(gout_d && ep_d && pp_d && w_out_d && dz_d && workspace_d, WR_EINVAL, "joint_bwd_dz_split: null pointer argument");
+    WR_REQUIRE((logit_lengths_d == nullptr) == (target_lengths_d == nullptr), WR_EINVAL,
+               "joint_bwd_dz_split: pass both length arrays or neither");
+    const int n_jt = (J + 31) / 32, D = (V + 31) / 32;
+    const size_t img = align_up((size_t)n_jt * D * 2 * 64 * 8 * sizeof(unsigned short), 256);
+    WR_REQUIRE(workspace_bytes >= 2 * img, WR_EWORKSPACE, "joint_bwd_dz_split: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned short *wh = static_cast<unsigned short *>(workspace_d);
+    unsigned short *wl = reinterpret_cast<unsigned short *>(static_cast<char *>(workspace_d) + img);
+    hipLaunchKernelGGL(split_w_dz_kernel, dim3(512), dim3(256), 0, st, w_out_d, V, J, D, n_jt, wh, wl);
+    WR_CHECK_LAUNCH("split_w_dz_kernel");
+    const long M = (long)B * T * U1;
+    const dim3 grid((unsigned)((M + kSM - 1) / kSM));
+    if (terms == 3)
+        hipLaunchKernelGGL(joint_bwd_dz_split_kernel<3>, grid, dim3(64 * kZWaves), 0, st, gout_d, ep_d, pp_d,
+                           reinterpret_cast<const u32x4 *>(wh), reinterpret_cast<const u32x4 *>(wl), logit_lengths_d,
+                           target_lengths_d, B, T, U1, J, V, D, n_jt, dz_d, h_d);
+    else
+        hipLaunchKernelGGL(joint_bwd_dz_split_kernel<1>, grid, dim3(64 * kZWaves), 0, st, gout_d, ep_d, pp_d,
+                           reinterpret_cast<const u32x4 *>(wh), reinterpret_cast<const u32x4 *>(wl), logit_lengths_d,
+                           target_lengths_d, B, T, U1, J, V, D, n_jt, dz_d, h_d);
+    WR_CHECK_LAUNCH("joint_bwd_dz_split_kernel");
     return WR_OK;
 }

@@ -14,7 +14,8 @@ Precision (extension, default exact fp32): ``precision="bf16x3"`` (or env ``WR_J
 forward contraction on the bf16 matrix cores with every fp32 operand split in two (three MFMA terms, fp32
 accumulation): logits within 1e-4 of the fp32 result relative to their scale, 2.7x faster.
 ``precision="bf16"`` is the single-term AMP mode (the reference under ``--use_amp`` runs this Linear in fp16):
-under autocast the logits come out in the autocast dtype.  The backward kernels are exact fp32 in every mode.
+under autocast the logits come out in the autocast dtype.  In both modes the activation gradient ``dZ = dY W``
+uses the same split (``wr_joint_bwd_dz_split``, when V is a multiple of 4); the weight gradient stays exact fp32.
 
 Supported configuration: the reference's shipped one (``joint_mode='add'``,
 ``activation='tanh'``, ``postjoin_linear=False``,
@@ -78,6 +79,7 @@ class _JointFn(torch.autograd.Function):
                                             _lib.current_stream(dev))
             _lib.check(rc, "wr_joint_fwd_split")
         ctx.save_for_backward(ep, pp, w, llens, tlens)
+        ctx.terms = terms
         return out
 
     @staticmethod
@@ -93,11 +95,20 @@ class _JointFn(torch.autograd.Function):
         dz = torch.empty(B, T, U1, J, dtype=torch.float32, device=dev)
         need_w = ctx.needs_input_grad[2]
         h = torch.empty_like(dz) if need_w else None
-        with torch.cuda.device(dev):
-            rc = lib.wr_joint_bwd_dz(_lib.ptr(gout), _lib.ptr(ep), _lib.ptr(pp), _lib.ptr(w), _lib.ptr(llens),
-                                     _lib.ptr(tlens), B, T, U1, J, V, _lib.ptr(dz), _lib.ptr(h),
-                                     _lib.current_stream(dev))
-        _lib.check(rc, "wr_joint_bwd_dz")
+        if ctx.terms != 0 and V % 4 == 0 and V >= 32:       # same split as the forward (gradient rows 16-byte aligned)
+            wsb = lib.wr_joint_dz_split_workspace_bytes(J, V)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                rc = lib.wr_joint_bwd_dz_split(_lib.ptr(gout), _lib.ptr(ep), _lib.ptr(pp), _lib.ptr(w), _lib.ptr(llens),
+                                               _lib.ptr(tlens), B, T, U1, J, V, ctx.terms, _lib.ptr(dz), _lib.ptr(h),
+                                               _lib.ptr(ws), wsb, _lib.current_stream(dev))
+            _lib.check(rc, "wr_joint_bwd_dz_split")
+        else:
+            with torch.cuda.device(dev):
+                rc = lib.wr_joint_bwd_dz(_lib.ptr(gout), _lib.ptr(ep), _lib.ptr(pp), _lib.ptr(w), _lib.ptr(llens),
+                                         _lib.ptr(tlens), B, T, U1, J, V, _lib.ptr(dz), _lib.ptr(h),
+                                         _lib.current_stream(dev))
+            _lib.check(rc, "wr_joint_bwd_dz")
         d_ep = dz.sum(dim=2)
         d_pp = dz.sum(dim=1)
         d_w = d_b = None
