@@ -202,9 +202,50 @@ def bench_beam(args):
                           "utt_per_s": round(B / dt, 2), "best_len": len(out[0][0].hyp)}), flush=True)
 
 
+def bench_step(args):
+    """The loss block of Transducer.forward (transducer.py:131-147) through the autograd path: pre-join
+    projections -> joiner -> RNN-T loss -> backward to enc/pred outputs and all joiner weights."""
+    import wenet_celoss_amd as w
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    B, T, U, V, E, P, J = args.B, args.T, args.U, args.V, 256, 256, 512
+    enc = torch.randn(B, T, E, device=dev, requires_grad=True)
+    pred = torch.randn(B, U + 1, P, device=dev, requires_grad=True)
+    y = torch.randint(1, V, (B, U), dtype=torch.int32, device=dev)
+    ll = torch.full((B,), T, dtype=torch.int32, device=dev); tl = torch.full((B,), U, dtype=torch.int32, device=dev)
+    base = None
+    for prec in ("fp32", "bf16x3"):
+        joint = w.TransducerJoint(V, E, P, J, precision=prec).to(dev)
+        torch.manual_seed(4)
+        with torch.no_grad():
+            for prm in joint.parameters():
+                prm.copy_(torch.randn_like(prm) * 0.05)
+
+        def step():
+            joint.zero_grad(set_to_none=True); enc.grad = None; pred.grad = None
+            logits = joint(enc, pred)
+            loss = w.rnnt_loss(logits, y, ll, tl, blank=0, reduction="mean", inplace_grad=True)
+            loss.backward()
+            return loss
+        loss = step()
+        ms = timeit(step, args.steps)
+        rec = {"what": "joint+rnnt_loss fwd+bwd (autograd)", "precision": prec, "shape": [B, T, U + 1, J, V],
+               "ms": round(ms, 2), "utt_per_s": round(B / ms * 1e3, 1), "loss": float(loss)}
+        if base is None:
+            base = (float(loss), enc.grad.clone(), joint.ffn_out.weight.grad.clone())
+        else:
+            rec["loss_rel_diff_vs_fp32"] = abs(float(loss) - base[0]) / abs(base[0])
+            for name, got, ref in (("grad_enc", enc.grad, base[1]), ("grad_w", joint.ffn_out.weight.grad, base[2])):
+                rms = ref.pow(2).mean().sqrt()
+                rec[name + "_max_err_over_rms"] = float((got - ref).abs().max() / rms)
+                rec[name + "_rms_err_over_rms"] = float((got - ref).pow(2).mean().sqrt() / rms)
+        print(json.dumps(rec), flush=True)
+        del joint
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["joint", "ctc", "greedy", "beam"])
+    ap.add_argument("what", choices=["joint", "ctc", "greedy", "beam", "step"])
     ap.add_argument("--chunks", type=int, default=4)
     ap.add_argument("--B", type=int, default=32)
     ap.add_argument("--T", type=int, default=1000)
@@ -217,4 +258,4 @@ if __name__ == "__main__":
     if a.tile:
         from wenet_celoss_amd import _lib
         _lib.load().wr_tune_set(6, a.tile)
-    {"joint": bench_joint, "ctc": bench_ctc, "greedy": bench_greedy, "beam": bench_beam}[a.what](a)
+    {"joint": bench_joint, "ctc": bench_ctc, "greedy": bench_greedy, "beam": bench_beam, "step": bench_step}[a.what](a)
