@@ -202,6 +202,16 @@ int wr_joint_bwd_dw(const float *gout_d /* [B,T,U1,V] */, const float *h_d /* [B
                     float *dw_d /* [V,J] */, float *db_d /* [V] or NULL */,
                     void *workspace_d, size_t workspace_bytes, void *stream);
 
+/* wr_joint_bwd_dw on the bf16 matrix cores (terms as in wr_joint_fwd_split): dw = gout^T h, db = column sums of gout
+ * (kept in fp32), padded cells excluded when lengths are given.  V and J multiples of 4.  Deterministic. */
+size_t wr_joint_dw_split_workspace_bytes(int B, int T, int U1, int J, int V);
+
+int wr_joint_bwd_dw_split(const float *gout_d /* [B,T,U1,V] */, const float *h_d /* [B,T,U1,J] */,
+                          const int32_t *logit_lengths_d /* nullable */, const int32_t *target_lengths_d /* nullable */,
+                          int B, int T, int U1, int J, int V, int terms,
+                          float *dw_d /* [V,J] */, float *db_d /* [V] or NULL */,
+                          void *workspace_d, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------
  * Transducer decoding: batched greedy search, batched prefix beam search and
  * the predictor step API, with every per-step operation on the device.

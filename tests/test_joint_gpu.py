@@ -140,14 +140,15 @@ def test_split_forward_parity_float64(precision, tol, B, T, U1, E, P, J, V):
     rms = float(np.sqrt((ro ** 2).mean()))
     err = float(np.abs(out.detach().cpu().numpy() - ro).max())
     assert err <= tol * rms, (err, rms)
-    # backward: dZ = dY W runs with the same split when V % 4 == 0 (else exact fp32); the weight gradient is exact
+    # backward: dZ = dY W and dW = dY^T H run with the same split when V % 4 == 0 (else exact fp32); db is fp32
     out.backward(gout.to(DEV))
-    for got, want in ((e.grad, rg["enc"]), (p.grad, rg["pred"]), (m.enc_ffn.weight.grad, rg["enc_ffn.weight"])):
+    for got, want in ((e.grad, rg["enc"]), (p.grad, rg["pred"]), (m.enc_ffn.weight.grad, rg["enc_ffn.weight"]),
+                      (m.ffn_out.weight.grad, rg["ffn_out.weight"])):
         want_rms = float(np.sqrt((want ** 2).mean()))
         assert float(np.abs(got.cpu().numpy() - want).max()) <= tol * want_rms
     scale = lambda a: 1e-4 * max(1.0, float(np.abs(a).max()))
-    np.testing.assert_allclose(m.ffn_out.weight.grad.cpu().numpy(), rg["ffn_out.weight"], rtol=1e-4,
-                               atol=scale(rg["ffn_out.weight"]))
+    np.testing.assert_allclose(m.ffn_out.bias.grad.cpu().numpy(), rg["ffn_out.bias"], rtol=1e-4,
+                               atol=scale(rg["ffn_out.bias"]))
 
 
 @pytest.mark.parametrize("terms,tol", [(3, 1e-4), (1, 3e-2)])
@@ -221,3 +222,37 @@ def test_split_forward_amp_dtype_and_errors():
     lib = _lib.load()
     assert lib.wr_joint_fwd_split(None, None, None, None, None, None, 1, 1, 1, 64, 10, 2, None, 0, None, 0, None) != 0
     assert b"terms" in lib.wr_last_error()
+
+
+@pytest.mark.parametrize("terms,tol", [(3, 1e-4), (1, 3e-2)])
+@pytest.mark.parametrize("B,T,U1,J,V", [(2, 9, 5, 128, 300), (1, 70, 3, 256, 1000), (2, 13, 4, 36, 64), (1, 20, 9, 512, 5000),
+                                        (1, 33, 2, 64, 32), (3, 50, 7, 260, 520)])
+def test_split_dw_matches_float64(terms, tol, B, T, U1, J, V):
+    """wr_joint_bwd_dw_split against a float64 evaluation of dW = dY^T H, db = sum dY (with and without lengths:
+    padded cells must not contribute); partial 256-blocks in v and j, cell ranges that do not fill a 16-cell step."""
+    from wenet_celoss_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(terms * 777 + T + J + V)
+    gout = torch.randn(B, T, U1, V, generator=g).to(DEV)
+    h = torch.tanh(torch.randn(B, T, U1, J, generator=g)).to(DEV)
+    ll = torch.randint(1, T + 1, (B,), generator=g).to(torch.int32); ll[0] = T
+    tl = torch.randint(0, U1, (B,), generator=g).to(torch.int32); tl[0] = U1 - 1
+    ll, tl = ll.to(DEV), tl.to(DEV)
+    st, P = _lib.current_stream(torch.device(DEV)), _lib.ptr
+    wsb = lib.wr_joint_dw_split_workspace_bytes(B, T, U1, J, V)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    for lens in ((None, None), (ll, tl)):
+        g64, h64 = gout.double(), h.double()
+        if lens[0] is not None:
+            tt = torch.arange(T, device=DEV)[None, :, None] < ll[:, None, None]
+            uu = torch.arange(U1, device=DEV)[None, None, :] <= tl[:, None, None]
+            g64 = g64 * (tt & uu)[..., None]
+        dw_ref = g64.reshape(-1, V).T @ h64.reshape(-1, J)
+        db_ref = g64.reshape(-1, V).sum(0)
+        dw = torch.full((V, J), float("nan"), device=DEV); db = torch.full((V,), float("nan"), device=DEV)
+        _lib.check(lib.wr_joint_bwd_dw_split(P(gout), P(h), P(lens[0]), P(lens[1]), B, T, U1, J, V, terms, P(dw), P(db),
+                                             P(ws), wsb, st))
+        rms = float(dw_ref.pow(2).mean().sqrt())
+        assert float((dw.double() - dw_ref).abs().max()) <= tol * rms
+        torch.testing.assert_close(db.double(), db_ref, rtol=1e-5, atol=1e-4)
+    assert lib.wr_joint_bwd_dw_split(P(gout), P(h), None, None, B, T, U1, J, 30, terms, P(dw), P(db), P(ws), wsb, st) != 0

@@ -87,6 +87,18 @@ def bench_joint(args):
     ms = timeit(kdw, args.steps)
     print(json.dumps({"what": "joint_bwd_dw", "shape": [B, T, U1, J, V], "ms": round(ms, 3),
                       "TFLOPs": round(flops / ms / 1e9, 2), "frac": round(flops / ms / 1e9 / 157.3, 4)}), flush=True)
+    dw_ref, db_ref = dwt.clone(), dbt.clone()
+    wsb3 = lib.wr_joint_dw_split_workspace_bytes(B, T, U1, J, V)
+    ws3 = torch.empty(wsb3, dtype=torch.uint8, device=dev)
+    for terms in (3, 1):
+        ks = lambda: _lib.check(lib.wr_joint_bwd_dw_split(P(out), P(h), None, None, B, T, U1, J, V, terms, P(dwt), P(dbt),
+                                                           P(ws3), wsb3, st))
+        ms = timeit(ks, args.steps)
+        rms = float(dw_ref.pow(2).mean().sqrt())
+        print(json.dumps({"what": "joint_bwd_dw_split", "terms": terms, "shape": [B, T, U1, J, V], "ms": round(ms, 3),
+                          "TFLOPs_fp32_equiv": round(flops / ms / 1e9, 2),
+                          "max_err_over_rms": float((dwt - dw_ref).abs().max()) / rms,
+                          "db_max_err_over_rms": float((dbt - db_ref).abs().max() / db_ref.pow(2).mean().sqrt())}), flush=True)
     if args.dw:
         g2 = out.view(-1, V)
         k = lambda: g2.t().mm(h.view(-1, J))

@@ -53,6 +53,19 @@ __device__ __forceinline__ void split_bf16(float x, unsigned &hi, unsigned &lo)
     lo = bf16_bits(x - __builtin_bit_cast(float, hi << 16));
 }
 
+// two floats -> packed bf16 pair of the hi parts and of the lo parts (v_cvt_pk_bf16_f32, round to nearest even):
+// five instructions per pair
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned &hi, unsigned &lo)
+{
+    const f32x2 x = (f32x2){x0, x1};
+    const bf16x2 h = __builtin_convertvector(x, bf16x2);
+    const bf16x2 l = __builtin_convertvector(x - __builtin_convertvector(h, f32x2), bf16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
 // tanh through the hardware exp2 / rcp (|error| ~ 1e-7 absolute: below the split's own 2^-17 operand error)
 __device__ __forceinline__ float tanh_fast(float x)
 {
@@ -191,11 +204,10 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
                 const bool kin = in && k < J;
                 const float x0 = kin ? tanh_fast(ev[q][i].x + pv[q][i].x) : 0.f;
                 const float x1 = kin ? tanh_fast(ev[q][i].y + pv[q][i].y) : 0.f;
-                unsigned h0, l0, h1, l1;
-                split_bf16(x0, h0, l0);
-                split_bf16(x1, h1, l1);
-                *reinterpret_cast<unsigned *>(Ahi + (size_t)row * JS + k) = h0 | (h1 << 16);
-                if (TERMS == 3) *reinterpret_cast<unsigned *>(Alo + (size_t)row * JS + k) = l0 | (l1 << 16);
+                unsigned hp, lp;
+                split_pair(x0, x1, hp, lp);
+                *reinterpret_cast<unsigned *>(Ahi + (size_t)row * JS + k) = hp;
+                if (TERMS == 3) *reinterpret_cast<unsigned *>(Alo + (size_t)row * JS + k) = lp;
             }
         }
     }
@@ -325,20 +337,13 @@ __global__ void split_w_dz_kernel(const float *__restrict__ w, int V, int J, int
 // eight floats -> bf16x8 hi (and lo) fragments
 __device__ __forceinline__ void split8(const f32x4 &a, const f32x4 &b, bf16x8 &hi, bf16x8 &lo, bool want_lo)
 {
-    unsigned h[8], l[8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        split_bf16(a[i], h[i], l[i]);
-        split_bf16(b[i], h[4 + i], l[4 + i]);
-    }
-    u32x4 ph, pl;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ph[i] = h[2 * i] | (h[2 * i + 1] << 16);
-        pl[i] = l[2 * i] | (l[2 * i + 1] << 16);
-    }
-    hi = __builtin_bit_cast(bf16x8, ph);
-    if (want_lo) lo = __builtin_bit_cast(bf16x8, pl);
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    split_pair(a[0], a[1], h0, l0);
+    split_pair(a[2], a[3], h1, l1);
+    split_pair(b[0], b[1], h2, l2);
+    split_pair(b[2], b[3], h3, l3);
+    hi = __builtin_bit_cast(bf16x8, (u32x4){h0, h1, h2, h3});
+    if (want_lo) lo = __builtin_bit_cast(bf16x8, (u32x4){l0, l1, l2, l3});
 }
 
 template <int TERMS>
@@ -497,6 +502,200 @@ __global__ __launch_bounds__(64 * kZWaves) void joint_bwd_dz_split_kernel(
     }
 }
 
+// ---------------------------------------------------- backward, weight gradient --
+// dW[v, j] = sum_m dY[m, v] * H[m, j],  db[v] = sum_m dY[m, v]     (M = B*T*U1 lattice cells, padded cells excluded)
+// A reduction over millions of cells into a V x J matrix.  One workgroup (4 waves = 2 v-halves x 2 j-halves, one
+// per SIMD) owns a 256 x 256 block of dW and one of `parts` contiguous cell ranges; a wave holds 4 x 4 accumulator
+// tiles (256 registers).  Both operands are cell-major as stored, so a 16-cell step of each ([16][256] fp32) is
+// staged through LDS with coalesced 16-byte loads (three stages, registers two steps ahead); a lane then reads, for
+// its 8 cells, the 4 consecutive columns 4*l31 .. 4*l31+3 of its half (8 ds_read_b128) and treats them as rows of four
+// interleaved MFMA tiles (tile t holds columns 4*i + t) -- the contraction index stays along the fragment, no
+// transposition anywhere.  Values are split to bf16 hi / lo in registers (same three-term product as the forward).
+// The `parts` partial blocks are summed by a second, deterministic kernel (no float atomics).
+constexpr int kWB = 256;         // dW block edge (v and j) per workgroup
+constexpr int kWStages = 3;
+
+// one byte per lattice cell: 1 inside [0, T_b) x [0, U_b], 0 in the padded region
+__global__ void cell_mask_kernel(const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens, int T, int U1, long M,
+                                 unsigned char *__restrict__ mask)
+{
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
+        const long bt = m / U1;
+        const int u = (int)(m - bt * U1);
+        const long b = bt / T;
+        const int t = (int)(bt - b * T);
+        mask[m] = (t < llens[b]) && (u <= tlens[b]);
+    }
+}
+
+template <int TERMS>
+__global__ __launch_bounds__(256) void joint_bwd_dw_split_kernel(
+    const float *__restrict__ gout /* [M, V] */, const float *__restrict__ h /* [M, J] */,
+    const unsigned char *__restrict__ mask /* [M] or null */, long M, int V, int J, int n_vs, int n_js, long rows_per_part,
+    float *__restrict__ part_dw /* [parts][V][J] */, float *__restrict__ part_db /* [parts][V] */)
+{
+    extern __shared__ __attribute__((aligned(16))) float stage[];     // [kWStages][2 operands][16][kWB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int vh = wave >> 1, jh = wave & 1;
+    const int tiles = n_vs * n_js;
+    const int part = blockIdx.x / tiles, tile = blockIdx.x - part * tiles;
+    const int vs = tile / n_js, js = tile - vs * n_js;
+    const int v0 = vs * kWB, j0 = js * kWB;
+    const long mb = (long)part * rows_per_part;
+    const long me = mb + rows_per_part < M ? mb + rows_per_part : M;
+    const int steps = me > mb ? (int)((me - mb + 15) / 16) : 0;
+
+    // staging map: thread -> float4 column c4 of the 256-wide block, rows r4 + 4*i of the 16-cell step
+    const int c4 = tid & 63, r4 = tid >> 6;
+    const bool a_in = v0 + 4 * c4 < V, b_in = j0 + 4 * c4 < J;       // V, J multiples of 4: a float4 is wholly in or out
+    const float *__restrict__ ga = gout + (a_in ? v0 + 4 * c4 : 0);
+    const float *__restrict__ gb = h + (b_in ? j0 + 4 * c4 : 0);
+    struct Regs { f32x4 a[4], b[4]; };
+    auto gload = [&](int s, Regs &z) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            long m = mb + 16L * s + r4 + 4 * i;
+            m = m < me ? m : me - 1;
+            z.a[i] = *reinterpret_cast<const f32x4 *>(ga + (size_t)m * V);
+            z.b[i] = *reinterpret_cast<const f32x4 *>(gb + (size_t)m * J);
+        }
+    };
+    f32x4 dbacc = (f32x4){0, 0, 0, 0};
+    auto lwrite = [&](int s, const Regs &z) {                        // masks, accumulates db, stores the stage
+        float *sa = stage + (size_t)(s % kWStages) * 2 * 16 * kWB;
+        float *sb = sa + 16 * kWB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long m = mb + 16L * s + r4 + 4 * i;
+            bool on = m < me;
+            if (on && mask != nullptr) on = mask[m] != 0;
+            const f32x4 zero = (f32x4){0, 0, 0, 0};
+            const f32x4 av = (on && a_in) ? z.a[i] : zero;
+            const f32x4 bv = (on && b_in) ? z.b[i] : zero;
+            dbacc += av;
+            *reinterpret_cast<f32x4 *>(sa + (r4 + 4 * i) * kWB + 4 * c4) = av;
+            *reinterpret_cast<f32x4 *>(sb + (r4 + 4 * i) * kWB + 4 * c4) = bv;
+        }
+    };
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x16){0};
+
+    auto compute = [&](int s) {
+        const float *sa = stage + (size_t)(s % kWStages) * 2 * 16 * kWB + (8 * half) * kWB + 128 * vh + 4 * l31;
+        const float *sb = stage + (size_t)(s % kWStages) * 2 * 16 * kWB + 16 * kWB + (8 * half) * kWB + 128 * jh + 4 * l31;
+        f32x4 pa[8], pb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            pa[e] = *reinterpret_cast<const f32x4 *>(sa + e * kWB);
+            pb[e] = *reinterpret_cast<const f32x4 *>(sb + e * kWB);
+        }
+        bf16x8 ah[4], al[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 lo4 = (f32x4){pa[0][t], pa[1][t], pa[2][t], pa[3][t]};
+            const f32x4 hi4 = (f32x4){pa[4][t], pa[5][t], pa[6][t], pa[7][t]};
+            split8(lo4, hi4, ah[t], al[t], TERMS == 3);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            bf16x8 bh, bl;
+            const f32x4 lo4 = (f32x4){pb[0][u], pb[1][u], pb[2][u], pb[3][u]};
+            const f32x4 hi4 = (f32x4){pb[4][u], pb[5][u], pb[6][u], pb[7][u]};
+            split8(lo4, hi4, bh, bl, TERMS == 3);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (TERMS == 3) {
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], bh, acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bl, acc[t][u], 0, 0, 0);
+                }
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bh, acc[t][u], 0, 0, 0);
+            }
+        }
+    };
+
+    if (steps > 0) {
+        // global loads run two steps ahead of their LDS write (two register sets), the LDS stages one more.  The
+        // loop runs an even number of steps (a step past the range stages zeros) so that it has a single exit.
+        const int steps2 = (steps + 1) & ~1;
+        Regs r0, r1;
+        gload(0, r0);
+        lwrite(0, r0);
+        gload(1, r0);
+        lwrite(1, r0);
+        gload(2, r0);
+        gload(3, r1);
+        for (int s = 0; s < steps2; s += 2) {
+            __syncthreads();                                         // stage s visible; stage s+2's buffer is free
+            lwrite(s + 2, r0);
+            gload(s + 4, r0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(s);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            lwrite(s + 3, r1);
+            gload(s + 5, r1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // partial block of dW: tile (t, u) element (row i, col c) is dW[v0 + 128 vh + 4 i + t][j0 + 128 jh + 4 c + u]
+    float *__restrict__ pw = part_dw + (size_t)part * V * J;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int i = (q & 3) + 8 * (q >> 2) + 4 * half;
+            const int v = v0 + 128 * vh + 4 * i + t;
+            if (v >= V) continue;
+            const int j = j0 + 128 * jh + 4 * l31;
+            if (j < J) {                                             // J % 4 == 0: the four u's are in together
+                const f32x4 o = (f32x4){acc[t][0][q], acc[t][1][q], acc[t][2][q], acc[t][3][q]};
+                *reinterpret_cast<f32x4 *>(pw + (size_t)v * J + j) = o;
+            }
+        }
+    // db: the four row groups of every float4 column -> one sum (j-block 0 only)
+    if (js == 0) {
+        __syncthreads();
+        f32x4 *red = reinterpret_cast<f32x4 *>(stage);
+        red[tid] = dbacc;
+        __syncthreads();
+        if (tid < 64 && a_in) {
+            const f32x4 t4 = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
+            *reinterpret_cast<f32x4 *>(part_db + (size_t)part * V + v0 + 4 * tid) = t4;
+        }
+    }
+}
+
+__global__ void split_dw_reduce_kernel(const float *__restrict__ part_dw, const float *__restrict__ part_db, int parts,
+                                       long nw, int V, float *__restrict__ dw, float *__restrict__ db)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nw + V; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        if (i < nw) {
+            for (int p = 0; p < parts; ++p) s += part_dw[(size_t)p * nw + i];
+            dw[i] = s;
+        } else if (db != nullptr) {
+            const long v = i - nw;
+            for (int p = 0; p < parts; ++p) s += part_db[(size_t)p * V + v];
+            db[v] = s;
+        }
+    }
+}
+
+inline int split_dw_parts(int V, int J)
+{
+    const int tiles = ((V + kWB - 1) / kWB) * ((J + kWB - 1) / kWB);
+    const int parts = 256 / tiles;                                   // one workgroup per CU
+    return parts < 1 ? 1 : parts;
+}
+
 int split_check(int B, int T, int U1, int J, int V, int terms, int out_dtype)
 {
     WR_REQUIRE(B > 0 && T > 0 && U1 > 0 && J > 0 && V > 0, WR_EINVAL,
@@ -611,5 +810,56 @@ extern "C" int wr_joint_bwd_dz_split(const float *gout_d, const float *ep_d, con
                            reinterpret_cast<const u32x4 *>(wh), reinterpret_cast<const u32x4 *>(wl), logit_lengths_d,
                            target_lengths_d, B, T, U1, J, V, D, n_jt, dz_d, h_d);
     WR_CHECK_LAUNCH("joint_bwd_dz_split_kernel");
+    return WR_OK;
+}
+
+extern "C" size_t wr_joint_dw_split_workspace_bytes(int B, int T, int U1, int J, int V)
+{
+    if (B <= 0 || T <= 0 || U1 <= 0 || J <= 0 || V <= 0) return 0;
+    const size_t M = (size_t)B * T * U1;
+    return align_up((size_t)split_dw_parts(V, J) * ((size_t)V * J + V) * sizeof(float), 256) + align_up(M, 256);
+}
+
+extern "C" int wr_joint_bwd_dw_split(const float *gout_d, const float *h_d, const int32_t *logit_lengths_d,
+                                     const int32_t *target_lengths_d, int B, int T, int U1, int J, int V, int terms,
+                                     float *dw_d, float *db_d, void *workspace_d, size_t workspace_bytes, void *stream)
+{
+    if (int rc = split_check(B, T, U1, J, V, terms, 0)) return rc;
+    WR_REQUIRE(V % 4 == 0 && J % 4 == 0, WR_EUNSUPPORTED,
+               "joint_bwd_dw_split: V=%d, J=%d not supported (16-byte aligned rows: multiples of 4)", V, J);
+    WR_REQUIRE(gout_d && h_d && dw_d && workspace_d, WR_EINVAL, "joint_bwd_dw_split: null pointer argument");
+    WR_REQUIRE((logit_lengths_d == nullptr) == (target_lengths_d == nullptr), WR_EINVAL,
+               "joint_bwd_dw_split: pass both length arrays or neither");
+    const long M = (long)B * T * U1;
+    const int parts = split_dw_parts(V, J);
+    const size_t pbytes = align_up((size_t)parts * ((size_t)V * J + V) * sizeof(float), 256);
+    WR_REQUIRE(workspace_bytes >= pbytes + align_up((size_t)M, 256), WR_EWORKSPACE,
+               "joint_bwd_dw_split: workspace %zu < required %zu", workspace_bytes, pbytes + align_up((size_t)M, 256));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *part_dw = static_cast<float *>(workspace_d);
+    float *part_db = part_dw + (size_t)parts * V * J;
+    unsigned char *mask = nullptr;
+    if (logit_lengths_d != nullptr) {
+        mask = reinterpret_cast<unsigned char *>(static_cast<char *>(workspace_d) + pbytes);
+        hipLaunchKernelGGL(cell_mask_kernel, dim3(1024), dim3(256), 0, st, logit_lengths_d, target_lengths_d, T, U1, M, mask);
+        WR_CHECK_LAUNCH("cell_mask_kernel");
+    }
+    const int n_vs = (V + kWB - 1) / kWB, n_js = (J + kWB - 1) / kWB;
+    long rows_per_part = (M + parts - 1) / parts;
+    rows_per_part = (rows_per_part + 15) / 16 * 16;
+    const size_t lds = (size_t)kWStages * 2 * 16 * kWB * sizeof(float);
+#define WR_LAUNCH_DW(TERMS)                                                                                            \
+    do {                                                                                                              \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_bwd_dw_split_kernel<TERMS>),                     \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+        hipLaunchKernelGGL(joint_bwd_dw_split_kernel<TERMS>, dim3(n_vs * n_js * parts), dim3(256), lds, st, gout_d, h_d, \
+                           mask, M, V, J, n_vs, n_js, rows_per_part, part_dw, part_db);                                \
+    } while (0)
+    if (terms == 3) WR_LAUNCH_DW(3); else WR_LAUNCH_DW(1);
+#undef WR_LAUNCH_DW
+    WR_CHECK_LAUNCH("joint_bwd_dw_split_kernel");
+    hipLaunchKernelGGL(split_dw_reduce_kernel, dim3(1024), dim3(256), 0, st, part_dw, part_db, parts, (long)V * J, V, dw_d,
+                       db_d);
+    WR_CHECK_LAUNCH("split_dw_reduce_kernel");
     return WR_OK;
 }

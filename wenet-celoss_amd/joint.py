@@ -15,7 +15,8 @@ forward contraction on the bf16 matrix cores with every fp32 operand split in tw
 accumulation): logits within 1e-4 of the fp32 result relative to their scale, 2.7x faster.
 ``precision="bf16"`` is the single-term AMP mode (the reference under ``--use_amp`` runs this Linear in fp16):
 under autocast the logits come out in the autocast dtype.  In both modes the activation gradient ``dZ = dY W``
-uses the same split (``wr_joint_bwd_dz_split``, when V is a multiple of 4); the weight gradient stays exact fp32.
+and the weight gradient ``dW = dY^T H`` use the same split (``wr_joint_bwd_dz_split``, ``wr_joint_bwd_dw_split``,
+when V is a multiple of 4; otherwise the exact kernels); the bias gradient is summed in fp32.
 
 Supported configuration: the reference's shipped one (``joint_mode='add'``,
 ``activation='tanh'``, ``postjoin_linear=False``,
@@ -115,12 +116,21 @@ class _JointFn(torch.autograd.Function):
         if need_w:
             d_w = torch.empty(V, J, dtype=torch.float32, device=dev)
             d_b = torch.empty(V, dtype=torch.float32, device=dev)
-            wsb = lib.wr_joint_dw_workspace_bytes(J, V)
-            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-            with torch.cuda.device(dev):
-                rc = lib.wr_joint_bwd_dw(_lib.ptr(gout), _lib.ptr(h), _lib.ptr(llens), _lib.ptr(tlens), B, T, U1, J, V,
-                                         _lib.ptr(d_w), _lib.ptr(d_b), _lib.ptr(ws), wsb, _lib.current_stream(dev))
-            _lib.check(rc, "wr_joint_bwd_dw")
+            if ctx.terms != 0 and V % 4 == 0 and J % 4 == 0:
+                wsb = lib.wr_joint_dw_split_workspace_bytes(B, T, U1, J, V)
+                ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+                with torch.cuda.device(dev):
+                    rc = lib.wr_joint_bwd_dw_split(_lib.ptr(gout), _lib.ptr(h), _lib.ptr(llens), _lib.ptr(tlens), B, T, U1,
+                                                   J, V, ctx.terms, _lib.ptr(d_w), _lib.ptr(d_b), _lib.ptr(ws), wsb,
+                                                   _lib.current_stream(dev))
+                _lib.check(rc, "wr_joint_bwd_dw_split")
+            else:
+                wsb = lib.wr_joint_dw_workspace_bytes(J, V)
+                ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+                with torch.cuda.device(dev):
+                    rc = lib.wr_joint_bwd_dw(_lib.ptr(gout), _lib.ptr(h), _lib.ptr(llens), _lib.ptr(tlens), B, T, U1, J, V,
+                                             _lib.ptr(d_w), _lib.ptr(d_b), _lib.ptr(ws), wsb, _lib.current_stream(dev))
+                _lib.check(rc, "wr_joint_bwd_dw")
         elif ctx.needs_input_grad[3]:
             g2 = gout.view(-1, V)
             if llens is not None:
