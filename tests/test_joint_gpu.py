@@ -256,3 +256,42 @@ def test_split_dw_matches_float64(terms, tol, B, T, U1, J, V):
         assert float((dw.double() - dw_ref).abs().max()) <= tol * rms
         torch.testing.assert_close(db.double(), db_ref, rtol=1e-5, atol=1e-4)
     assert lib.wr_joint_bwd_dw_split(P(gout), P(h), None, None, B, T, U1, J, 30, terms, P(dw), P(db), P(ws), wsb, st) != 0
+
+
+def test_split_training_step_with_lengths_matches_exact(monkeypatch):
+    """Joiner + RNN-T loss, forward and backward, ragged lengths: every gradient of the bf16x3 mode against the exact
+    mode's (tolerances at the assertion); the environment switch selects the same path as the argument."""
+    import wenet_celoss_amd as w
+    torch.manual_seed(8)
+    B, T, U, E, P, J, V = 3, 60, 40, 16, 16, 128, 200
+    m = w.TransducerJoint(V, E, P, J).to(DEV)
+    enc = torch.randn(B, T, E, device=DEV); pred = torch.randn(B, U + 1, P, device=DEV)
+    y = torch.randint(1, V, (B, U), dtype=torch.int32, device=DEV)
+    ll = torch.tensor([60, 33, 7], dtype=torch.int32, device=DEV)
+    tl = torch.tensor([12, 40, 5], dtype=torch.int32, device=DEV)
+
+    def run(lens):
+        m.zero_grad()
+        e = enc.clone().requires_grad_(True); p = pred.clone().requires_grad_(True)
+        logits = m(e, p, ll, tl) if lens else m(e, p)
+        loss = w.rnnt_loss(logits, y, ll, tl, blank=0, reduction="mean")
+        loss.backward()
+        return [loss.detach(), e.grad, p.grad] + [prm.grad.clone() for prm in m.parameters()]
+
+    ref = run(False)
+    m.precision = "bf16x3"
+    for lens in (False, True):
+        got = run(lens)
+        assert float(got[0]) == pytest.approx(float(ref[0]), rel=1e-6)
+        for a, b in zip(got[1:], ref[1:]):
+            # end to end the error of single elements follows sum |dY H| rather than the cancelled sums: the bar is
+            # 1e-4 of the tensor's largest magnitude for the worst element and 2e-5 of its r.m.s. in the r.m.s. sense
+            assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-9
+            assert float((a - b).pow(2).mean().sqrt()) <= 2e-5 * float(b.pow(2).mean().sqrt()) + 1e-9
+    m.precision = None
+    monkeypatch.setenv("WR_JOINT_PRECISION", "bf16x3")
+    env = run(True)
+    m.precision = "bf16x3"
+    arg = run(True)
+    for a, b in zip(env, arg):
+        assert torch.equal(a, b)

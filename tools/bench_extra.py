@@ -226,8 +226,9 @@ def bench_step(args):
     y = torch.randint(1, V, (B, U), dtype=torch.int32, device=dev)
     ll = torch.full((B,), T, dtype=torch.int32, device=dev); tl = torch.full((B,), U, dtype=torch.int32, device=dev)
     base = None
-    for prec in ("fp32", "bf16x3"):
-        joint = w.TransducerJoint(V, E, P, J, precision=prec).to(dev)
+    for prec in ("fp32", "bf16x3", "bf16-autocast"):
+        amp = prec == "bf16-autocast"                  # the --use_amp configuration (executor.py:91)
+        joint = w.TransducerJoint(V, E, P, J, precision="bf16" if amp else prec).to(dev)
         torch.manual_seed(4)
         with torch.no_grad():
             for prm in joint.parameters():
@@ -235,8 +236,9 @@ def bench_step(args):
 
         def step():
             joint.zero_grad(set_to_none=True); enc.grad = None; pred.grad = None
-            logits = joint(enc, pred)
-            loss = w.rnnt_loss(logits, y, ll, tl, blank=0, reduction="mean", inplace_grad=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                logits = joint(enc, pred)
+                loss = w.rnnt_loss(logits, y, ll, tl, blank=0, reduction="mean", inplace_grad=True)
             loss.backward()
             return loss
         loss = step()
