@@ -277,3 +277,52 @@ def test_stream_state_is_invalidated_by_other_searches_on_the_handle():
     dec.prefix_beam(enc, lens, torch.log_softmax(torch.randn(1, 16, V, device=DEV), -1), 2, 0.3, 0.7)
     with pytest.raises(RuntimeError, match="no stream state"):
         dec.greedy_chunk(enc, lens, n_steps=4, reset=False)
+
+
+@pytest.mark.parametrize("look", [2, 3, 4])
+@pytest.mark.parametrize("path", names("greedy_core_*.npz"))
+def test_greedy_lookahead_keeps_reference_tokens(path, look):
+    """wr_decoder_set_lookahead: several encoder frames per micro-step, same tokens as the reference's loop (the
+    fixtures include n_steps limits that force frame advances after emissions)."""
+    import wenet_celoss_amd as w
+    d = np.load(path)
+    pred, joint, _ = build_modules(d)
+    model = types.SimpleNamespace(blank=0, predictor=pred, joint=joint)
+    enc = torch.tensor(d["enc"], device=DEV)
+    T, n_steps = int(d["T"]), int(d["n_steps"])
+    from wenet_celoss_amd.decoder import DecoderCache
+    model._decoder_cache = DecoderCache()
+    dec = model._decoder_cache.get(pred, joint, lanes=1, utts=1, tmax=T, max_hyp=T * n_steps, beam=1)
+    dec.set_lookahead(look)
+    assert w.basic_greedy_search(model, enc, torch.tensor(T), n_steps=n_steps) == [list(d["hyp"])]
+    with pytest.raises(RuntimeError, match="frames"):
+        dec.set_lookahead(5)
+
+
+@pytest.mark.parametrize("look", [2, 4])
+def test_greedy_lookahead_batched_and_streaming(look):
+    """Look-ahead with ragged streams and across chunk boundaries: identical to look-ahead 1."""
+    import wenet_celoss_amd as w
+    from wenet_celoss_amd.decoder import DeviceDecoder
+    d = np.load(names("greedy_core_1.npz")[0])
+    pred, joint, _ = build_modules(d)
+    enc0 = torch.tensor(d["enc"], device=DEV)[0]
+    T = enc0.shape[0]
+    lens = torch.tensor([T, T // 2, 1, T - 7, 13])
+    encs = torch.stack([enc0, enc0.flip(0), enc0 * 0.5, enc0.roll(5, 0), enc0 * 2.0])
+    n_steps = int(d["n_steps"])
+    dec = DeviceDecoder(pred, joint, max_lanes=5, max_utt=5, tmax=T, max_hyp=T * n_steps)
+    base = dec.greedy(encs, lens, n_steps=n_steps)
+    chunks = [(0, 16), (16, 21), (21, T)]
+    base_chunks = []
+    for a, b in chunks:
+        cl = (lens - a).clamp(min=0, max=b - a)
+        base_chunks.append(dec.greedy_chunk(encs[:, a:b].contiguous(), cl.clamp(min=1), n_steps=n_steps, reset=a == 0,
+                                            reference_new_cache=False))
+    dec.set_lookahead(look)
+    assert dec.greedy(encs, lens, n_steps=n_steps) == base
+    for i, (a, b) in enumerate(chunks):
+        cl = (lens - a).clamp(min=0, max=b - a)
+        got = dec.greedy_chunk(encs[:, a:b].contiguous(), cl.clamp(min=1), n_steps=n_steps, reset=a == 0,
+                               reference_new_cache=False)
+        assert got == base_chunks[i], (a, b)

@@ -173,6 +173,36 @@ def bench_greedy(args):
         print(json.dumps({"what": "greedy_search", "hipGraph": use_graph, "streams": N, "frames": T, "tokens": ntok,
                           "ms_per_call": round(dt * 1e3, 3), "utt_per_s": round(N / dt, 1),
                           "lane_steps_per_s": round(micro / dt)}), flush=True)
+    # look-ahead: frames per micro-step (token sequences must not change).  Second scenario shaped like speech: most
+    # frames quiet (blank), a quarter of them loud, at most 2 symbols per frame -> about one token per five frames
+    # (the dense scenario above keeps emitting until n_steps stops it, which no trained model does).
+    scenarios = [("dense", enc, 64, 0.0)]
+    gq = torch.Generator(device=dev).manual_seed(11)
+    quiet = torch.randn(N, T, E, device=dev, generator=gq) * 0.1
+    loud = torch.randn(N, T, E, device=dev, generator=gq) * 2.5
+    spikes = torch.rand(N, T, device=dev, generator=gq) < 0.25
+    scenarios.append(("speech-like", torch.where(spikes[..., None], loud, quiet), 2, 1.0))
+    for name, e_s, n_steps_s, extra_blank in scenarios:
+        with torch.no_grad():
+            joint.ffn_out.bias[0] += extra_blank
+        m_s = types.SimpleNamespace(blank=0, predictor=pred, joint=joint)
+        ref_hyps = w.basic_greedy_search(m_s, e_s, lens, n_steps=n_steps_s)
+        for look in (1, 2, 4):
+            dec = m_s._decoder_cache._dec
+            dec.set_lookahead(look)
+            got = w.basic_greedy_search(m_s, e_s, lens, n_steps=n_steps_s)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                got = w.basic_greedy_search(m_s, e_s, lens, n_steps=n_steps_s)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.steps
+            print(json.dumps({"what": "greedy_search_lookahead", "scenario": name, "frames_per_micro_step": look,
+                              "streams": N, "frames": T, "n_steps": n_steps_s, "tokens": sum(len(h) for h in got),
+                              "max_tokens_per_stream": max(len(h) for h in got), "ms_per_call": round(dt * 1e3, 3),
+                              "utt_per_s": round(N / dt, 1), "tokens_identical": got == ref_hyps}), flush=True)
+        with torch.no_grad():
+            joint.ffn_out.bias[0] -= extra_blank
     # CPU reference: the reference's loop restated in numpy (oracle), one stream, scaled to 64
     p = do.Predictor({k: v.detach().cpu().numpy() for k, v in pred.state_dict().items()}, L)
     j = do.Joint({k: v.detach().cpu().numpy() for k, v in joint.state_dict().items()})

@@ -110,6 +110,7 @@ SIGNATURES = {
     "wr_decoder_create": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "wr_decoder_destroy": (_i, [_vp]),
     "wr_decoder_set_graph": (_i, [_vp, _i]),
+    "wr_decoder_set_lookahead": (_i, [_vp, _i]),
     "wr_greedy_search": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "wr_greedy_search_chunk": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "wr_prefix_beam_search": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),

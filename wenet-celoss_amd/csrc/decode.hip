@@ -52,6 +52,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kMaxLayers = WR_MAX_LSTM_LAYERS;
 constexpr int kMaxBeam = 16;
+constexpr int kMaxLook = 4;          // greedy look-ahead: encoder frames evaluated per micro-step against one predictor state
 constexpr int kStepsPerGraph = 16;
 
 struct Dims {
@@ -83,8 +84,10 @@ struct DevState {
     float *cache_hT, *cache_cT;   // [L][Hp][NLp]  committed LSTM state
     float *new_hT, *new_cT;       // [L][Hp][NLp]  output of the last predictor step
     float *outT;                  // [Pp][NLp]     projected predictor output
-    float *ht;                    // [Jp][NLp]     joiner activation
-    float *logits;                // [NL, V]
+    float *ht;                    // [Jp][kMaxLook * NLp]  joiner activation, column f * NLp + n
+    float *logits;                // [kMaxLook * NLp, V]   row f * NLp + n: lane n, frame t_n + f
+    int32_t *row_tok;             // [kMaxLook * NLp]      argmax of each logits row (look-ahead greedy)
+    int look;                     // frames per micro-step (1: the plain loop)
     int32_t *active_count;        // lanes still decoding
     // greedy outputs / params
     int32_t *hyps;                // [NL, max_hyp]
@@ -120,6 +123,7 @@ struct GemmArgs {
     float *new_cT, *new_hT;       // this layer's new state
     const float *ep_all;          // [n_utt, T, J]
     int H, J;
+    int look, lane_stride;        // joiner activation: frames per lane and the column stride between frames (NLp)
 };
 
 enum GemmEpilogue { kEpiKMajor = 0, kEpiRowMajor = 1, kEpiLstmCell = 2, kEpiJointAct = 3 };
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(64 * kGemmWaves) void lane_gemm_kernel(GemmArgs g)
     size_t cell_o = 0;
     float cell_c = 0.f;
     bool act_on[kItems];
-    float act_ep[kItems];
+    float act_ep[kMaxLook][kItems];
     if (EPI == kEpiRowMajor) {
         const int v = n0 + l31;                                          // the column of every item of this thread
         bias_v[0] = g.bias ? g.bias[v < g.N ? v : g.N - 1] : 0.f;
@@ -299,12 +303,14 @@ __global__ __launch_bounds__(64 * kGemmWaves) void lane_gemm_kernel(GemmArgs g)
             tt[it] = g.lane_t[in ? n : 0];
         }
 #pragma unroll
-        for (int it = 0; it < kItems; ++it) {
-            const int i = tid + it * NT;
-            const int v = n0 + ((i & 1023) >> 5), n = lane0 + (i >> 10) * 32 + (i & 31);
-            const int t = tt[it] < T ? tt[it] : T - 1;
-            act_ep[it] = act_on[it] ? g.ep_all[((size_t)(n / lpu) * T + t) * g.J + v] : 0.f;
-        }
+        for (int f = 0; f < kMaxLook; ++f)
+#pragma unroll
+            for (int it = 0; it < kItems; ++it) {
+                const int i = tid + it * NT;
+                const int v = n0 + ((i & 1023) >> 5), n = lane0 + (i >> 10) * 32 + (i & 31);
+                const int t = tt[it] + f < T ? tt[it] + f : T - 1;
+                act_ep[f][it] = (act_on[it] && f < g.look) ? g.ep_all[((size_t)(n / lpu) * T + t) * g.J + v] : 0.f;
+            }
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -363,14 +369,17 @@ __global__ __launch_bounds__(64 * kGemmWaves) void lane_gemm_kernel(GemmArgs g)
             g.new_cT[cell_o] = c;
             g.new_hT[cell_o] = og * tanhf(c);
         }
-    } else {   // kEpiJointAct: ht[j][lane] = tanh(ep_all[utt, t_lane, j] + pp[j][lane]); zero for idle lanes
+    } else {   // kEpiJointAct: ht[j][f * stride + lane] = tanh(ep_all[utt, t_lane + f, j] + pp[j][lane]); zero for idle lanes
 #pragma unroll
         for (int it = 0; it < kItems; ++it) {
             const int i = tid + it * NT;
             const int m = i >> 10, col = (i & 1023) >> 5, ln = i & 31;
             const int v = n0 + col, n = lane0 + m * 32 + ln;
             if (v >= g.N) continue;
-            g.C[(size_t)v * g.ldc + n] = act_on[it] ? tanhf(act_ep[it] + total(m, ln, col) + bias_v[it]) : 0.f;
+            const float pp = total(m, ln, col) + bias_v[it];
+#pragma unroll
+            for (int f = 0; f < kMaxLook; ++f)
+                if (f < g.look) g.C[(size_t)v * g.ldc + f * g.lane_stride + n] = act_on[it] ? tanhf(act_ep[f][it] + pp) : 0.f;
         }
     }
 }
@@ -506,6 +515,116 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(DevState *sp)
     }
     if (emit) {                                    // next predictor input
         for (int q = tid; q < d.D; q += 256) S.xT[(size_t)q * d.NLp + n] = S.embed[(size_t)k * d.D + q];
+    }
+    if (commit) {                                  // cache = new_cache (greedy_search copy.py:52)
+        for (int i = tid; i < d.L * d.Hp; i += 256) {
+            const size_t o = (size_t)i * d.NLp + n;
+            S.cache_hT[o] = S.new_hT[o];
+            S.cache_cT[o] = S.new_cT[o];
+        }
+    }
+}
+
+// ---- look-ahead greedy: `look` encoder frames per micro-step against one predictor state -------------------
+// While a lane keeps answering blank its predictor output does not change, so the joiner rows of frames t, t+1, ...
+// can be evaluated together: greedy_rows_kernel takes the argmax of every (frame, lane) row in parallel,
+// greedy_resolve_kernel then walks a lane's rows in order through the same state machine as greedy_update_kernel
+// and stops at the first emission (the predictor must step before the next decision).  Token sequences are
+// identical to the one-frame-per-step loop; a run of blanks costs one micro-step instead of `look`.
+template <int NV>
+__global__ __launch_bounds__(256) void greedy_rows_kernel(DevState *sp)
+{
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const DevState S = *sp;
+    const Dims &d = S.d;
+    const int n = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const int act = S.lane_active[n];
+    const int t = S.lane_t[n];
+    const int enc_len = S.enc_lens[n];
+    const float *__restrict__ x = S.logits + ((size_t)f * d.NLp + n) * d.V;
+    float xv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * 256;
+        xv[i] = x[v < d.V ? v : d.V - 1];
+    }
+    float m = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) m = fmaxf(m, (tid + i * 256 < d.V) ? xv[i] : -3.0e38f);
+    m = block_max(m, sv);
+    const int T = enc_len < S.T ? enc_len : S.T;
+    if (!act || t + f >= T) return;                // frames past the end are never consulted
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) sum += (tid + i * 256 < d.V) ? expf(xv[i] - m) : 0.f;
+    sum = block_sum(sum, sv);
+    const float ls = logf(sum);
+    float best = -3.0e38f;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * 256;
+        const float lp = (xv[i] - m) - ls;
+        if (v < d.V && lp > best) { best = lp; bi = v; }   // strided ascending scan keeps the lowest index per thread
+    }
+    block_argmax(best, bi, sv, si);
+    if (tid == 0) S.row_tok[(size_t)f * d.NLp + n] = bi;
+}
+
+__global__ __launch_bounds__(256) void greedy_resolve_kernel(DevState *sp)
+{
+    const DevState S = *sp;
+    const Dims &d = S.d;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int act = S.lane_active[n];
+    int t = S.lane_t[n], nb = S.noblk[n];
+    const int need0 = S.need_pred[n];
+    int nic = S.new_is_cache[n];
+    int len = S.hyp_lens[n];
+    const int enc_len = S.enc_lens[n];
+    int toks[kMaxLook];
+#pragma unroll
+    for (int f = 0; f < kMaxLook; ++f) toks[f] = S.row_tok[(size_t)(f < S.look ? f : 0) * d.NLp + n];
+    if (!act) return;
+    const int T = enc_len < S.T ? enc_len : S.T;
+    if (need0) nic = 0;                            // the predictor stepped in this micro-step
+    int need = need0, emitted = -1;
+    bool commit = false, done = false;
+#pragma unroll
+    for (int f = 0; f < kMaxLook; ++f) {
+        if (f >= S.look || done) continue;
+        const int k = toks[f];
+        const bool emit = (k != S.blank);
+        if (emit) {
+            if (tid == 0 && len < S.max_hyp) S.hyps[(size_t)n * S.max_hyp + len] = k;
+            len += 1;
+            need = 1;
+            nb += 1;
+            commit = !nic;
+            emitted = k;
+        }
+        if (!emit || nb >= S.n_steps) {
+            if (!emit) need = 0;
+            t += 1;
+            nb = 0;
+        }
+        done = emit || t >= T;                     // after an emission the remaining rows belong to a stale predictor state
+    }
+    if (tid == 0) {
+        if (need0) S.new_is_cache[n] = 0;
+        S.hyp_lens[n] = len;
+        if (emitted >= 0) S.token[n] = emitted;
+        S.need_pred[n] = need;
+        S.lane_t[n] = t;
+        S.noblk[n] = nb;
+        if (t >= T) {
+            S.lane_active[n] = 0;
+            atomicSub(S.active_count, 1);
+        }
+    }
+    if (emitted >= 0) {                            // next predictor input
+        for (int q = tid; q < d.D; q += 256) S.xT[(size_t)q * d.NLp + n] = S.embed[(size_t)emitted * d.D + q];
     }
     if (commit) {                                  // cache = new_cache (greedy_search copy.py:52)
         for (int i = tid; i < d.L * d.Hp; i += 256) {
@@ -894,6 +1013,7 @@ struct wr_decoder {
     hipGraphExec_t beam_graph;
     int greedy_graph_lanes, beam_graph_lanes;
     int stream_lanes;             // lanes whose streaming state (cache, token, flags) is live; -1: none
+    int look;                     // greedy look-ahead frames per micro-step (1..kMaxLook)
     bool use_graph;               // greedy micro-steps replayed from a hipGraph (default on)
     bool use_graph_beam;          // beam frames: plain launches measured faster (no host polling to amortise), default off
 };
@@ -947,13 +1067,14 @@ size_t carve(const wr_transducer_weights *w, int max_lanes, int max_utt, int Tma
     s.cache_hT = c.take<float>(cs); s.cache_cT = c.take<float>(cs);
     s.new_hT = c.take<float>(cs); s.new_cT = c.take<float>(cs);
     s.outT = c.take<float>((size_t)d.Pp * d.NLp);
-    s.ht = c.take<float>((size_t)d.Jp * d.NLp);
+    s.ht = c.take<float>((size_t)d.Jp * kMaxLook * d.NLp);
     const size_t zero_end = align_up(c.off, 256);
     s.ep_all = c.take<float>((size_t)max_utt * Tmax * d.J);
     s.token = c.take<int32_t>(d.NLp); s.lane_t = c.take<int32_t>(d.NLp); s.noblk = c.take<int32_t>(d.NLp);
     s.need_pred = c.take<int32_t>(d.NLp); s.lane_active = c.take<int32_t>(d.NLp);
     s.new_is_cache = c.take<int32_t>(d.NLp);
-    s.logits = c.take<float>((size_t)d.NL * d.V);
+    s.logits = c.take<float>((size_t)kMaxLook * d.NLp * d.V);
+    s.row_tok = c.take<int32_t>((size_t)kMaxLook * d.NLp);
     s.active_count = c.take<int32_t>(64);
     s.topv = c.take<float>((size_t)d.NL * kMaxBeam); s.topi = c.take<int32_t>((size_t)d.NL * kMaxBeam);
     s.n_hyps = c.take<int32_t>(max_utt); s.frame = c.take<int32_t>(max_utt);
@@ -1030,7 +1151,7 @@ void launch_predictor(wr_decoder *h, int n_lanes, hipStream_t st)
     launch_gemm<kEpiKMajor>(g, up(d.P, 32), n_lanes, st);
 }
 
-void launch_predictor_and_joint(wr_decoder *h, int n_lanes, hipStream_t st)
+void launch_predictor_and_joint(wr_decoder *h, int n_lanes, hipStream_t st, int look = 1)
 {
     const Dims &d = h->d;
     const DevState &s = h->host;
@@ -1039,14 +1160,17 @@ void launch_predictor_and_joint(wr_decoder *h, int n_lanes, hipStream_t st)
     {   // pred_ffn with the joiner activation as epilogue
         GemmArgs g{};
         g.A0 = s.outT; g.B0 = s.predffn_wt; g.K0 = d.Pp;
-        g.lda = d.NLp; g.ldb = up(d.J, 32); g.bias = s.predffn_b; g.C = s.ht; g.ldc = d.NLp; g.N = d.J; g.n_lanes = n_lanes;
+        g.lda = d.NLp; g.ldb = up(d.J, 32); g.bias = s.predffn_b; g.C = s.ht; g.ldc = kMaxLook * d.NLp; g.N = d.J; g.n_lanes = n_lanes;
         g.st = h->dev; g.lane_active = s.lane_active; g.lane_t = s.lane_t; g.ep_all = s.ep_all; g.J = d.J;
+        g.look = look; g.lane_stride = d.NLp;
         launch_gemm<kEpiJointAct>(g, up(d.J, 32), n_lanes, st);
     }
     GemmArgs g{};
+    // the joiner output for every (frame, lane) column of ht: rows f * NLp + n of the logits
+    const int rows = (look - 1) * d.NLp + n_lanes;
     g.A0 = s.ht; g.B0 = s.out_wt; g.K0 = d.Jp;
-    g.lda = d.NLp; g.ldb = d.Vp; g.bias = s.out_b; g.C = s.logits; g.ldc = d.V; g.N = d.V; g.n_lanes = n_lanes;
-    launch_gemm<kEpiRowMajor>(g, d.Vp, n_lanes, st);
+    g.lda = kMaxLook * d.NLp; g.ldb = d.Vp; g.bias = s.out_b; g.C = s.logits; g.ldc = d.V; g.N = d.V; g.n_lanes = rows;
+    launch_gemm<kEpiRowMajor>(g, d.Vp, rows, st);
 }
 
 }  // namespace
@@ -1079,6 +1203,7 @@ extern "C" int wr_decoder_create(const wr_transducer_weights *w, int max_lanes, 
     h->greedy_graph = nullptr; h->beam_graph = nullptr; h->greedy_graph_lanes = h->beam_graph_lanes = -1;
     h->use_graph = true;
     h->use_graph_beam = false;
+    h->look = 1;
     h->stream_lanes = -1;
     h->h_active = nullptr;
     if (hipHostMalloc(reinterpret_cast<void **>(&h->h_active), 64, hipHostMallocDefault) != hipSuccess) {
@@ -1143,6 +1268,14 @@ extern "C" int wr_decoder_set_graph(wr_decoder *h, int enable)
     return WR_OK;
 }
 
+extern "C" int wr_decoder_set_lookahead(wr_decoder *h, int frames)
+{
+    WR_REQUIRE(h != nullptr, WR_EINVAL, "decoder_set_lookahead: null handle");
+    WR_REQUIRE(frames >= 1 && frames <= kMaxLook, WR_EINVAL, "decoder_set_lookahead: frames=%d (1..%d)", frames, kMaxLook);
+    h->look = frames;
+    return WR_OK;
+}
+
 namespace {
 
 int upload_state(wr_decoder *h, hipStream_t st)
@@ -1154,11 +1287,20 @@ int upload_state(wr_decoder *h, hipStream_t st)
 
 void greedy_micro_step(wr_decoder *h, int n_lanes, hipStream_t st)
 {
-    launch_predictor_and_joint(h, n_lanes, st);
-    const int V = h->d.V;
-    if (V <= 256 * 8) hipLaunchKernelGGL(greedy_update_kernel<8>, dim3(n_lanes), dim3(256), 0, st, h->dev);
-    else if (V <= 256 * 24) hipLaunchKernelGGL(greedy_update_kernel<24>, dim3(n_lanes), dim3(256), 0, st, h->dev);
-    else hipLaunchKernelGGL(greedy_update_kernel<64>, dim3(n_lanes), dim3(256), 0, st, h->dev);   // V <= 16384 (check_weights)
+    const int look = h->look;
+    launch_predictor_and_joint(h, n_lanes, st, look);
+    const int V = h->d.V;                           // <= 16384 (check_weights)
+    if (look == 1) {
+        if (V <= 256 * 8) hipLaunchKernelGGL(greedy_update_kernel<8>, dim3(n_lanes), dim3(256), 0, st, h->dev);
+        else if (V <= 256 * 24) hipLaunchKernelGGL(greedy_update_kernel<24>, dim3(n_lanes), dim3(256), 0, st, h->dev);
+        else hipLaunchKernelGGL(greedy_update_kernel<64>, dim3(n_lanes), dim3(256), 0, st, h->dev);
+        return;
+    }
+    const dim3 grid(n_lanes, look);
+    if (V <= 256 * 8) hipLaunchKernelGGL(greedy_rows_kernel<8>, grid, dim3(256), 0, st, h->dev);
+    else if (V <= 256 * 24) hipLaunchKernelGGL(greedy_rows_kernel<24>, grid, dim3(256), 0, st, h->dev);
+    else hipLaunchKernelGGL(greedy_rows_kernel<64>, grid, dim3(256), 0, st, h->dev);
+    hipLaunchKernelGGL(greedy_resolve_kernel, dim3(n_lanes), dim3(256), 0, st, h->dev);
 }
 
 void beam_frame(wr_decoder *h, int n_lanes, int n_utt, hipStream_t st)
@@ -1220,6 +1362,7 @@ int greedy_run(wr_decoder *h, const float *enc_out_d, const int32_t *enc_lens_d,
     s.enc = enc_out_d; s.enc_lens = enc_lens_d; s.ctc_logp = nullptr;
     s.n_utt = N; s.T = T; s.lanes_per_utt = 1; s.n_lanes = N;
     s.hyps = hyps_d; s.hyp_lens = hyp_lens_d; s.max_hyp = h->max_hyp; s.n_steps = n_steps; s.blank = blank; s.beam = 1;
+    s.look = h->look;
     if (int rc = upload_state(h, st)) return rc;
     (void)hipMemsetAsync(s.active_count, 0, sizeof(int32_t), st);
     (void)hipMemsetAsync(s.lane_active, 0, sizeof(int32_t) * h->d.NLp, st);
@@ -1229,10 +1372,11 @@ int greedy_run(wr_decoder *h, const float *enc_out_d, const int32_t *enc_lens_d,
     else hipLaunchKernelGGL(greedy_chunk_init_kernel, dim3(N), dim3(128), 0, st, h->dev, mode == 2 ? 1 : 0);
     WR_CHECK_LAUNCH("greedy_init");
     h->stream_lanes = N;
-    if (h->use_graph && h->greedy_graph_lanes != N) {
+    const int gkey = N * 8 + h->look;
+    if (h->use_graph && h->greedy_graph_lanes != gkey) {
         if (h->greedy_graph) { (void)hipGraphExecDestroy(h->greedy_graph); h->greedy_graph = nullptr; }
         if (int rc = capture(st, kStepsPerGraph, [&] { greedy_micro_step(h, N, st); }, &h->greedy_graph)) return rc;
-        h->greedy_graph_lanes = N;
+        h->greedy_graph_lanes = gkey;
     }
     const long max_micro = (long)T * ((long)n_steps + 1) + 1;
     for (long done = 0; done < max_micro; done += kStepsPerGraph) {

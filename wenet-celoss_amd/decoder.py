@@ -5,6 +5,7 @@ search and the predictor step."""
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Tuple
 
 import torch
@@ -75,6 +76,9 @@ class DeviceDecoder:
         _lib.check(rc, "wr_decoder_create")
         self._h = handle
         self._lib = lib
+        look = int(os.environ.get("WR_GREEDY_LOOKAHEAD", "1"))
+        if look != 1:
+            self.set_lookahead(look)
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -86,6 +90,10 @@ class DeviceDecoder:
 
     def set_graph(self, enable: bool) -> None:
         _lib.check(self._lib.wr_decoder_set_graph(self._h, int(enable)), "wr_decoder_set_graph")
+
+    def set_lookahead(self, frames: int) -> None:
+        """Greedy search: encoder frames evaluated per micro-step (1..4); token sequences do not depend on it."""
+        _lib.check(self._lib.wr_decoder_set_lookahead(self._h, int(frames)), "wr_decoder_set_lookahead")
 
     def greedy(self, encoder_out: torch.Tensor, encoder_out_lens: torch.Tensor, n_steps: int = 64, blank: int = 0
                ) -> List[List[int]]:
