@@ -115,3 +115,28 @@ def test_model_survives_train_py_script_export(tmp_path):
     sm = torch.jit.script(m)
     sm.save(str(tmp_path / "init.zip"))
     assert (tmp_path / "init.zip").stat().st_size > 0
+
+
+def test_joint_precision_selection(monkeypatch):
+    """precision= / WR_JOINT_PRECISION select the joiner mode; unknown names are rejected; every mode refuses CPU
+    tensors (there is no CPU path in the product)."""
+    import pytest
+    import torch
+    import wenet_celoss_amd as w
+    from wenet_celoss_amd import joint as jm
+    monkeypatch.delenv("WR_JOINT_PRECISION", raising=False)
+    assert jm._resolve_precision(None) == "fp32"
+    monkeypatch.setenv("WR_JOINT_PRECISION", "bf16x3")
+    assert jm._resolve_precision(None) == "bf16x3"
+    assert jm._resolve_precision("bf16") == "bf16"          # the argument wins over the environment
+    with pytest.raises(ValueError, match="precision"):
+        jm._resolve_precision("tf32")
+    monkeypatch.setenv("WR_JOINT_PRECISION", "fast")
+    with pytest.raises(ValueError, match="precision"):
+        jm._resolve_precision(None)
+    monkeypatch.delenv("WR_JOINT_PRECISION")
+    for prec in (None, "bf16x3", "bf16"):
+        m = w.TransducerJoint(12, 4, 4, 8, precision=prec)
+        assert m.precision == prec
+        with pytest.raises(RuntimeError, match="HIP device"):
+            m(torch.zeros(1, 2, 4), torch.zeros(1, 3, 4))
