@@ -274,7 +274,9 @@ int wr_decoder_set_graph(wr_decoder *h, int enable);
 /* Greedy look-ahead: evaluate the joiner for `frames` (1..4) consecutive encoder frames of every stream per
  * micro-step.  A stream's predictor output only changes after a non-blank, so a run of blanks is consumed in one
  * micro-step instead of `frames`; decisions are walked in frame order through the same state machine and stop at
- * the first emission, so the token sequences are those of the one-frame loop (frames = 1, the default). */
+ * the first emission, so the token sequences are those of the one-frame loop (frames = 1).
+ * frames = 0 (the default): chosen before every graph replay from the share of blank decisions in the previous one
+ * (>= 75 % blank: 4 frames, >= 62 %: 2, else 1). */
 int wr_decoder_set_lookahead(wr_decoder *h, int frames);
 
 /* enc_out [N, T, E] fp32, enc_lens [N]; hyps [N, max_hyp] / hyp_lens [N] out (tokens beyond

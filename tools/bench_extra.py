@@ -187,7 +187,7 @@ def bench_greedy(args):
             joint.ffn_out.bias[0] += extra_blank
         m_s = types.SimpleNamespace(blank=0, predictor=pred, joint=joint)
         ref_hyps = w.basic_greedy_search(m_s, e_s, lens, n_steps=n_steps_s)
-        for look in (1, 2, 4):
+        for look in (1, 2, 4, 0):                      # 0: adaptive
             dec = m_s._decoder_cache._dec
             dec.set_lookahead(look)
             got = w.basic_greedy_search(m_s, e_s, lens, n_steps=n_steps_s)
@@ -203,6 +203,7 @@ def bench_greedy(args):
                               "utt_per_s": round(N / dt, 1), "tokens_identical": got == ref_hyps}), flush=True)
         with torch.no_grad():
             joint.ffn_out.bias[0] -= extra_blank
+        m_s._decoder_cache._dec.set_lookahead(0)
     # CPU reference: the reference's loop restated in numpy (oracle), one stream, scaled to 64
     p = do.Predictor({k: v.detach().cpu().numpy() for k, v in pred.state_dict().items()}, L)
     j = do.Joint({k: v.detach().cpu().numpy() for k, v in joint.state_dict().items()})

@@ -87,7 +87,6 @@ struct DevState {
     float *ht;                    // [Jp][kMaxLook * NLp]  joiner activation, column f * NLp + n
     float *logits;                // [kMaxLook * NLp, V]   row f * NLp + n: lane n, frame t_n + f
     int32_t *row_tok;             // [kMaxLook * NLp]      argmax of each logits row (look-ahead greedy)
-    int look;                     // frames per micro-step (1: the plain loop)
     int32_t *active_count;        // lanes still decoding
     // greedy outputs / params
     int32_t *hyps;                // [NL, max_hyp]
@@ -499,6 +498,7 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(DevState *sp)
     }
     const int T = enc_len < S.T ? enc_len : S.T;
     if (tid == 0) {
+        atomicAdd(S.active_count + (emit ? 2 : 1), 1);               // decision statistics for the look-ahead policy
         if (need) S.new_is_cache[n] = 0;
         if (emit) {
             if (len < S.max_hyp) S.hyps[(size_t)n * S.max_hyp + len] = k;
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(256) void greedy_rows_kernel(DevState *sp)
     if (tid == 0) S.row_tok[(size_t)f * d.NLp + n] = bi;
 }
 
-__global__ __launch_bounds__(256) void greedy_resolve_kernel(DevState *sp)
+__global__ __launch_bounds__(256) void greedy_resolve_kernel(DevState *sp, int look)
 {
     const DevState S = *sp;
     const Dims &d = S.d;
@@ -585,17 +585,18 @@ __global__ __launch_bounds__(256) void greedy_resolve_kernel(DevState *sp)
     const int enc_len = S.enc_lens[n];
     int toks[kMaxLook];
 #pragma unroll
-    for (int f = 0; f < kMaxLook; ++f) toks[f] = S.row_tok[(size_t)(f < S.look ? f : 0) * d.NLp + n];
+    for (int f = 0; f < kMaxLook; ++f) toks[f] = S.row_tok[(size_t)(f < look ? f : 0) * d.NLp + n];
     if (!act) return;
     const int T = enc_len < S.T ? enc_len : S.T;
     if (need0) nic = 0;                            // the predictor stepped in this micro-step
-    int need = need0, emitted = -1;
+    int need = need0, emitted = -1, n_blank = 0;
     bool commit = false, done = false;
 #pragma unroll
     for (int f = 0; f < kMaxLook; ++f) {
-        if (f >= S.look || done) continue;
+        if (f >= look || done) continue;
         const int k = toks[f];
         const bool emit = (k != S.blank);
+        n_blank += emit ? 0 : 1;
         if (emit) {
             if (tid == 0 && len < S.max_hyp) S.hyps[(size_t)n * S.max_hyp + len] = k;
             len += 1;
@@ -612,6 +613,8 @@ __global__ __launch_bounds__(256) void greedy_resolve_kernel(DevState *sp)
         done = emit || t >= T;                     // after an emission the remaining rows belong to a stale predictor state
     }
     if (tid == 0) {
+        if (n_blank) atomicAdd(S.active_count + 1, n_blank);         // decision statistics for the look-ahead policy
+        if (emitted >= 0) atomicAdd(S.active_count + 2, 1);
         if (need0) S.new_is_cache[n] = 0;
         S.hyp_lens[n] = len;
         if (emitted >= 0) S.token[n] = emitted;
@@ -1009,11 +1012,12 @@ struct wr_decoder {
     int32_t *h_active;            // pinned host word
     hipStream_t work;             // decode work runs here (graph capture is illegal on the legacy default stream)
     hipEvent_t ev_in, ev_out;     // ordering against the caller's stream, no device-wide sync
-    hipGraphExec_t greedy_graph;
+    hipGraphExec_t greedy_graph[kMaxLook + 1];   // one per look-ahead setting
+    int greedy_graph_key[kMaxLook + 1];
     hipGraphExec_t beam_graph;
-    int greedy_graph_lanes, beam_graph_lanes;
+    int beam_graph_lanes;
     int stream_lanes;             // lanes whose streaming state (cache, token, flags) is live; -1: none
-    int look;                     // greedy look-ahead frames per micro-step (1..kMaxLook)
+    int look;                     // greedy look-ahead: frames per micro-step (1..kMaxLook), 0: chosen per replay
     bool use_graph;               // greedy micro-steps replayed from a hipGraph (default on)
     bool use_graph_beam;          // beam frames: plain launches measured faster (no host polling to amortise), default off
 };
@@ -1200,10 +1204,11 @@ extern "C" int wr_decoder_create(const wr_transducer_weights *w, int max_lanes, 
     carve(w, max_lanes, max_utt, Tmax, max_hyp, max_beam, h->ws, &h->host, &h->dev, h->zero_range);
     h->d = h->host.d;
     h->max_utt = max_utt; h->Tmax = Tmax; h->max_hyp = max_hyp; h->max_beam = max_beam;
-    h->greedy_graph = nullptr; h->beam_graph = nullptr; h->greedy_graph_lanes = h->beam_graph_lanes = -1;
+    for (int i = 0; i <= kMaxLook; ++i) { h->greedy_graph[i] = nullptr; h->greedy_graph_key[i] = -1; }
+    h->beam_graph = nullptr; h->beam_graph_lanes = -1;
     h->use_graph = true;
     h->use_graph_beam = false;
-    h->look = 1;
+    h->look = 0;
     h->stream_lanes = -1;
     h->h_active = nullptr;
     if (hipHostMalloc(reinterpret_cast<void **>(&h->h_active), 64, hipHostMallocDefault) != hipSuccess) {
@@ -1250,7 +1255,8 @@ extern "C" int wr_decoder_create(const wr_transducer_weights *w, int max_lanes, 
 extern "C" int wr_decoder_destroy(wr_decoder *h)
 {
     if (!h) return WR_OK;
-    if (h->greedy_graph) (void)hipGraphExecDestroy(h->greedy_graph);
+    for (int i = 0; i <= kMaxLook; ++i)
+        if (h->greedy_graph[i]) (void)hipGraphExecDestroy(h->greedy_graph[i]);
     if (h->beam_graph) (void)hipGraphExecDestroy(h->beam_graph);
     if (h->h_active) (void)hipHostFree(h->h_active);
     (void)hipStreamSynchronize(h->work);
@@ -1271,7 +1277,7 @@ extern "C" int wr_decoder_set_graph(wr_decoder *h, int enable)
 extern "C" int wr_decoder_set_lookahead(wr_decoder *h, int frames)
 {
     WR_REQUIRE(h != nullptr, WR_EINVAL, "decoder_set_lookahead: null handle");
-    WR_REQUIRE(frames >= 1 && frames <= kMaxLook, WR_EINVAL, "decoder_set_lookahead: frames=%d (1..%d)", frames, kMaxLook);
+    WR_REQUIRE(frames >= 0 && frames <= kMaxLook, WR_EINVAL, "decoder_set_lookahead: frames=%d (0..%d)", frames, kMaxLook);
     h->look = frames;
     return WR_OK;
 }
@@ -1285,9 +1291,8 @@ int upload_state(wr_decoder *h, hipStream_t st)
     return WR_OK;
 }
 
-void greedy_micro_step(wr_decoder *h, int n_lanes, hipStream_t st)
+void greedy_micro_step(wr_decoder *h, int n_lanes, hipStream_t st, int look)
 {
-    const int look = h->look;
     launch_predictor_and_joint(h, n_lanes, st, look);
     const int V = h->d.V;                           // <= 16384 (check_weights)
     if (look == 1) {
@@ -1300,7 +1305,7 @@ void greedy_micro_step(wr_decoder *h, int n_lanes, hipStream_t st)
     if (V <= 256 * 8) hipLaunchKernelGGL(greedy_rows_kernel<8>, grid, dim3(256), 0, st, h->dev);
     else if (V <= 256 * 24) hipLaunchKernelGGL(greedy_rows_kernel<24>, grid, dim3(256), 0, st, h->dev);
     else hipLaunchKernelGGL(greedy_rows_kernel<64>, grid, dim3(256), 0, st, h->dev);
-    hipLaunchKernelGGL(greedy_resolve_kernel, dim3(n_lanes), dim3(256), 0, st, h->dev);
+    hipLaunchKernelGGL(greedy_resolve_kernel, dim3(n_lanes), dim3(256), 0, st, h->dev, look);
 }
 
 void beam_frame(wr_decoder *h, int n_lanes, int n_utt, hipStream_t st)
@@ -1362,9 +1367,8 @@ int greedy_run(wr_decoder *h, const float *enc_out_d, const int32_t *enc_lens_d,
     s.enc = enc_out_d; s.enc_lens = enc_lens_d; s.ctc_logp = nullptr;
     s.n_utt = N; s.T = T; s.lanes_per_utt = 1; s.n_lanes = N;
     s.hyps = hyps_d; s.hyp_lens = hyp_lens_d; s.max_hyp = h->max_hyp; s.n_steps = n_steps; s.blank = blank; s.beam = 1;
-    s.look = h->look;
     if (int rc = upload_state(h, st)) return rc;
-    (void)hipMemsetAsync(s.active_count, 0, sizeof(int32_t), st);
+    (void)hipMemsetAsync(s.active_count, 0, 3 * sizeof(int32_t), st);    // lanes active, blank decisions, emissions
     (void)hipMemsetAsync(s.lane_active, 0, sizeof(int32_t) * h->d.NLp, st);
     hipLaunchKernelGGL(ep_all_kernel, dim3((unsigned)(((long)N * T + 7) / 8)), dim3(256), (size_t)8 * h->d.E * sizeof(float), st,
                        h->dev);
@@ -1372,25 +1376,35 @@ int greedy_run(wr_decoder *h, const float *enc_out_d, const int32_t *enc_lens_d,
     else hipLaunchKernelGGL(greedy_chunk_init_kernel, dim3(N), dim3(128), 0, st, h->dev, mode == 2 ? 1 : 0);
     WR_CHECK_LAUNCH("greedy_init");
     h->stream_lanes = N;
-    const int gkey = N * 8 + h->look;
-    if (h->use_graph && h->greedy_graph_lanes != gkey) {
-        if (h->greedy_graph) { (void)hipGraphExecDestroy(h->greedy_graph); h->greedy_graph = nullptr; }
-        if (int rc = capture(st, kStepsPerGraph, [&] { greedy_micro_step(h, N, st); }, &h->greedy_graph)) return rc;
-        h->greedy_graph_lanes = gkey;
-    }
+    // look-ahead per replay: fixed, or (h->look == 0) chosen from the share of blank decisions in the previous
+    // replay -- any value gives the same tokens, so switching between replays is safe
+    int look = h->look > 0 ? h->look : 1;
+    int prev_blank = 0, prev_emit = 0;
     const long max_micro = (long)T * ((long)n_steps + 1) + 1;
     for (long done = 0; done < max_micro; done += kStepsPerGraph) {
         if (h->use_graph) {
-            hipError_t e = hipGraphLaunch(h->greedy_graph, st);
+            if (h->greedy_graph_key[look] != N) {
+                if (h->greedy_graph[look]) { (void)hipGraphExecDestroy(h->greedy_graph[look]); h->greedy_graph[look] = nullptr; }
+                if (int rc = capture(st, kStepsPerGraph, [&] { greedy_micro_step(h, N, st, look); }, &h->greedy_graph[look]))
+                    return rc;
+                h->greedy_graph_key[look] = N;
+            }
+            hipError_t e = hipGraphLaunch(h->greedy_graph[look], st);
             if (e != hipSuccess) { set_error("greedy_search: hipGraphLaunch failed: %s", hipGetErrorString(e)); return WR_ELAUNCH; }
         } else {
-            for (int i = 0; i < kStepsPerGraph; ++i) greedy_micro_step(h, N, st);
+            for (int i = 0; i < kStepsPerGraph; ++i) greedy_micro_step(h, N, st, look);
         }
         // the reference synchronises on every step (.item()); we do once per kStepsPerGraph micro-steps
-        (void)hipMemcpyAsync(h->h_active, s.active_count, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        (void)hipMemcpyAsync(h->h_active, s.active_count, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st);
         hipError_t e = hipStreamSynchronize(st);
         if (e != hipSuccess) { set_error("greedy_search: stream error: %s", hipGetErrorString(e)); return WR_ELAUNCH; }
-        if (*h->h_active <= 0) break;
+        if (h->h_active[0] <= 0) break;
+        if (h->look == 0) {
+            const int nb = h->h_active[1] - prev_blank, ne = h->h_active[2] - prev_emit;
+            prev_blank = h->h_active[1]; prev_emit = h->h_active[2];
+            const float share = (nb + ne) > 0 ? (float)nb / (float)(nb + ne) : 0.f;
+            look = share >= 0.75f ? 4 : share >= 0.62f ? 2 : 1;
+        }
     }
     leave(h, caller);
     WR_CHECK_LAUNCH("greedy_search");

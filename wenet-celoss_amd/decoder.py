@@ -76,9 +76,9 @@ class DeviceDecoder:
         _lib.check(rc, "wr_decoder_create")
         self._h = handle
         self._lib = lib
-        look = int(os.environ.get("WR_GREEDY_LOOKAHEAD", "1"))
-        if look != 1:
-            self.set_lookahead(look)
+        look = os.environ.get("WR_GREEDY_LOOKAHEAD")      # unset: the library default (adaptive)
+        if look is not None:
+            self.set_lookahead(int(look))
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -92,7 +92,8 @@ class DeviceDecoder:
         _lib.check(self._lib.wr_decoder_set_graph(self._h, int(enable)), "wr_decoder_set_graph")
 
     def set_lookahead(self, frames: int) -> None:
-        """Greedy search: encoder frames evaluated per micro-step (1..4); token sequences do not depend on it."""
+        """Greedy search: encoder frames evaluated per micro-step (1..4, 0 = adaptive); token sequences do not
+        depend on it."""
         _lib.check(self._lib.wr_decoder_set_lookahead(self._h, int(frames)), "wr_decoder_set_lookahead")
 
     def greedy(self, encoder_out: torch.Tensor, encoder_out_lens: torch.Tensor, n_steps: int = 64, blank: int = 0
