@@ -502,6 +502,183 @@ __global__ __launch_bounds__(64 * kZWaves) void joint_bwd_dz_split_kernel(
     }
 }
 
+// dZ, second tiling: the W fragments of a step are needed by every row tile, so here the waves split the ROWS (a
+// workgroup owns 128 cells, a wave 32 of them and all J columns: 16 accumulator tiles = 256 registers) and the
+// fragments of one 16-deep step (hi and lo of every column tile, 32 KB at J = 512) are staged once per workgroup
+// in LDS (three stages, two register sets: loads run two steps ahead of their LDS write, as in the weight-gradient
+// kernel).  Half the L2 traffic for W per cell of the first tiling.
+constexpr int kZM2 = 128;        // cells per workgroup
+constexpr int kZStages = 3;
+
+template <int TERMS>
+__global__ __launch_bounds__(256) void joint_bwd_dz_split128_kernel(
+    const float *__restrict__ gout /* [M, V] */, const float *__restrict__ ep, const float *__restrict__ pp,
+    const u32x4 *__restrict__ wh, const u32x4 *__restrict__ wl, const int32_t *__restrict__ llens,
+    const int32_t *__restrict__ tlens, int B, int T, int U1, int J, int V, int D, int n_jt,
+    float *__restrict__ dz /* [M, J] */, float *__restrict__ hout /* [M, J] or null */)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dz_lds[];
+    // stage layout: [kZStages][2 images][16 column tiles][64 lanes] x 16 bytes
+    u32x4 *stage = reinterpret_cast<u32x4 *>(dz_lds);
+    long *row_e = reinterpret_cast<long *>(dz_lds + (size_t)kZStages * 2 * 16 * 64 * 16);
+    long *row_p = row_e + kZM2;
+    int *row_ok = reinterpret_cast<int *>(row_p + kZM2);
+    const long M = (long)B * T * U1;
+    const long m0 = (long)blockIdx.x * kZM2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    int valid = 0;
+    if (tid < kZM2) {
+        const long m = m0 + tid < M ? m0 + tid : M - 1;
+        const long bt = m / U1;
+        const int u = (int)(m - bt * U1);
+        const long b = bt / T;
+        valid = m0 + tid < M;
+        if (valid && llens != nullptr && tlens != nullptr) {
+            const int t = (int)(bt - b * T);
+            valid = (t < llens[b]) && (u <= tlens[b]);
+        }
+        row_e[tid] = bt * J;
+        row_p[tid] = (b * U1 + u) * J;
+        row_ok[tid] = valid;
+    }
+    const bool any = __syncthreads_or(valid);
+    if (!any) {
+        for (int i = tid; i < kZM2 * J; i += 256) {
+            const long m = m0 + i / J;
+            if (m < M) {
+                dz[(size_t)m * J + i % J] = 0.f;
+                if (hout) hout[(size_t)m * J + i % J] = 0.f;
+            }
+        }
+        return;
+    }
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = (f32x16){0};
+
+    const long mrow = m0 + 32 * wave + l31 < M ? m0 + 32 * wave + l31 : M - 1;
+    const float *__restrict__ arow = gout + (size_t)mrow * V + 16 * half;
+    const int Dfull = V / 32;
+    const int steps = 2 * D;                                // 16-deep steps, two per double step
+
+    // W staging: chunk c = tid + 256 q (q < 8) is lane (c & 63) of fragment (c >> 6): fragments 0..15 hi, 16..31 lo
+    struct WRegs { u32x4 v[8]; };
+    auto wload = [&](int s, WRegs &z) {
+        const int ss = s < steps ? s : steps - 1;
+        const int d = ss >> 1, t = ss & 1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c = tid + 256 * q, fr = c >> 6, ln = c & 63;
+            int jt = fr & 15;
+            jt = jt < n_jt ? jt : n_jt - 1;
+            const size_t f = (((size_t)jt * D + d) * 2 + t) * 64 + ln;
+            z.v[q] = (fr < 16) ? wh[f] : (TERMS == 3 ? wl[f] : wh[f]);
+        }
+    };
+    auto wwrite = [&](int s, const WRegs &z) {
+        u32x4 *st = stage + (size_t)(s % kZStages) * 2 * 16 * 64;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) st[tid + 256 * q] = z.v[q];
+    };
+    // dY of this lane's row: 16 floats per double step (elements 0-7 feed the even step, 8-15 the odd one)
+    struct ARegs { f32x4 a[4]; };
+    auto aload = [&](int d, ARegs &z) {
+        const int dd = d < Dfull ? d : (Dfull > 0 ? Dfull - 1 : 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z.a[i] = *reinterpret_cast<const f32x4 *>(arow + 32 * dd + 4 * i);
+    };
+    auto atail = [&](ARegs &z) {                            // the row's tail (V % 32 values): guarded scalar reads
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int v = 32 * Dfull + 16 * half + 4 * i + e;
+                z.a[i][e] = v < V ? arow[32 * Dfull + 4 * i + e] : 0.f;
+            }
+    };
+    auto compute = [&](int s, const ARegs &z) {
+        const int t = s & 1;
+        bf16x8 ah, al;
+        split8(z.a[2 * t], z.a[2 * t + 1], ah, al, TERMS == 3);
+        const u32x4 *st = stage + (size_t)(s % kZStages) * 2 * 16 * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (c < n_jt) {
+                const bf16x8 bhv = __builtin_bit_cast(bf16x8, st[c * 64]);
+                if (TERMS == 3) {
+                    const bf16x8 blv = __builtin_bit_cast(bf16x8, st[(16 + c) * 64]);
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bhv, acc[c], 0, 0, 0);
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blv, acc[c], 0, 0, 0);
+                }
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhv, acc[c], 0, 0, 0);
+            }
+        }
+    };
+
+    WRegs w0, w1;
+    ARegs a0, a1;
+    wload(0, w0); wwrite(0, w0);
+    wload(1, w0); wwrite(1, w0);
+    wload(2, w0);
+    wload(3, w1);
+    if (Dfull > 0) aload(0, a0); else atail(a0);
+    if (1 < Dfull) aload(1, a1); else if (1 < D) atail(a1);
+    // the loop handles two double steps (four 16-deep steps) per trip; D is padded to even below by repeating the
+    // last double step with zero fragments (W is zero past V, and the A tail is zero there too)
+    for (int d = 0; d < D; d += 2) {
+        // ---- double step d (registers a0) ----
+        __syncthreads();
+        wwrite(2 * d + 2, w0);
+        wload(2 * d + 4, w0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(2 * d, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        wwrite(2 * d + 3, w1);
+        wload(2 * d + 5, w1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(2 * d + 1, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (d + 2 < Dfull) aload(d + 2, a0); else if (d + 2 < D) atail(a0);
+        // ---- double step d + 1 (registers a1) ----
+        __syncthreads();
+        wwrite(2 * d + 4, w0);
+        wload(2 * d + 6, w0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (d + 1 < D) compute(2 * d + 2, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        wwrite(2 * d + 5, w1);
+        wload(2 * d + 7, w1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (d + 1 < D) compute(2 * d + 3, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (d + 3 < Dfull) aload(d + 3, a1); else if (d + 3 < D) atail(a1);
+    }
+
+    // epilogue: dZ = dH * (1 - H^2), H recomputed per element; padded cells give zeros
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int row = 32 * wave + (q & 3) + 8 * (q >> 2) + 4 * half;
+        const long m = m0 + row;
+        if (m >= M) continue;
+        const bool ok = row_ok[row] != 0;
+        const float *__restrict__ e = ep + row_e[row];
+        const float *__restrict__ p = pp + row_p[row];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int k = c * 32 + l31;
+            if (c >= n_jt || k >= J) continue;
+            const float h = tanhf(e[k] + p[k]);
+            dz[(size_t)m * J + k] = ok ? acc[c][q] * (1.f - h * h) : 0.f;
+            if (hout) hout[(size_t)m * J + k] = ok ? h : 0.f;
+        }
+    }
+}
+
 // ---------------------------------------------------- backward, weight gradient --
 // dW[v, j] = sum_m dY[m, v] * H[m, j],  db[v] = sum_m dY[m, v]     (M = B*T*U1 lattice cells, padded cells excluded)
 // A reduction over millions of cells into a V x J matrix.  One workgroup (4 waves = 2 v-halves x 2 j-halves, one
@@ -801,6 +978,22 @@ extern "C" int wr_joint_bwd_dz_split(const float *gout_d, const float *ep_d, con
     WR_CHECK_LAUNCH("split_w_dz_kernel");
     const long M = (long)B * T * U1;
     const dim3 grid((unsigned)((M + kSM - 1) / kSM));
+    if (tune_get(kTuneDzTile) != 1) {                       // default: 128-cell tiling, W fragments staged in LDS
+        const size_t lds = (size_t)kZStages * 2 * 16 * 64 * 16 + (size_t)kZM2 * (2 * sizeof(long) + sizeof(int));
+        const dim3 grid2((unsigned)((M + kZM2 - 1) / kZM2));
+#define WR_LAUNCH_DZ2(TERMS)                                                                                           \
+        do {                                                                                                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_bwd_dz_split128_kernel<TERMS>),              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+            hipLaunchKernelGGL(joint_bwd_dz_split128_kernel<TERMS>, grid2, dim3(256), lds, st, gout_d, ep_d, pp_d,      \
+                               reinterpret_cast<const u32x4 *>(wh), reinterpret_cast<const u32x4 *>(wl),               \
+                               logit_lengths_d, target_lengths_d, B, T, U1, J, V, D, n_jt, dz_d, h_d);                 \
+        } while (0)
+        if (terms == 3) WR_LAUNCH_DZ2(3); else WR_LAUNCH_DZ2(1);
+#undef WR_LAUNCH_DZ2
+        WR_CHECK_LAUNCH("joint_bwd_dz_split128_kernel");
+        return WR_OK;
+    }
     if (terms == 3)
         hipLaunchKernelGGL(joint_bwd_dz_split_kernel<3>, grid, dim3(64 * kZWaves), 0, st, gout_d, ep_d, pp_d,
                            reinterpret_cast<const u32x4 *>(wh), reinterpret_cast<const u32x4 *>(wl), logit_lengths_d,
