@@ -232,7 +232,7 @@ int wr_joint_bwd_dw_split(const float *gout_d /* [B,T,U1,V] */, const float *h_d
  * stream with events (no device-wide synchronisation).  wr_greedy_search synchronises its own work
  * stream once every 16 micro-steps to test the "lanes still decoding" word (the reference
  * synchronises on every step); wr_prefix_beam_search and wr_predictor_step never do.
- * Limits: lanes <= 128, vocabulary <= 16384, LSTM layers <= 4, beam <= 16, layer widths <= 1024.
+ * Limits: lanes <= 1024, vocabulary <= 16384, LSTM layers <= 4, beam <= 16, layer widths <= 1024.
  * ---------------------------------------------------------------------- */
 #define WR_MAX_LSTM_LAYERS 4
 
@@ -276,7 +276,7 @@ int wr_decoder_set_graph(wr_decoder *h, int enable);
  * micro-step instead of `frames`; decisions are walked in frame order through the same state machine and stop at
  * the first emission, so the token sequences are those of the one-frame loop (frames = 1).
  * frames = 0 (the default): chosen before every graph replay from the share of blank decisions in the previous one
- * (>= 75 % blank: 4 frames, >= 62 %: 2, else 1). */
+ * (>= 75 % blank: 4 frames, >= 62 %: 2, else 1; never more than 256 joiner rows per micro-step). */
 int wr_decoder_set_lookahead(wr_decoder *h, int frames);
 
 /* enc_out [N, T, E] fp32, enc_lens [N]; hyps [N, max_hyp] / hyp_lens [N] out (tokens beyond

@@ -326,3 +326,47 @@ def test_greedy_lookahead_batched_and_streaming(look):
         got = dec.greedy_chunk(encs[:, a:b].contiguous(), cl.clamp(min=1), n_steps=n_steps, reset=a == 0,
                                reference_new_cache=False)
         assert got == base_chunks[i], (a, b)
+
+
+def test_greedy_many_streams_equal_small_batches():
+    """300 streams in one call (lane tiles beyond the first 128) give each stream the tokens it gets in a small
+    batch -- streams are independent."""
+    from wenet_celoss_amd.decoder import DeviceDecoder
+    d = np.load(names("greedy_core_1.npz")[0])
+    pred, joint, _ = build_modules(d)
+    enc0 = torch.tensor(d["enc"], device=DEV)[0]
+    T, n_steps = enc0.shape[0], int(d["n_steps"])
+    g = torch.Generator(device=DEV).manual_seed(3)
+    N = 300
+    scale = 0.5 + torch.rand(N, 1, 1, device=DEV, generator=g)
+    encs = enc0[None] * scale
+    encs[1::3] = encs[1::3].flip(1)
+    lens = torch.randint(1, T + 1, (N,), generator=torch.Generator().manual_seed(4))
+    big = DeviceDecoder(pred, joint, max_lanes=N, max_utt=N, tmax=T, max_hyp=T * n_steps)
+    small = DeviceDecoder(pred, joint, max_lanes=20, max_utt=20, tmax=T, max_hyp=T * n_steps)
+    got = big.greedy(encs, lens, n_steps=n_steps)
+    for a in range(0, N, 100):
+        ref = small.greedy(encs[a:a + 20].contiguous(), lens[a:a + 20], n_steps=n_steps)
+        assert got[a:a + 20] == ref, a
+    with pytest.raises(RuntimeError, match="max_lanes"):
+        DeviceDecoder(pred, joint, max_lanes=2000, max_utt=1, tmax=T)
+
+
+def test_prefix_beam_many_utterances_equal_single():
+    """40 utterances x beam 5 = 200 lanes in one call: every utterance gets the hypotheses of its own single run."""
+    import wenet_celoss_amd as w
+    d = np.load(names("prefix_beam_1.npz")[0])
+    pred, joint, ctc = build_modules(d, with_ctc=True)
+    enc0 = torch.tensor(d["enc"], device=DEV)
+    T = int(d["T"])
+    g = torch.Generator(device=DEV).manual_seed(12)
+    B = 40
+    encs = enc0 * (0.5 + torch.rand(B, 1, 1, device=DEV, generator=g))
+    encs[::2] = encs[::2].flip(1)
+    lens = torch.randint(3, T + 1, (B,), generator=torch.Generator().manual_seed(13)).to(torch.int32)
+    bs = w.PrefixBeamSearch(None, pred, joint, ctc, 0)
+    batch = bs.search_encoded(encs, lens, beam_size=5)
+    for b in (0, 7, 25, 39):
+        single = bs.search_encoded(encs[b:b + 1, :int(lens[b])].contiguous(), lens[b:b + 1], beam_size=5)[0]
+        assert [s.hyp for s in single] == [s.hyp for s in batch[b]], b
+        np.testing.assert_allclose([s.score for s in single], [s.score for s in batch[b]], rtol=1e-6)

@@ -150,7 +150,7 @@ def bench_greedy(args):
     from oracle import decode_oracle as do
     dev = torch.device("cuda:0")
     torch.manual_seed(5)
-    V, E, P, J, H, L, N = 5000, 256, 256, 512, 256, 2, 64
+    V, E, P, J, H, L, N = 5000, 256, 256, 512, 256, 2, args.streams
     T = 16 * args.chunks
     pred = w.RNNPredictor(V, P, P, 0.1, H, L).to(dev).eval()
     joint = w.TransducerJoint(V, E, P, J).to(dev).eval()
@@ -222,7 +222,7 @@ def bench_beam(args):
     import wenet_celoss_amd as w
     dev = torch.device("cuda:0")
     torch.manual_seed(6)
-    V, E, P, J, H, L, B, T, beam = 5000, 256, 256, 512, 256, 2, 16, args.T if args.T != 1000 else 1500, 8
+    V, E, P, J, H, L, B, T, beam = 5000, 256, 256, 512, 256, 2, args.B if args.B != 32 else 16, args.T if args.T != 1000 else 1500, 8
     pred = w.RNNPredictor(V, P, P, 0.1, H, L).to(dev).eval()
     joint = w.TransducerJoint(V, E, P, J).to(dev).eval()
     ctc = w.CTC(V, E).to(dev).eval()
@@ -300,6 +300,7 @@ if __name__ == "__main__":
     ap.add_argument("--V", type=int, default=5000)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--dw", action="store_true")
+    ap.add_argument("--streams", type=int, default=64, help="greedy: independent streams decoded together")
     ap.add_argument("--tile", type=int, default=0, help="lane-GEMM tile policy of the decoders (wr_tune_set key 6)")
     a = ap.parse_args()
     if a.tile:

@@ -51,6 +51,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kMaxLayers = WR_MAX_LSTM_LAYERS;
+constexpr int kMaxLanes = 1024;      // streams (greedy) or utterances x beam decoded together
 constexpr int kMaxBeam = 16;
 constexpr int kMaxLook = 4;          // greedy look-ahead: encoder frames evaluated per micro-step against one predictor state
 constexpr int kStepsPerGraph = 16;
@@ -1191,7 +1192,8 @@ extern "C" int wr_decoder_create(const wr_transducer_weights *w, int max_lanes, 
 {
     if (int rc = check_weights(w)) return rc;
     WR_REQUIRE(out && workspace_d, WR_EINVAL, "decoder_create: null pointer argument");
-    WR_REQUIRE(max_lanes > 0 && max_lanes <= 128, WR_EUNSUPPORTED, "decoder_create: max_lanes=%d (1..128)", max_lanes);
+    WR_REQUIRE(max_lanes > 0 && max_lanes <= kMaxLanes, WR_EUNSUPPORTED, "decoder_create: max_lanes=%d (1..%d)", max_lanes,
+               kMaxLanes);
     WR_REQUIRE(max_utt > 0 && max_utt <= max_lanes && Tmax > 0 && max_hyp >= 0, WR_EINVAL, "decoder_create: bad sizes");
     if (max_beam <= 0) max_beam = 1;
     WR_REQUIRE(max_beam <= kMaxBeam, WR_EUNSUPPORTED, "decoder_create: beam %d exceeds %d", max_beam, kMaxBeam);
@@ -1404,6 +1406,8 @@ int greedy_run(wr_decoder *h, const float *enc_out_d, const int32_t *enc_lens_d,
             prev_blank = h->h_active[1]; prev_emit = h->h_active[2];
             const float share = (nb + ne) > 0 ? (float)nb / (float)(nb + ne) : 0.f;
             look = share >= 0.75f ? 4 : share >= 0.62f ? 2 : 1;
+            // beyond ~256 joiner rows a micro-step is matrix-core bound and extra frames are no longer free
+            while (look > 1 && look * N > 256) look >>= 1;
         }
     }
     leave(h, caller);
