@@ -170,7 +170,7 @@ int wr_joint_bwd_dz(const float *gout_d /* [B,T,U1,V] */, const float *ep_d, con
  *               their scale) of the fp32 result, at several times the rate of the exact-fp32 MFMA;
  *   terms = 1:  a_hi*b_hi only: the AMP path (the reference under --use_amp, executor.py:91, runs ffn_out in
  *               fp16 with fp32 accumulation).
- * out_d has out_dtype (WR_F32 / WR_F16 / WR_BF16).  J even, at most 512. */
+ * out_d has out_dtype (WR_F32 / WR_F16 / WR_BF16).  J a multiple of 4, at most 512 (as the exact entry points). */
 size_t wr_joint_split_workspace_bytes(int J, int V);
 
 int wr_joint_fwd_split(const float *ep_d, const float *pp_d, const float *w_out_d, const float *b_out_d,

@@ -124,6 +124,9 @@ def test_unsupported_configuration_raises():
     (3, 11, 7, 64, 64, 512, 517),     # the shipped join_dim; odd V
     (2, 13, 4, 8, 8, 36, 64),         # J not a multiple of 64 (zero-padded k depth), one column pair
     (1, 40, 9, 16, 16, 512, 5000),    # the shipped vocabulary: 79 column pairs over 4 waves
+    (1, 1, 1, 4, 4, 4, 32),           # a single lattice cell, the smallest join_dim
+    (1, 3, 2, 8, 8, 508, 36),         # join_dim just under the limit
+    (2, 5, 3, 8, 8, 20, 4100),        # 65 column pairs: an odd last round
 ])
 def test_split_forward_parity_float64(precision, tol, B, T, U1, E, P, J, V):
     g = torch.Generator().manual_seed(B * 100 + T + J + V)

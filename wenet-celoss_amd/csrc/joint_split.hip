@@ -877,7 +877,8 @@ int split_check(int B, int T, int U1, int J, int V, int terms, int out_dtype)
 {
     WR_REQUIRE(B > 0 && T > 0 && U1 > 0 && J > 0 && V > 0, WR_EINVAL,
                "joint_split: B, T, U1, J, V must be positive (got %d,%d,%d,%d,%d)", B, T, U1, J, V);
-    WR_REQUIRE(J % 2 == 0 && J <= 512, WR_EUNSUPPORTED, "joint_split: join_dim=%d not supported (even, at most 512)", J);
+    WR_REQUIRE(J % 4 == 0 && J <= 512, WR_EUNSUPPORTED,
+               "joint_split: join_dim=%d not supported (must be a multiple of 4, at most 512)", J);
     WR_REQUIRE(terms == 1 || terms == 3, WR_EINVAL, "joint_split: terms must be 1 (bf16) or 3 (split fp32), got %d", terms);
     WR_REQUIRE(out_dtype >= 0 && out_dtype <= 2, WR_EINVAL, "joint_split: bad output dtype code %d", out_dtype);
     WR_REQUIRE(((long)B * T * U1 + kSM - 1) / kSM < (1L << 31), WR_EUNSUPPORTED, "joint_split: too many lattice cells");
