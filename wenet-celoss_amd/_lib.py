@@ -53,10 +53,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
     (hipcc cross-compiles without a GPU)."""
     if not force and not is_stale():
         return LIB_PATH
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
     build_dir = os.path.join(_PKG, "build")
     os.makedirs(build_dir, exist_ok=True)
+    # one builder at a time (several ranks of a torch.distributed launch may find the library stale together)
+    import fcntl
+    with open(os.path.join(build_dir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not is_stale():
+            return LIB_PATH
+        return _build_locked(build_dir, verbose)
+
+
+def _build_locked(build_dir: str, verbose: bool) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + _INCLUDE, "-I" + _CSRC,
              "-Wall", "-Wno-unused-function"]
     procs = []
