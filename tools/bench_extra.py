@@ -142,6 +142,45 @@ def bench_ctc(args):
                       "cpu_utt_per_s": round(B / cpu_ms * 1e3, 1), "cpu_threads": torch.get_num_threads()}), flush=True)
 
 
+def bench_ctcdec(args):
+    """CTC decode modes and forced alignment from the ctc_lo output on: B=16, T=1500, V=5000."""
+    import time
+    import wenet_celoss_amd as wc
+    from oracle import decode_oracle as do
+    dev = torch.device("cuda:0")
+    torch.manual_seed(7)
+    B, T, V, S = (args.B if args.B != 32 else 16), (args.T if args.T != 1000 else 1500), 5000, 150
+    x = torch.randn(B, T, V, device=dev) * 3
+    x[..., 0] += 14.0                                  # blank-heavy, like a trained CTC head (about one label per 12 frames)
+    lens = torch.full((B,), T)
+    y = torch.randint(1, V, (B, S))
+
+    def timed(fn, n):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n, r
+
+    dt, (hyps, _) = timed(lambda: wc.ctc_greedy_search(x, lens), args.steps)
+    print(json.dumps({"what": "ctc_greedy_search", "B": B, "T": T, "V": V, "ms_per_call": round(dt * 1e3, 3),
+                      "utt_per_s": round(B / dt, 1), "frames_per_s": round(B * T / dt), "tokens": sum(len(h) for h in hyps)}), flush=True)
+    dt, res = timed(lambda: wc.ctc_prefix_beam_search(x, lens, 10), args.steps)
+    print(json.dumps({"what": "ctc_prefix_beam_search", "beam": 10, "B": B, "T": T, "V": V, "ms_per_call": round(dt * 1e3, 3),
+                      "utt_per_s": round(B / dt, 1), "frames_per_s": round(B * T / dt), "best_len": len(res[0][0][0])}), flush=True)
+    dt, ali = timed(lambda: wc.forced_align_batch(x, y, lens, torch.full((B,), S)), args.steps)
+    print(json.dumps({"what": "ctc_forced_align", "B": B, "T": T, "S": S, "ms_per_call": round(dt * 1e3, 3),
+                      "utt_per_s": round(B / dt, 1), "frames_per_s": round(B * T / dt)}), flush=True)
+    # CPU: the numpy restatement of the reference's prefix beam search on one utterance of 200 frames
+    lp = do.log_softmax(x[0, :200].cpu().numpy())
+    t0 = time.perf_counter()
+    ref = do.ctc_prefix_beam_search(lp, 200, 10)
+    cdt = time.perf_counter() - t0
+    print(json.dumps({"what": "ctc_prefix_beam_search_cpu_oracle", "frames": 200, "s": round(cdt, 3),
+                      "frames_per_s": round(200 / cdt)}), flush=True)
+
+
 def bench_greedy(args):
     """BASELINE config 3: B=64 streams, chunks of 16 encoder frames, V=5000, LSTM 2x256, J=512, n_steps=64."""
     import time
@@ -292,7 +331,7 @@ def bench_step(args):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["joint", "ctc", "greedy", "beam", "step"])
+    ap.add_argument("what", choices=["joint", "ctc", "ctcdec", "greedy", "beam", "step"])
     ap.add_argument("--chunks", type=int, default=4)
     ap.add_argument("--B", type=int, default=32)
     ap.add_argument("--T", type=int, default=1000)
@@ -306,4 +345,4 @@ if __name__ == "__main__":
     if a.tile:
         from wenet_celoss_amd import _lib
         _lib.load().wr_tune_set(6, a.tile)
-    {"joint": bench_joint, "ctc": bench_ctc, "greedy": bench_greedy, "beam": bench_beam, "step": bench_step}[a.what](a)
+    {"joint": bench_joint, "ctc": bench_ctc, "greedy": bench_greedy, "beam": bench_beam, "step": bench_step, "ctcdec": bench_ctcdec}[a.what](a)

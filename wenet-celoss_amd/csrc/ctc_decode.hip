@@ -13,7 +13,8 @@
 //   ctc_frame_topk_kernel     one workgroup per frame: log-softmax row in LDS, top-`beam` (value desc, index asc)
 //   ctc_prefix_beam_kernel    one workgroup per utterance, all T frames inside one launch: the prefix
 //                             dictionary (blank / non-blank ending scores in float64, log_add exactly as
-//                             wenet/utils/common.py:268-276), insertion-ordered, stable prune.
+//                             wenet/utils/common.py:268-276), insertion-ordered, stable prune -- one contribution
+//                             per thread, all-pairs steps in parallel (see the kernel).
 //                             Prefixes are compared by (length, 64-bit rolling hash) and verified token by token.
 #include "wr_common.hpp"
 
@@ -21,7 +22,6 @@ namespace wr {
 namespace {
 
 constexpr int kMaxCtcBeam = 16;
-constexpr int kMaxNext = kMaxCtcBeam * (kMaxCtcBeam + 1);
 
 struct CtcDecWs {
     size_t best_off, top_off, tkv_off, tki_off, seq_off, total;
@@ -147,6 +147,21 @@ __device__ __forceinline__ double py_log_add3(double a, double b, double c)
     return mx + log((exp(a - mx) + exp(b - mx)) + exp(c - mx));    // sum() adds left to right
 }
 
+// One workgroup per utterance, all T frames inside one launch.  Per frame the reference visits the (top-k symbol,
+// current prefix) pairs in order and adds each pair's contribution(s) to a dictionary keyed by the new prefix.  Here
+// every contribution is a SLOT (slot = 2 * (k * ncur + i) + j in the reference's visiting order; j = 1 only for the
+// "same symbol again" case, which feeds two keys), handled in parallel:
+//   A  a thread fills its slots: key (base prefix, appended token or -1), its length and rolling hash, the operation;
+//   B  all pairs of slots: equal keys (length + hash, verified token by token unless trivially equal) -> every slot
+//      learns the first slot with its key, its representative; representatives in slot order = the dictionary's
+//      insertion order;
+//   C  a representative applies its slots' operations in slot order (float64 log_add exactly as
+//      wenet/utils/common.py:268-276: the n-ary form sums left to right);
+//   D  score = log_add(pb, pnb); stable descending rank among representatives by counting over all pairs;
+//   E  the kept prefixes are copied into the other sequence buffer ((prefix, position) pairs in flight together).
+constexpr int kMaxSlots = 2 * kMaxCtcBeam * kMaxCtcBeam;
+enum CtcOp { kOpNone = 0, kOpPb3 = 1, kOpPnb2 = 2, kOpPnb3 = 3 };
+
 __global__ __launch_bounds__(256) void ctc_prefix_beam_kernel(
     const float *__restrict__ tkv, const int32_t *__restrict__ tki, const int32_t *__restrict__ lens, int T, int beam,
     int blank, int32_t *__restrict__ seqs /* [B][2][beam][T] */, int32_t *__restrict__ hyps /* [B][beam][T] */,
@@ -156,101 +171,162 @@ __global__ __launch_bounds__(256) void ctc_prefix_beam_kernel(
     __shared__ int c_len[kMaxCtcBeam], c_last[kMaxCtcBeam];
     __shared__ unsigned long long c_hash[kMaxCtcBeam];
     __shared__ double c_pb[kMaxCtcBeam], c_pnb[kMaxCtcBeam];
-    // next_hyps in insertion order: key = (base prefix, appended token or -1)
-    __shared__ int n_base[kMaxNext], n_tok[kMaxNext], n_len[kMaxNext], order[kMaxNext];
-    __shared__ unsigned long long n_hash[kMaxNext];
-    __shared__ double n_pb[kMaxNext], n_pnb[kMaxNext], n_score[kMaxNext];
-    __shared__ int s_ncur, s_nnext, s_sel;
+    // slots of this frame
+    __shared__ int s_base[kMaxSlots], s_tok[kMaxSlots], s_len[kMaxSlots], s_op[kMaxSlots], s_rep[kMaxSlots], s_rank[kMaxSlots];
+    __shared__ unsigned long long s_hash[kMaxSlots];
+    __shared__ double s_a[kMaxSlots], s_b[kMaxSlots], r_pb[kMaxSlots], r_pnb[kMaxSlots], r_score[kMaxSlots];
+    __shared__ int order[kMaxCtcBeam];
+    __shared__ int s_nrep, s_wtot[4];
+    // next beam (staged so that the current one stays readable while it is built)
+    __shared__ int t_len[kMaxCtcBeam], t_last[kMaxCtcBeam], t_base[kMaxCtcBeam], t_tok[kMaxCtcBeam];
+    __shared__ unsigned long long t_hash[kMaxCtcBeam];
+    __shared__ double t_pb[kMaxCtcBeam], t_pnb[kMaxCtcBeam];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int len = lens[b] < T ? lens[b] : T;
     const double NINF = -__builtin_huge_val();
     int32_t *sq = seqs + (size_t)b * 2 * beam * T;
-    if (tid == 0) {
-        s_ncur = 1; s_sel = 0;
-        c_len[0] = 0; c_last[0] = -1; c_hash[0] = 1469598103934665603ULL; c_pb[0] = 0.0; c_pnb[0] = NINF;
-    }
+    int ncur = 1, sel = 0;
+    if (tid == 0) { c_len[0] = 0; c_last[0] = -1; c_hash[0] = 1469598103934665603ULL; c_pb[0] = 0.0; c_pnb[0] = NINF; }
     __syncthreads();
     for (int t = 0; t < len; ++t) {
-        const int32_t *cur = sq + (size_t)s_sel * beam * T;
-        int32_t *nxt = sq + (size_t)(1 - s_sel) * beam * T;
-        if (tid == 0) {
-            int nn = 0;
-            const int ncur = s_ncur;
-            auto seq_elem = [&](int base, int tok, int q) -> int {      // q-th token of prefix (base [+ tok])
-                return (q < c_len[base]) ? cur[(size_t)base * T + q] : tok;
-            };
-            auto find_or_insert = [&](int base, int tok) -> int {
-                const int ln = c_len[base] + (tok >= 0 ? 1 : 0);
-                const unsigned long long hs = (tok >= 0) ? c_hash[base] * 1099511628211ULL + (unsigned long long)(tok + 1)
-                                                         : c_hash[base];
-                for (int e = 0; e < nn; ++e) {
-                    if (n_len[e] != ln || n_hash[e] != hs) continue;
-                    bool same = true;
-                    if (!(n_base[e] == base && n_tok[e] == tok))
-                        for (int q = ln - 1; q >= 0 && same; --q) same = seq_elem(base, tok, q) == seq_elem(n_base[e], n_tok[e], q);
-                    if (same) return e;
-                }
-                n_base[nn] = base; n_tok[nn] = tok; n_len[nn] = ln; n_hash[nn] = hs; n_pb[nn] = NINF; n_pnb[nn] = NINF;
-                return nn++;
-            };
-            const size_t row = ((size_t)b * T + t) * beam;
-            for (int k = 0; k < beam; ++k) {
-                const int s = tki[row + k];
-                const double ps = (double)tkv[row + k];               // logp[s].item()
-                for (int i = 0; i < ncur; ++i) {
-                    const double pb = c_pb[i], pnb = c_pnb[i];
-                    if (s == blank) {
-                        const int e = find_or_insert(i, -1);
-                        n_pb[e] = py_log_add3(n_pb[e], pb + ps, pnb + ps);
-                    } else if (s == c_last[i]) {
-                        const int e = find_or_insert(i, -1);             // *ss -> *s
-                        n_pnb[e] = py_log_add2(n_pnb[e], pnb + ps);
-                        const int f = find_or_insert(i, s);              // *s-s -> *ss
-                        n_pnb[f] = py_log_add2(n_pnb[f], pb + ps);
-                    } else {
-                        const int f = find_or_insert(i, s);
-                        n_pnb[f] = py_log_add3(n_pnb[f], pb + ps, pnb + ps);
+        const int32_t *__restrict__ cur = sq + (size_t)sel * beam * T;
+        int32_t *__restrict__ nxt = sq + (size_t)(1 - sel) * beam * T;
+        const size_t row = ((size_t)b * T + t) * beam;
+        // ---- A: slots, written densely in the reference's visiting order (one (symbol, prefix) pair per thread) ----
+        const int C = beam * ncur;                                    // <= 256
+        int tok0 = -1, op0 = kOpNone, tok1 = -1, op1 = kOpNone, pi = 0;
+        double a0 = NINF, b0 = NINF, a1 = NINF;
+        if (tid < C) {
+            const int k = tid / ncur;
+            pi = tid - k * ncur;
+            const int sym = tki[row + k];
+            const double ps = (double)tkv[row + k];                   // logp[s].item()
+            const double pb = c_pb[pi], pnb = c_pnb[pi];
+            if (sym == blank) { op0 = kOpPb3; a0 = pb + ps; b0 = pnb + ps; }
+            else if (sym == c_last[pi]) {
+                op0 = kOpPnb2; a0 = pnb + ps;                          // *ss -> *s
+                tok1 = sym; op1 = kOpPnb2; a1 = pb + ps;               // *s-s -> *ss
+            } else { tok0 = sym; op0 = kOpPnb3; a0 = pb + ps; b0 = pnb + ps; }
+        }
+        const int lane = tid & 63, wave = tid >> 6;
+        const unsigned long long extra_mask = __ballot(op1 != kOpNone);
+        if (lane == 0) s_wtot[wave] = __popcll(extra_mask);
+        if (tid == 0) s_nrep = 0;
+        __syncthreads();
+        int dpos = tid + __popcll(extra_mask & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) dpos += s_wtot[w];
+        const int nslot = C + s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
+        if (tid < C) {
+            s_base[dpos] = pi; s_tok[dpos] = tok0; s_op[dpos] = op0; s_a[dpos] = a0; s_b[dpos] = b0;
+            s_len[dpos] = c_len[pi] + (tok0 >= 0 ? 1 : 0);
+            s_hash[dpos] = tok0 >= 0 ? c_hash[pi] * 1099511628211ULL + (unsigned long long)(tok0 + 1) : c_hash[pi];
+            s_rep[dpos] = dpos; s_rank[dpos] = 0;
+            if (op1 != kOpNone) {
+                const int d1 = dpos + 1;
+                s_base[d1] = pi; s_tok[d1] = tok1; s_op[d1] = op1; s_a[d1] = a1; s_b[d1] = NINF;
+                s_len[d1] = c_len[pi] + 1;
+                s_hash[d1] = c_hash[pi] * 1099511628211ULL + (unsigned long long)(tok1 + 1);
+                s_rep[d1] = d1; s_rank[d1] = 0;
+            }
+        }
+        __syncthreads();
+        // ---- B: representative = first slot with the same key (four threads per slot i, f < i) ----
+        for (int i = tid >> 2; i < nslot; i += 64) {
+            const int li_ = s_len[i];
+            const unsigned long long hi_ = s_hash[i];
+            for (int f = tid & 3; f < i; f += 4) {
+                if (s_len[f] != li_ || s_hash[f] != hi_) continue;
+                bool same = (s_base[f] == s_base[i] && s_tok[f] == s_tok[i]);
+                if (!same) {                                           // different spelling of (maybe) the same prefix
+                    const int bi = s_base[i], bf = s_base[f], ti = s_tok[i], tf = s_tok[f];
+                    const int li = c_len[bi], lf = c_len[bf];
+                    same = true;
+                    for (int q = li_ - 1; q >= 0 && same; --q) {
+                        const int x = q < li ? cur[(size_t)bi * T + q] : ti;
+                        const int y = q < lf ? cur[(size_t)bf * T + q] : tf;
+                        same = (x == y);
                     }
                 }
+                if (same) atomicMin(&s_rep[i], f);
             }
-            // sorted(..., key=log_add([pb, pnb]), reverse=True): stable
-            for (int e = 0; e < nn; ++e) { n_score[e] = py_log_add2(n_pb[e], n_pnb[e]); order[e] = e; }
-            for (int i = 1; i < nn; ++i) {
-                const int o = order[i];
-                int p = i - 1;
-                while (p >= 0 && n_score[order[p]] < n_score[o]) { order[p + 1] = order[p]; --p; }
-                order[p + 1] = o;
-            }
-            s_nnext = nn < beam ? nn : beam;
         }
         __syncthreads();
-        const int keep = s_nnext;
-        for (int e = 0; e < keep; ++e) {                                  // materialise the kept prefixes
-            const int f = order[e];
-            const int base = n_base[f], lb = c_len[base];
-            for (int q = tid; q < lb; q += 256) nxt[(size_t)e * T + q] = cur[(size_t)base * T + q];
-            if (tid == 0 && n_tok[f] >= 0 && lb < T) nxt[(size_t)e * T + lb] = n_tok[f];
+        // ---- C: a representative applies its slots' operations in slot order ----
+        for (int i = tid; i < nslot; i += 256) {
+            if (s_rep[i] != i) continue;
+            double pb = NINF, pnb = NINF;
+            for (int f = i; f < nslot; ++f) {
+                if (s_rep[f] != i) continue;
+                if (s_op[f] == kOpPb3) pb = py_log_add3(pb, s_a[f], s_b[f]);
+                else if (s_op[f] == kOpPnb2) pnb = py_log_add2(pnb, s_a[f]);
+                else pnb = py_log_add3(pnb, s_a[f], s_b[f]);
+            }
+            r_pb[i] = pb; r_pnb[i] = pnb;
+            r_score[i] = py_log_add2(pb, pnb);
+            atomicAdd(&s_nrep, 1);
         }
         __syncthreads();
-        if (tid == 0) {
-            int t_len[kMaxCtcBeam], t_last[kMaxCtcBeam];
-            unsigned long long t_hash[kMaxCtcBeam];
-            double t_pb[kMaxCtcBeam], t_pnb[kMaxCtcBeam];
-            for (int e = 0; e < keep; ++e) {
-                const int f = order[e];
-                t_len[e] = n_len[f]; t_hash[e] = n_hash[f]; t_pb[e] = n_pb[f]; t_pnb[e] = n_pnb[f];
-                t_last[e] = (n_tok[f] >= 0) ? n_tok[f] : c_last[n_base[f]];
+        // ---- D: stable descending rank among representatives (sorted(..., reverse=True) keeps insertion order on ties) ----
+        for (int i = tid >> 2; i < nslot; i += 64) {
+            if (s_rep[i] != i) continue;
+            const double me = r_score[i];
+            int cnt = 0;
+            for (int f = tid & 3; f < nslot; f += 4) {
+                if (s_rep[f] != f) continue;
+                const double ot = r_score[f];
+                cnt += (ot > me || (ot == me && f < i)) ? 1 : 0;
             }
-            for (int e = 0; e < keep; ++e) {
-                c_len[e] = t_len[e]; c_hash[e] = t_hash[e]; c_pb[e] = t_pb[e]; c_pnb[e] = t_pnb[e]; c_last[e] = t_last[e];
-            }
-            s_ncur = keep;
-            s_sel = 1 - s_sel;
+            if (cnt) atomicAdd(&s_rank[i], cnt);
         }
+        __syncthreads();
+        const int keep = s_nrep < beam ? s_nrep : beam;
+        for (int i = tid; i < nslot; i += 256)
+            if (s_rep[i] == i && s_rank[i] < beam) order[s_rank[i]] = i;
+        __syncthreads();
+        // ---- E: the next beam ----
+        if (tid < keep) {
+            const int f = order[tid];
+            t_base[tid] = s_base[f]; t_tok[tid] = s_tok[f];
+            t_len[tid] = s_len[f]; t_hash[tid] = s_hash[f]; t_pb[tid] = r_pb[f]; t_pnb[tid] = r_pnb[f];
+            t_last[tid] = s_tok[f] >= 0 ? s_tok[f] : c_last[s_base[f]];
+        }
+        __syncthreads();
+        {
+            int maxlb = 0;
+            for (int e = 0; e < keep; ++e) maxlb = c_len[t_base[e]] > maxlb ? c_len[t_base[e]] : maxlb;
+            constexpr int UN = 4;
+            for (int i0 = 0; i0 < keep * maxlb; i0 += 256 * UN) {
+                int val[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int i = i0 + u * 256 + tid;
+                    const int e = i / maxlb, q = i - e * maxlb;
+                    const bool in = e < keep && q < c_len[t_base[e < keep ? e : 0]];
+                    val[u] = in ? cur[(size_t)t_base[e] * T + q] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int i = i0 + u * 256 + tid;
+                    const int e = i / maxlb, q = i - e * maxlb;
+                    if (e < keep && q < c_len[t_base[e]]) nxt[(size_t)e * T + q] = val[u];
+                }
+            }
+            if (tid < keep) {
+                const int lb = c_len[t_base[tid]];
+                if (t_tok[tid] >= 0 && lb < T) nxt[(size_t)tid * T + lb] = t_tok[tid];
+            }
+        }
+        __syncthreads();
+        if (tid < keep) {
+            c_len[tid] = t_len[tid]; c_hash[tid] = t_hash[tid]; c_pb[tid] = t_pb[tid]; c_pnb[tid] = t_pnb[tid];
+            c_last[tid] = t_last[tid];
+        }
+        ncur = keep;
+        sel = 1 - sel;
         __syncthreads();
     }
-    const int32_t *fin = sq + (size_t)s_sel * beam * T;
-    const int n = s_ncur;
+    const int32_t *fin = sq + (size_t)sel * beam * T;
+    const int n = ncur;
     for (int i = tid; i < beam * T; i += 256) {
         const int e = i / T, q = i % T;
         hyps[((size_t)b * beam + e) * T + q] = (e < n && q < c_len[e]) ? fin[(size_t)e * T + q] : -1;
