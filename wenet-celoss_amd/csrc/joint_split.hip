@@ -260,19 +260,29 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
         const int r = ci / cpr;
         const int pr = r * kSWaves + wave;
         const int ct0 = (pair0 + pr) * kSCT;
+        // interior tiles (all 64 cells and all 64 columns valid: everything but the matrix edges) store without
+        // per-element guards, so the stores issue back to back
+        const bool full = m0 + kSM <= M && pr < npairs && (ct0 + kSCT) * 32 <= V;
 #pragma unroll
         for (int c = 0; c < kSCT; ++c) {
             const int col = (ct0 + c) * 32 + l31;
             const bool colin = pr < npairs && col < V;
             const float bv = colin ? bias_s[(pr * kSCT + c) * 32 + l31] : 0.f;
+            OutT *__restrict__ ocol = out + (size_t)m0 * V + (colin ? col : 0);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
+                if (full) {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int row = 32 * rt + (q & 3) + 8 * (q >> 2) + 4 * half;   // C/D layout of the 32x32 MFMA
-                    const long m = m0 + row;
-                    // streaming store: the logits must not push the W slab out of L2
-                    if (m < M && colin) __builtin_nontemporal_store(to_out<OutT>(acc[rt][c][q] + bv), out + (size_t)m * V + col);
+                    for (int q = 0; q < 16; ++q) {
+                        const int row = 32 * rt + (q & 3) + 8 * (q >> 2) + 4 * half;   // C/D layout of the 32x32 MFMA
+                        __builtin_nontemporal_store(to_out<OutT>(acc[rt][c][q] + bv), ocol + (size_t)row * V);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int row = 32 * rt + (q & 3) + 8 * (q >> 2) + 4 * half;
+                        if (m0 + row < M && colin) __builtin_nontemporal_store(to_out<OutT>(acc[rt][c][q] + bv), ocol + (size_t)row * V);
+                    }
                 }
                 acc[rt][c] = (f32x16){0};
             }
