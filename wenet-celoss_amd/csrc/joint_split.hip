@@ -693,11 +693,12 @@ __global__ __launch_bounds__(256) void joint_bwd_dz_split128_kernel(
 // dW[v, j] = sum_m dY[m, v] * H[m, j],  db[v] = sum_m dY[m, v]     (M = B*T*U1 lattice cells, padded cells excluded)
 // A reduction over millions of cells into a V x J matrix.  One workgroup (4 waves = 2 v-halves x 2 j-halves, one
 // per SIMD) owns a 256 x 256 block of dW and one of `parts` contiguous cell ranges; a wave holds 4 x 4 accumulator
-// tiles (256 registers).  Both operands are cell-major as stored, so a 16-cell step of each ([16][256] fp32) is
-// staged through LDS with coalesced 16-byte loads (three stages, registers two steps ahead); a lane then reads, for
-// its 8 cells, the 4 consecutive columns 4*l31 .. 4*l31+3 of its half (8 ds_read_b128) and treats them as rows of four
-// interleaved MFMA tiles (tile t holds columns 4*i + t) -- the contraction index stays along the fragment, no
-// transposition anywhere.  Values are split to bf16 hi / lo in registers (same three-term product as the forward).
+// tiles (256 registers).  Both operands are cell-major as stored: a staging thread loads an 8-cell x 4-column patch
+// of dY (waves 0-1) or H (waves 2-3) with coalesced 16-byte loads, masks it, splits it to bf16 hi / lo ONCE for
+// the whole workgroup and writes four ready-made MFMA fragments per image into LDS (three stages; global loads
+// run two steps ahead).  The four columns of a patch become rows of four interleaved MFMA tiles (tile t holds
+// columns 4*i + t), so the contraction index stays along the fragment and nothing is transposed; in the k-loop a
+// lane only reads its fragments (16 ds_read_b128 per 48 MFMAs).
 // The `parts` partial blocks are summed by a second, deterministic kernel (no float atomics).
 constexpr int kWB = 256;         // dW block edge (v and j) per workgroup
 constexpr int kWStages = 3;
@@ -721,7 +722,10 @@ __global__ __launch_bounds__(256) void joint_bwd_dw_split_kernel(
     const unsigned char *__restrict__ mask /* [M] or null */, long M, int V, int J, int n_vs, int n_js, long rows_per_part,
     float *__restrict__ part_dw /* [parts][V][J] */, float *__restrict__ part_db /* [parts][V] */)
 {
-    extern __shared__ __attribute__((aligned(16))) float stage[];     // [kWStages][2 operands][16][kWB]
+    // stage layout (16-byte units): [kWStages][operand 2][hi/lo 2][cell group 2][column-in-patch 4][64 patches] --
+    // ready-made MFMA fragments: the staging thread converts its 8-cell x 4-column patch once for every wave
+    extern __shared__ __attribute__((aligned(16))) u32x4 stage[];
+    constexpr int kStageUnits = 2 * 2 * 2 * 4 * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int vh = wave >> 1, jh = wave & 1;
@@ -733,36 +737,40 @@ __global__ __launch_bounds__(256) void joint_bwd_dw_split_kernel(
     const long me = mb + rows_per_part < M ? mb + rows_per_part : M;
     const int steps = me > mb ? (int)((me - mb + 15) / 16) : 0;
 
-    // staging map: thread -> float4 column c4 of the 256-wide block, rows r4 + 4*i of the 16-cell step
-    const int c4 = tid & 63, r4 = tid >> 6;
-    const bool a_in = v0 + 4 * c4 < V, b_in = j0 + 4 * c4 < J;       // V, J multiples of 4: a float4 is wholly in or out
-    const float *__restrict__ ga = gout + (a_in ? v0 + 4 * c4 : 0);
-    const float *__restrict__ gb = h + (b_in ? j0 + 4 * c4 : 0);
-    struct Regs { f32x4 a[4], b[4]; };
+    // staging map: thread -> operand (waves 0-1: dY, 2-3: H), cell group mg (8 cells), float4 column c4
+    const int c4 = tid & 63, mg = (tid >> 6) & 1, op = tid >> 7;
+    const bool col_in = op == 0 ? (v0 + 4 * c4 < V) : (j0 + 4 * c4 < J);   // V, J multiples of 4: wholly in or out
+    const int ld = op == 0 ? V : J;
+    const float *__restrict__ gsrc = (op == 0 ? gout + v0 : h + j0) + (col_in ? 4 * c4 : 0);
+    struct Regs { f32x4 x[8]; };
     auto gload = [&](int s, Regs &z) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            long m = mb + 16L * s + r4 + 4 * i;
+        for (int e = 0; e < 8; ++e) {
+            long m = mb + 16L * s + 8 * mg + e;
             m = m < me ? m : me - 1;
-            z.a[i] = *reinterpret_cast<const f32x4 *>(ga + (size_t)m * V);
-            z.b[i] = *reinterpret_cast<const f32x4 *>(gb + (size_t)m * J);
+            z.x[e] = *reinterpret_cast<const f32x4 *>(gsrc + (size_t)m * ld);
         }
     };
     f32x4 dbacc = (f32x4){0, 0, 0, 0};
-    auto lwrite = [&](int s, const Regs &z) {                        // masks, accumulates db, stores the stage
-        float *sa = stage + (size_t)(s % kWStages) * 2 * 16 * kWB;
-        float *sb = sa + 16 * kWB;
+    auto lwrite = [&](int s, Regs &z) {                              // masks, accumulates db, converts, stores the fragments
+        const f32x4 zero = (f32x4){0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long m = mb + 16L * s + r4 + 4 * i;
-            bool on = m < me;
+        for (int e = 0; e < 8; ++e) {
+            const long m = mb + 16L * s + 8 * mg + e;
+            bool on = m < me && col_in;
             if (on && mask != nullptr) on = mask[m] != 0;
-            const f32x4 zero = (f32x4){0, 0, 0, 0};
-            const f32x4 av = (on && a_in) ? z.a[i] : zero;
-            const f32x4 bv = (on && b_in) ? z.b[i] : zero;
-            dbacc += av;
-            *reinterpret_cast<f32x4 *>(sa + (r4 + 4 * i) * kWB + 4 * c4) = av;
-            *reinterpret_cast<f32x4 *>(sb + (r4 + 4 * i) * kWB + 4 * c4) = bv;
+            z.x[e] = on ? z.x[e] : zero;
+            if (op == 0) dbacc += z.x[e];
+        }
+        u32x4 *st = stage + (size_t)(s % kWStages) * kStageUnits + (size_t)(op * 2) * 2 * 4 * 64 + (size_t)mg * 4 * 64 + c4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            bf16x8 hi, lo;
+            const f32x4 lo4 = (f32x4){z.x[0][t], z.x[1][t], z.x[2][t], z.x[3][t]};
+            const f32x4 hi4 = (f32x4){z.x[4][t], z.x[5][t], z.x[6][t], z.x[7][t]};
+            split8(lo4, hi4, hi, lo, TERMS == 3);
+            st[t * 64] = __builtin_bit_cast(u32x4, hi);
+            if (TERMS == 3) st[2 * 4 * 64 + t * 64] = __builtin_bit_cast(u32x4, lo);
         }
     };
 
@@ -773,27 +781,20 @@ __global__ __launch_bounds__(256) void joint_bwd_dw_split_kernel(
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x16){0};
 
     auto compute = [&](int s) {
-        const float *sa = stage + (size_t)(s % kWStages) * 2 * 16 * kWB + (8 * half) * kWB + 128 * vh + 4 * l31;
-        const float *sb = stage + (size_t)(s % kWStages) * 2 * 16 * kWB + 16 * kWB + (8 * half) * kWB + 128 * jh + 4 * l31;
-        f32x4 pa[8], pb[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            pa[e] = *reinterpret_cast<const f32x4 *>(sa + e * kWB);
-            pb[e] = *reinterpret_cast<const f32x4 *>(sb + e * kWB);
-        }
+        // fragment of column-in-patch t for this lane: [operand][hi/lo][half][t][32 * (vh or jh) + l31]
+        const u32x4 *sa = stage + (size_t)(s % kWStages) * kStageUnits + (size_t)half * 4 * 64 + 32 * vh + l31;
+        const u32x4 *sb = stage + (size_t)(s % kWStages) * kStageUnits + (size_t)2 * 2 * 4 * 64 + (size_t)half * 4 * 64 + 32 * jh + l31;
         bf16x8 ah[4], al[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const f32x4 lo4 = (f32x4){pa[0][t], pa[1][t], pa[2][t], pa[3][t]};
-            const f32x4 hi4 = (f32x4){pa[4][t], pa[5][t], pa[6][t], pa[7][t]};
-            split8(lo4, hi4, ah[t], al[t], TERMS == 3);
+            ah[t] = __builtin_bit_cast(bf16x8, sa[t * 64]);
+            if (TERMS == 3) al[t] = __builtin_bit_cast(bf16x8, sa[2 * 4 * 64 + t * 64]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            bf16x8 bh, bl;
-            const f32x4 lo4 = (f32x4){pb[0][u], pb[1][u], pb[2][u], pb[3][u]};
-            const f32x4 hi4 = (f32x4){pb[4][u], pb[5][u], pb[6][u], pb[7][u]};
-            split8(lo4, hi4, bh, bl, TERMS == 3);
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, sb[u * 64]);
+            bf16x8 bl;
+            if (TERMS == 3) bl = __builtin_bit_cast(bf16x8, sb[2 * 4 * 64 + u * 64]);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if (TERMS == 3) {
@@ -847,14 +848,14 @@ __global__ __launch_bounds__(256) void joint_bwd_dw_split_kernel(
                 *reinterpret_cast<f32x4 *>(pw + (size_t)v * J + j) = o;
             }
         }
-    // db: the four row groups of every float4 column -> one sum (j-block 0 only)
+    // db: the two cell groups of every float4 column -> one sum (j-block 0 only; the dY patches sit in waves 0-1)
     if (js == 0) {
         __syncthreads();
         f32x4 *red = reinterpret_cast<f32x4 *>(stage);
-        red[tid] = dbacc;
+        if (op == 0) red[tid] = dbacc;
         __syncthreads();
-        if (tid < 64 && a_in) {
-            const f32x4 t4 = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
+        if (tid < 64 && col_in) {
+            const f32x4 t4 = red[tid] + red[tid + 64];
             *reinterpret_cast<f32x4 *>(part_db + (size_t)part * V + v0 + 4 * tid) = t4;
         }
     }
@@ -1051,7 +1052,7 @@ extern "C" int wr_joint_bwd_dw_split(const float *gout_d, const float *h_d, cons
     const int n_vs = (V + kWB - 1) / kWB, n_js = (J + kWB - 1) / kWB;
     long rows_per_part = (M + parts - 1) / parts;
     rows_per_part = (rows_per_part + 15) / 16 * 16;
-    const size_t lds = (size_t)kWStages * 2 * 16 * kWB * sizeof(float);
+    const size_t lds = (size_t)kWStages * 2 * 2 * 2 * 4 * 64 * 16;   // three stages of ready-made fragments
 #define WR_LAUNCH_DW(TERMS)                                                                                            \
     do {                                                                                                              \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_bwd_dw_split_kernel<TERMS>),                     \
