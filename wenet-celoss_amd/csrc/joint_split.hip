@@ -717,7 +717,7 @@ __global__ void cell_mask_kernel(const int32_t *__restrict__ llens, const int32_
 }
 
 template <int TERMS>
-__global__ __launch_bounds__(256) void joint_bwd_dw_split_kernel(
+__global__ __launch_bounds__(512) void joint_bwd_dw_split_kernel(
     const float *__restrict__ gout /* [M, V] */, const float *__restrict__ h /* [M, J] */,
     const unsigned char *__restrict__ mask /* [M] or null */, long M, int V, int J, int n_vs, int n_js, long rows_per_part,
     float *__restrict__ part_dw /* [parts][V][J] */, float *__restrict__ part_db /* [parts][V] */)
@@ -728,7 +728,10 @@ __global__ __launch_bounds__(256) void joint_bwd_dw_split_kernel(
     constexpr int kStageUnits = 2 * 2 * 2 * 4 * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int vh = wave >> 1, jh = wave & 1;
+    // eight waves, two per SIMD (waves w and w+4 share one): wave = (v-half, j-quarter); the first four also stage,
+    // so every SIMD holds a staging wave and a compute-only wave whose MFMAs fill the staging gaps
+    const int vh = wave >> 2, jq = wave & 3;
+    const bool stager = tid < 256;
     const int tiles = n_vs * n_js;
     const int part = blockIdx.x / tiles, tile = blockIdx.x - part * tiles;
     const int vs = tile / n_js, js = tile - vs * n_js;
@@ -738,12 +741,13 @@ __global__ __launch_bounds__(256) void joint_bwd_dw_split_kernel(
     const int steps = me > mb ? (int)((me - mb + 15) / 16) : 0;
 
     // staging map: thread -> operand (waves 0-1: dY, 2-3: H), cell group mg (8 cells), float4 column c4
-    const int c4 = tid & 63, mg = (tid >> 6) & 1, op = tid >> 7;
+    const int c4 = tid & 63, mg = (tid >> 6) & 1, op = (tid >> 7) & 1;
     const bool col_in = op == 0 ? (v0 + 4 * c4 < V) : (j0 + 4 * c4 < J);   // V, J multiples of 4: wholly in or out
     const int ld = op == 0 ? V : J;
     const float *__restrict__ gsrc = (op == 0 ? gout + v0 : h + j0) + (col_in ? 4 * c4 : 0);
     struct Regs { f32x4 x[8]; };
     auto gload = [&](int s, Regs &z) {
+        if (!stager) return;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             long m = mb + 16L * s + 8 * mg + e;
@@ -753,6 +757,7 @@ __global__ __launch_bounds__(256) void joint_bwd_dw_split_kernel(
     };
     f32x4 dbacc = (f32x4){0, 0, 0, 0};
     auto lwrite = [&](int s, Regs &z) {                              // masks, accumulates db, converts, stores the fragments
+        if (!stager) return;
         const f32x4 zero = (f32x4){0, 0, 0, 0};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -774,16 +779,18 @@ __global__ __launch_bounds__(256) void joint_bwd_dw_split_kernel(
         }
     };
 
-    f32x16 acc[4][4];
+    f32x16 acc[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x16){0};
+        for (int b = 0; b < 2; ++b) acc[a][b] = (f32x16){0};
 
+    // B side: a wave covers 64 columns = 16 patches x 4; tile u takes patch columns 2u and 2u+1: lane l31 reads
+    // column-in-patch 2u + (l31 >> 4) of patch 16 jq + (l31 & 15)
+    const int bpatch = 16 * jq + (l31 & 15), bsub = l31 >> 4;
     auto compute = [&](int s) {
-        // fragment of column-in-patch t for this lane: [operand][hi/lo][half][t][32 * (vh or jh) + l31]
         const u32x4 *sa = stage + (size_t)(s % kWStages) * kStageUnits + (size_t)half * 4 * 64 + 32 * vh + l31;
-        const u32x4 *sb = stage + (size_t)(s % kWStages) * kStageUnits + (size_t)2 * 2 * 4 * 64 + (size_t)half * 4 * 64 + 32 * jh + l31;
+        const u32x4 *sb = stage + (size_t)(s % kWStages) * kStageUnits + (size_t)2 * 2 * 4 * 64 + (size_t)half * 4 * 64 + bpatch;
         bf16x8 ah[4], al[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -791,10 +798,10 @@ __global__ __launch_bounds__(256) void joint_bwd_dw_split_kernel(
             if (TERMS == 3) al[t] = __builtin_bit_cast(bf16x8, sa[2 * 4 * 64 + t * 64]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, sb[u * 64]);
+        for (int u = 0; u < 2; ++u) {
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, sb[(2 * u + bsub) * 64]);
             bf16x8 bl;
-            if (TERMS == 3) bl = __builtin_bit_cast(bf16x8, sb[2 * 4 * 64 + u * 64]);
+            if (TERMS == 3) bl = __builtin_bit_cast(bf16x8, sb[2 * 4 * 64 + (2 * u + bsub) * 64]);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if (TERMS == 3) {
@@ -833,7 +840,7 @@ __global__ __launch_bounds__(256) void joint_bwd_dw_split_kernel(
         }
     }
 
-    // partial block of dW: tile (t, u) element (row i, col c) is dW[v0 + 128 vh + 4 i + t][j0 + 128 jh + 4 c + u]
+    // partial block of dW: tile (t, u) element (row i, col c) is dW[v0 + 128 vh + 4 i + t][j0 + 4 (16 jq + (c & 15)) + 2 u + (c >> 4)]
     float *__restrict__ pw = part_dw + (size_t)part * V * J;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -842,10 +849,10 @@ __global__ __launch_bounds__(256) void joint_bwd_dw_split_kernel(
             const int i = (q & 3) + 8 * (q >> 2) + 4 * half;
             const int v = v0 + 128 * vh + 4 * i + t;
             if (v >= V) continue;
-            const int j = j0 + 128 * jh + 4 * l31;
-            if (j < J) {                                             // J % 4 == 0: the four u's are in together
-                const f32x4 o = (f32x4){acc[t][0][q], acc[t][1][q], acc[t][2][q], acc[t][3][q]};
-                *reinterpret_cast<f32x4 *>(pw + (size_t)v * J + j) = o;
+            const int j = j0 + 4 * bpatch + bsub;                    // + 2 u
+            if (j - bsub < J) {                                      // J % 4 == 0: a patch is wholly in or out
+                pw[(size_t)v * J + j] = acc[t][0][q];
+                pw[(size_t)v * J + j + 2] = acc[t][1][q];
             }
         }
     // db: the two cell groups of every float4 column -> one sum (j-block 0 only; the dY patches sit in waves 0-1)
@@ -1057,7 +1064,7 @@ extern "C" int wr_joint_bwd_dw_split(const float *gout_d, const float *h_d, cons
     do {                                                                                                              \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_bwd_dw_split_kernel<TERMS>),                     \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
-        hipLaunchKernelGGL(joint_bwd_dw_split_kernel<TERMS>, dim3(n_vs * n_js * parts), dim3(256), lds, st, gout_d, h_d, \
+        hipLaunchKernelGGL(joint_bwd_dw_split_kernel<TERMS>, dim3(n_vs * n_js * parts), dim3(512), lds, st, gout_d, h_d, \
                            mask, M, V, J, n_vs, n_js, rows_per_part, part_dw, part_db);                                \
     } while (0)
     if (terms == 3) WR_LAUNCH_DW(3); else WR_LAUNCH_DW(1);
