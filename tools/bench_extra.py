@@ -86,9 +86,12 @@ def bench_joint(args):
     ws2 = torch.empty(wsb2, dtype=torch.uint8, device=dev)
     dwt = torch.empty(V, J, device=dev); dbt = torch.empty(V, device=dev)
     kdw = lambda: _lib.check(lib.wr_joint_bwd_dw(P(out), P(h), None, None, B, T, U1, J, V, P(dwt), P(dbt), P(ws2), wsb2, st))
-    ms = timeit(kdw, args.steps)
-    print(json.dumps({"what": "joint_bwd_dw", "shape": [B, T, U1, J, V], "ms": round(ms, 3),
-                      "TFLOPs": round(flops / ms / 1e9, 2), "frac": round(flops / ms / 1e9 / 157.3, 4)}), flush=True)
+    for slabs in (1, 0):                               # knob 9: 1 = first tiling (128-row slabs), 0 = 256 x 256 blocks (default)
+        lib.wr_tune_set(9, slabs)
+        ms = timeit(kdw, args.steps)
+        print(json.dumps({"what": "joint_bwd_dw", "tiling": "slabs" if slabs else "blocks", "shape": [B, T, U1, J, V],
+                          "ms": round(ms, 3), "TFLOPs": round(flops / ms / 1e9, 2),
+                          "frac": round(flops / ms / 1e9 / 157.3, 4)}), flush=True)
     dw_ref, db_ref = dwt.clone(), dbt.clone()
     wsb3 = lib.wr_joint_dw_split_workspace_bytes(B, T, U1, J, V)
     ws3 = torch.empty(wsb3, dtype=torch.uint8, device=dev)

@@ -645,6 +645,9 @@ extern "C" int wr_joint_bwd_dw(const float *gout_d, const float *h_d, const int3
     const size_t need = (size_t)parts * ((size_t)V * J + V) * sizeof(float);
     WR_REQUIRE(workspace_bytes >= need, WR_EWORKSPACE, "joint_bwd_dw: workspace %zu < required %zu", workspace_bytes, need);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (V % 4 == 0 && J % 4 == 0 && tune_get(kTuneDwExact) != 1)     // default: 256 x 256 block tiling (knob 9 = 1: slabs)
+        return joint_bwd_dw_block(gout_d, h_d, logit_lengths_d, target_lengths_d, B, T, U1, J, V, parts, dw_d, db_d,
+                                  static_cast<float *>(workspace_d), st);
     const long M = (long)B * T * U1;
     const int nslabs = (V + kDwSlab - 1) / kDwSlab;
     const long per = 4 * kDwPF;                                // the main loop advances in units of two register sets

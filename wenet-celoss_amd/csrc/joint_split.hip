@@ -868,6 +868,136 @@ __global__ __launch_bounds__(512) void joint_bwd_dw_split_kernel(
     }
 }
 
+// The same 256 x 256 block tiling with the EXACT fp32 MFMA (v_mfma_f32_32x32x2_f32): the default weight gradient.
+// Four waves (2 v-halves x 2 j-halves), 4 x 4 accumulator tiles each; a 16-cell step of both operands is staged as
+// fp32 ([16][256] each, three LDS stages, global loads two steps ahead); per pair of cells a lane reads one float4
+// of each operand (its 4 interleaved tiles) and issues 16 MFMAs -- 128 MFMAs of 64 cycles per step against 16
+// ds_read_b128, so the k-loop is matrix-core bound.  Padded cells are excluded through the lengths.
+__global__ __launch_bounds__(256) void joint_bwd_dw_block_kernel(
+    const float *__restrict__ gout /* [M, V] */, const float *__restrict__ h /* [M, J] */,
+    const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens, int T, int U1, long M, int V, int J, int n_vs,
+    int n_js, long rows_per_part, float *__restrict__ part_dw /* [parts][V][J] */, float *__restrict__ part_db /* [parts][V] */)
+{
+    extern __shared__ __attribute__((aligned(16))) float fstage[];    // [kWStages][2 operands][16][kWB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int vh = wave >> 1, jh = wave & 1;
+    const int tiles = n_vs * n_js;
+    const int part = blockIdx.x / tiles, tile = blockIdx.x - part * tiles;
+    const int vs = tile / n_js, js = tile - vs * n_js;
+    const int v0 = vs * kWB, j0 = js * kWB;
+    const long mb = (long)part * rows_per_part;
+    const long me = mb + rows_per_part < M ? mb + rows_per_part : M;
+    const int steps = me > mb ? (int)((me - mb + 15) / 16) : 0;
+
+    const int c4 = tid & 63, r4 = tid >> 6;                           // staging: float4 column c4, rows r4 + 4 i
+    const bool a_in = v0 + 4 * c4 < V, b_in = j0 + 4 * c4 < J;
+    const float *__restrict__ ga = gout + (a_in ? v0 + 4 * c4 : 0);
+    const float *__restrict__ gb = h + (b_in ? j0 + 4 * c4 : 0);
+    struct Regs { f32x4 a[4], b[4]; };
+    auto gload = [&](int s, Regs &z) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            long m = mb + 16L * s + r4 + 4 * i;
+            m = m < me ? m : me - 1;
+            z.a[i] = *reinterpret_cast<const f32x4 *>(ga + (size_t)m * V);
+            z.b[i] = *reinterpret_cast<const f32x4 *>(gb + (size_t)m * J);
+        }
+    };
+    f32x4 dbacc = (f32x4){0, 0, 0, 0};
+    auto lwrite = [&](int s, const Regs &z) {
+        float *sa = fstage + (size_t)(s % kWStages) * 2 * 16 * kWB;
+        float *sb = sa + 16 * kWB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long m = mb + 16L * s + r4 + 4 * i;
+            bool on = m < me;
+            if (on && llens != nullptr) {                             // M < 2^31 (checked by the caller): 32-bit divisions
+                const unsigned mu = (unsigned)m, bt = mu / (unsigned)U1, u = mu - bt * (unsigned)U1;
+                const unsigned b = bt / (unsigned)T, t = bt - b * (unsigned)T;
+                on = ((int)t < llens[b]) && ((int)u <= tlens[b]);
+            }
+            const f32x4 zero = (f32x4){0, 0, 0, 0};
+            const f32x4 av = (on && a_in) ? z.a[i] : zero;
+            const f32x4 bv = (on && b_in) ? z.b[i] : zero;
+            dbacc += av;
+            *reinterpret_cast<f32x4 *>(sa + (r4 + 4 * i) * kWB + 4 * c4) = av;
+            *reinterpret_cast<f32x4 *>(sb + (r4 + 4 * i) * kWB + 4 * c4) = bv;
+        }
+    };
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x16){0};
+
+    auto compute = [&](int s) {
+        const float *sa = fstage + (size_t)(s % kWStages) * 2 * 16 * kWB + half * kWB + 128 * vh + 4 * l31;
+        const float *sb = fstage + (size_t)(s % kWStages) * 2 * 16 * kWB + 16 * kWB + half * kWB + 128 * jh + 4 * l31;
+#pragma unroll 2
+        for (int kp = 0; kp < 8; ++kp) {                              // cells 2 kp + half
+            const f32x4 pa = *reinterpret_cast<const f32x4 *>(sa + 2 * kp * kWB);
+            const f32x4 pb = *reinterpret_cast<const f32x4 *>(sb + 2 * kp * kWB);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[t], pb[u], acc[t][u], 0, 0, 0);
+        }
+    };
+
+    if (steps > 0) {
+        const int steps2 = (steps + 1) & ~1;                          // single loop exit (a step past the range stages zeros)
+        Regs r0, r1;
+        gload(0, r0);
+        lwrite(0, r0);
+        gload(1, r0);
+        lwrite(1, r0);
+        gload(2, r0);
+        gload(3, r1);
+        for (int s = 0; s < steps2; s += 2) {
+            __syncthreads();
+            lwrite(s + 2, r0);
+            gload(s + 4, r0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(s);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            lwrite(s + 3, r1);
+            gload(s + 5, r1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // tile (t, u) element (row i, col c) is dW[v0 + 128 vh + 4 i + t][j0 + 128 jh + 4 c + u]
+    float *__restrict__ pw = part_dw + (size_t)part * V * J;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int i = (q & 3) + 8 * (q >> 2) + 4 * half;
+            const int v = v0 + 128 * vh + 4 * i + t;
+            if (v >= V) continue;
+            const int j = j0 + 128 * jh + 4 * l31;
+            if (j < J) {
+                const f32x4 o = (f32x4){acc[t][0][q], acc[t][1][q], acc[t][2][q], acc[t][3][q]};
+                *reinterpret_cast<f32x4 *>(pw + (size_t)v * J + j) = o;
+            }
+        }
+    if (js == 0) {
+        __syncthreads();
+        f32x4 *red = reinterpret_cast<f32x4 *>(fstage);
+        red[tid] = dbacc;
+        __syncthreads();
+        if (tid < 64 && a_in) {
+            const f32x4 t4 = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
+            *reinterpret_cast<f32x4 *>(part_db + (size_t)part * V + v0 + 4 * tid) = t4;
+        }
+    }
+}
+
 __global__ void split_dw_reduce_kernel(const float *__restrict__ part_dw, const float *__restrict__ part_db, int parts,
                                        long nw, int V, float *__restrict__ dw, float *__restrict__ db)
 {
@@ -904,6 +1034,30 @@ int split_check(int B, int T, int U1, int J, int V, int terms, int out_dtype)
 }
 
 }  // namespace
+
+// Exact-fp32 weight gradient with the block tiling (called by wr_joint_bwd_dw in joint.hip).  `max_parts` is what the
+// caller's workspace was sized for.
+int joint_bwd_dw_block(const float *gout_d, const float *h_d, const int32_t *llens_d, const int32_t *tlens_d, int B, int T,
+                       int U1, int J, int V, int max_parts, float *dw_d, float *db_d, float *part_dw, hipStream_t st)
+{
+    const long M = (long)B * T * U1;
+    WR_REQUIRE(M < (1L << 31), WR_EUNSUPPORTED, "joint_bwd_dw: too many lattice cells");
+    int parts = split_dw_parts(V, J);
+    parts = parts > max_parts ? max_parts : parts;
+    float *part_db = part_dw + (size_t)parts * V * J;
+    const int n_vs = (V + kWB - 1) / kWB, n_js = (J + kWB - 1) / kWB;
+    long rows_per_part = (M + parts - 1) / parts;
+    rows_per_part = (rows_per_part + 15) / 16 * 16;
+    const size_t lds = (size_t)kWStages * 2 * 16 * kWB * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_bwd_dw_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    hipLaunchKernelGGL(joint_bwd_dw_block_kernel, dim3(n_vs * n_js * parts), dim3(256), lds, st, gout_d, h_d, llens_d, tlens_d, T,
+                       U1, M, V, J, n_vs, n_js, rows_per_part, part_dw, part_db);
+    WR_CHECK_LAUNCH("joint_bwd_dw_block_kernel");
+    hipLaunchKernelGGL(split_dw_reduce_kernel, dim3(1024), dim3(256), 0, st, part_dw, part_db, parts, (long)V * J, V, dw_d, db_d);
+    WR_CHECK_LAUNCH("split_dw_reduce_kernel");
+    return WR_OK;
+}
 }  // namespace wr
 
 using namespace wr;
