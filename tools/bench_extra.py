@@ -65,9 +65,18 @@ def bench_joint(args):
     lib.wr_tune_set(7, 0)
     dz = torch.empty(B, T, U1, J, device=dev); h = torch.empty_like(dz)
     g = lambda: _lib.check(lib.wr_joint_bwd_dz(P(out), P(ep), P(pp), P(w), None, None, B, T, U1, J, V, P(dz), P(h), st))
-    ms = timeit(g, args.steps)
-    print(json.dumps({"what": "joint_bwd_dz", "shape": [B, T, U1, J, V], "ms": round(ms, 3),
-                      "TFLOPs": round(flops / ms / 1e9, 2), "frac": round(flops / ms / 1e9 / 157.3, 4)}), flush=True)
+    dz_blocks = None
+    for blocks in (1, 0):                              # knob 10: 0 = 256 x 256 block tiling (default), 1 = 64-cell tiling
+        lib.wr_tune_set(10, 0 if blocks else 1)
+        ms = timeit(g, args.steps)
+        rec = {"what": "joint_bwd_dz", "tiling": "blocks" if blocks else "cells64", "shape": [B, T, U1, J, V], "ms": round(ms, 3),
+               "TFLOPs": round(flops / ms / 1e9, 2), "frac": round(flops / ms / 1e9 / 157.3, 4)}
+        if blocks:
+            dz_blocks = dz[:1].clone()
+        else:
+            rec["max_abs_diff_blocks_vs_cells64"] = float((dz[:1] - dz_blocks).abs().max())
+        print(json.dumps(rec), flush=True)
+    lib.wr_tune_set(10, 0)
     wsz = lib.wr_joint_dz_split_workspace_bytes(J, V)
     wz = torch.empty(wsz, dtype=torch.uint8, device=dev)
     dz_ref = dz.clone()

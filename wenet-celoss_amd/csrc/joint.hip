@@ -619,6 +619,8 @@ extern "C" int wr_joint_bwd_dz(const float *gout_d, const float *ep_d, const flo
     WR_REQUIRE((logit_lengths_d == nullptr) == (target_lengths_d == nullptr), WR_EINVAL,
                "joint_bwd_dz: pass both length arrays or neither");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (V % 4 == 0 && V >= 16 && J % 4 == 0 && tune_get(kTuneDzExact) != 1)   // default: 256 x 256 block tiling (knob 10 = 1: 64-cell tiling)
+        return joint_bwd_dz_block(gout_d, ep_d, pp_d, w_out_d, logit_lengths_d, target_lengths_d, B, T, U1, J, V, dz_d, h_d, st);
     const long M = (long)B * T * U1;
     const dim3 grid((unsigned)((M + kBM - 1) / kBM));
     hipLaunchKernelGGL(joint_bwd_dz_kernel, grid, dim3(64 * kBwdWaves), 0, st, gout_d, ep_d, pp_d, w_out_d,

@@ -998,6 +998,172 @@ __global__ __launch_bounds__(256) void joint_bwd_dw_block_kernel(
     }
 }
 
+// Exact-fp32 activation gradient with the same block tiling: dZ[m, j] = (sum_v dY[m, v] W[v, j]) (1 - H[m, j]^2).
+// A workgroup owns 256 cells x 256 join columns (4 waves = 2 x 2, 4 x 4 accumulator tiles each) and walks the
+// vocabulary in steps of 16: dY arrives row-major (v contiguous) and is transposed while it is staged (LDS rows of
+// 260 floats: the scattered 4-byte writes of a float4 hit 64 distinct banks), W [v][j] is staged as it is; per pair
+// of v a lane reads one float4 of each (4 cells, 4 columns) and issues 16 exact-fp32 MFMAs.  W is streamed once per
+// 256 cells (the 64-cell kernel in joint.hip streams it once per 64).
+constexpr int kZB = 256;         // block edge (cells and join columns)
+constexpr int kZApad = kZB + 4;  // transposed dY stage row stride (floats)
+
+__global__ __launch_bounds__(256) void joint_bwd_dz_block_kernel(
+    const float *__restrict__ gout /* [M, V] */, const float *__restrict__ ep, const float *__restrict__ pp,
+    const float *__restrict__ w /* [V, J] */, const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens, int B,
+    int T, int U1, int J, int V, int n_js, float *__restrict__ dz /* [M, J] */, float *__restrict__ hout /* [M,J] or null */)
+{
+    extern __shared__ __attribute__((aligned(16))) float zstage[];   // [kWStages]{ A^T [16][260], B [16][256] }, row tables
+    constexpr int kStageFloats = 16 * kZApad + 16 * kZB;
+    long *row_e = reinterpret_cast<long *>(zstage + (size_t)kWStages * kStageFloats);
+    long *row_p = row_e + kZB;
+    int *row_ok = reinterpret_cast<int *>(row_p + kZB);
+    const long M = (long)B * T * U1;
+    const int js = blockIdx.x % n_js;
+    const long m0 = (long)(blockIdx.x / n_js) * kZB;
+    const int j0 = js * kZB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int mh = wave >> 1, jh = wave & 1;
+
+    int valid = 0;
+    {
+        const long m = m0 + tid < M ? m0 + tid : M - 1;
+        const long bt = m / U1;
+        const int u = (int)(m - bt * U1);
+        const long b = bt / T;
+        valid = m0 + tid < M;
+        if (valid && llens != nullptr && tlens != nullptr) {
+            const int t = (int)(bt - b * T);
+            valid = (t < llens[b]) && (u <= tlens[b]);
+        }
+        row_e[tid] = bt * J;
+        row_p[tid] = (b * U1 + u) * J;
+        row_ok[tid] = valid;
+    }
+    const bool any = __syncthreads_or(valid);
+    if (!any) {                                             // wholly padded block: zeros, no arithmetic
+        for (int i = tid; i < kZB * kZB; i += 256) {
+            const long m = m0 + i / kZB;
+            const int j = j0 + i % kZB;
+            if (m < M && j < J) {
+                dz[(size_t)m * J + j] = 0.f;
+                if (hout) hout[(size_t)m * J + j] = 0.f;
+            }
+        }
+        return;
+    }
+
+    // staging maps.  A: thread -> row (tid >> 2) + 64 i, float4 along v at 4 (tid & 3).  B: thread -> float4 column
+    // (tid & 63) of the block, rows (tid >> 6) + 4 i of the step.
+    const int arow = tid >> 2, av4 = tid & 3;
+    const int bc4 = tid & 63, br4 = tid >> 6;
+    const bool b_in = j0 + 4 * bc4 < J;
+    const float *__restrict__ gb = w + (b_in ? j0 + 4 * bc4 : 0);
+    const int steps = (V + 15) / 16;
+    struct Regs { f32x4 a[4], b[4]; };
+    auto gload = [&](int s, Regs &z) {
+        const int ss = s < steps ? s : steps - 1;
+        const int v = 16 * ss + 4 * av4;
+        const int vc = v < V ? v : V - 4;                   // V % 4 == 0
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            long m = m0 + arow + 64 * i;
+            m = m < M ? m : M - 1;
+            z.a[i] = *reinterpret_cast<const f32x4 *>(gout + (size_t)m * V + vc);
+            int vr = 16 * ss + br4 + 4 * i;
+            vr = vr < V ? vr : V - 1;
+            z.b[i] = *reinterpret_cast<const f32x4 *>(gb + (size_t)vr * J);
+        }
+    };
+    auto lwrite = [&](int s, const Regs &z) {
+        float *sa = zstage + (size_t)(s % kWStages) * kStageFloats;
+        float *sb = sa + 16 * kZApad;
+        const bool a_in = 16 * s + 4 * av4 < V;
+        const f32x4 zero = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = arow + 64 * i;
+            const f32x4 av = (a_in && m0 + r < M) ? z.a[i] : zero;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sa[(4 * av4 + e) * kZApad + r] = av[e];
+            const bool bon = b_in && 16 * s + br4 + 4 * i < V;
+            *reinterpret_cast<f32x4 *>(sb + (br4 + 4 * i) * kZB + 4 * bc4) = bon ? z.b[i] : zero;
+        }
+    };
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x16){0};
+
+    auto compute = [&](int s) {
+        const float *sa = zstage + (size_t)(s % kWStages) * kStageFloats + half * kZApad + 128 * mh + 4 * l31;
+        const float *sb = zstage + (size_t)(s % kWStages) * kStageFloats + 16 * kZApad + half * kZB + 128 * jh + 4 * l31;
+#pragma unroll 2
+        for (int kp = 0; kp < 8; ++kp) {                              // v = 2 kp + half
+            const f32x4 pa = *reinterpret_cast<const f32x4 *>(sa + 2 * kp * kZApad);
+            const f32x4 pb = *reinterpret_cast<const f32x4 *>(sb + 2 * kp * kZB);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[t], pb[u], acc[t][u], 0, 0, 0);
+        }
+    };
+
+    {
+        const int steps2 = (steps + 1) & ~1;                          // single loop exit (a step past V stages zeros)
+        Regs r0, r1;
+        gload(0, r0);
+        lwrite(0, r0);
+        gload(1, r0);
+        lwrite(1, r0);
+        gload(2, r0);
+        gload(3, r1);
+        for (int s = 0; s < steps2; s += 2) {
+            __syncthreads();
+            lwrite(s + 2, r0);
+            gload(s + 4, r0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(s);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            lwrite(s + 3, r1);
+            gload(s + 5, r1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // epilogue: tile (t, u) element (row i, col c) is cell m0 + 128 mh + 4 i + t, column j0 + 128 jh + 4 c + u: the four
+    // u's of a (t, i) are four consecutive columns -> float4 loads of ep / pp and float4 stores
+    const int jcol = j0 + 128 * jh + 4 * l31;
+    if (jcol < J) {                                                   // J % 4 == 0
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int i = (q & 3) + 8 * (q >> 2) + 4 * half;
+                const int row = 128 * mh + 4 * i + t;
+                const long m = m0 + row;
+                if (m >= M) continue;
+                const bool ok = row_ok[row] != 0;
+                const f32x4 e4 = *reinterpret_cast<const f32x4 *>(ep + row_e[row] + jcol);
+                const f32x4 p4 = *reinterpret_cast<const f32x4 *>(pp + row_p[row] + jcol);
+                f32x4 h4, g4;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float hh = tanhf(e4[u] + p4[u]);
+                    h4[u] = ok ? hh : 0.f;
+                    g4[u] = ok ? acc[t][u][q] * (1.f - hh * hh) : 0.f;
+                }
+                *reinterpret_cast<f32x4 *>(dz + (size_t)m * J + jcol) = g4;
+                if (hout) *reinterpret_cast<f32x4 *>(hout + (size_t)m * J + jcol) = h4;
+            }
+    }
+}
+
 __global__ void split_dw_reduce_kernel(const float *__restrict__ part_dw, const float *__restrict__ part_db, int parts,
                                        long nw, int V, float *__restrict__ dw, float *__restrict__ db)
 {
@@ -1034,6 +1200,23 @@ int split_check(int B, int T, int U1, int J, int V, int terms, int out_dtype)
 }
 
 }  // namespace
+
+// Exact-fp32 activation gradient with the block tiling (called by wr_joint_bwd_dz in joint.hip).
+int joint_bwd_dz_block(const float *gout_d, const float *ep_d, const float *pp_d, const float *w_d, const int32_t *llens_d,
+                       const int32_t *tlens_d, int B, int T, int U1, int J, int V, float *dz_d, float *h_d, hipStream_t st)
+{
+    const long M = (long)B * T * U1;
+    const int n_js = (J + kZB - 1) / kZB;
+    const long blocks = (M + kZB - 1) / kZB * n_js;
+    WR_REQUIRE(blocks < (1L << 31), WR_EUNSUPPORTED, "joint_bwd_dz: too many lattice cells");
+    const size_t lds = (size_t)kWStages * (16 * kZApad + 16 * kZB) * sizeof(float) + (size_t)kZB * (2 * sizeof(long) + sizeof(int));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_bwd_dz_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    hipLaunchKernelGGL(joint_bwd_dz_block_kernel, dim3((unsigned)blocks), dim3(256), lds, st, gout_d, ep_d, pp_d, w_d, llens_d,
+                       tlens_d, B, T, U1, J, V, n_js, dz_d, h_d);
+    WR_CHECK_LAUNCH("joint_bwd_dz_block_kernel");
+    return WR_OK;
+}
 
 // Exact-fp32 weight gradient with the block tiling (called by wr_joint_bwd_dw in joint.hip).  `max_parts` is what the
 // caller's workspace was sized for.

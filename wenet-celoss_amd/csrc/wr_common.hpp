@@ -41,8 +41,12 @@ void set_error(const char *fmt, ...);
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- process-wide tuning knobs (wr_tune_set; defaults are the measured best) ----
-enum TuneKey { kTuneLseBlocksPerCu = 0, kTuneGradBlocksPerCu = 1, kTuneNonTemporal = 2, kTuneGradUnroll = 3, kTuneLseUnroll = 4, kTuneJointFwdVariant = 5, kTuneLaneGemmTile = 6, kTuneSplitParts = 7, kTuneDzTile = 8, kTuneDwExact = 9, kTuneCount = 12 };
+enum TuneKey { kTuneLseBlocksPerCu = 0, kTuneGradBlocksPerCu = 1, kTuneNonTemporal = 2, kTuneGradUnroll = 3, kTuneLseUnroll = 4, kTuneJointFwdVariant = 5, kTuneLaneGemmTile = 6, kTuneSplitParts = 7, kTuneDzTile = 8, kTuneDwExact = 9, kTuneDzExact = 10, kTuneCount = 12 };
 int tune_get(int key);
+
+// joint_split.hip: exact-fp32 activation gradient, 256 x 256 block tiling
+int joint_bwd_dz_block(const float *gout_d, const float *ep_d, const float *pp_d, const float *w_d, const int32_t *llens_d,
+                       const int32_t *tlens_d, int B, int T, int U1, int J, int V, float *dz_d, float *h_d, hipStream_t st);
 
 // joint_split.hip: exact-fp32 weight gradient, 256 x 256 block tiling (the partial blocks go to `part_dw`, sized by the
 // caller for `max_parts` parts of V*J + V floats)
