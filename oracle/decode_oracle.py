@@ -136,11 +136,12 @@ def greedy_search(pred: Predictor, joint: Joint, enc, T, blank=0, n_steps=64, re
 
 class StreamingGreedy:
     """reset_cache / forward_greedy_search of "wenet/transducer/transducer ref.py":541-606 for one stream.
-    That file cannot be imported here (it pulls in k2 and torchaudio at module level), so this restatement
-    has no reference-produced fixture: PARITY UNPINNED for the streaming export; it is checked against the
-    pinned offline greedy loop instead (a chunked decode with `reference_new_cache=False` must equal the
-    offline decode of the concatenated frames).  `reference_new_cache=True` keeps the reference's
-    `new_cache = self.cache` at the top of every chunk (:571)."""
+    PINNED: tests/golden/greedy_stream_*.npz hold what those two methods of the reference returned chunk by
+    chunk (tests/golden/make_golden.py::gen_greedy_stream loads the file with empty stubs for its unused
+    module-level imports of torchaudio / k2), and tests/test_oracle_decode.py::test_streaming_greedy replays
+    them.  `reference_new_cache=True` is the reference's behaviour: `new_cache = self.cache` at the top of every
+    chunk (:571) drops the predictor state that was computed but not yet committed in the previous chunk;
+    False keeps it, which makes a chunked decode equal the offline decode of the concatenated frames."""
 
     def __init__(self, pred: Predictor, joint: Joint, blank=0):
         self.pred, self.joint, self.blank = pred, joint, blank

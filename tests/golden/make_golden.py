@@ -17,6 +17,12 @@ for modules that are absent from the image -- `typeguard`, used only for
   wenet/transducer/search/greedy_search copy.py  basic_greedy_search -> greedy_core_*.npz
   wenet/transducer/search/prefix_beam_search.py  PrefixBeamSearch    -> prefix_beam_*.npz
   wenet/utils/common.py               add_blank, log_add             -> common_ref.npz
+  wenet/transducer/transducer ref.py  Transducer.reset_cache / forward_greedy_search (the TorchScript streaming
+                                      exports, :541-606)             -> greedy_stream_*.npz
+                                      (module-level imports of `torchaudio` and `k2.rnnt_loss` are satisfied by empty
+                                      in-process stubs; the two methods touch neither)
+  wenet/transformer/context_bias.py   ContextBias (the real module) driven by
+  wenet/transducer/search/greedy_search.py  basic_greedy_search_both -> greedy_both_real_*.npz
 torchaudio.functional.rnnt_loss cannot be imported (torchaudio is absent), so no
 RNN-T-loss fixture comes from the reference; rnnt_kat.npz holds the public
 known-answer vector instead.
@@ -412,6 +418,118 @@ def gen_greedy_fork():
              **{"pred_" + k: v for k, v in sd(pred).items()}, **{"joint_" + k: v for k, v in sd(joint).items()})
 
 
+class MarginJoint(torch.nn.Module):
+    """Wraps a reference joiner; records every decision (argmax) and the smallest top-1 / top-2 log-prob gap."""
+
+    def __init__(self, joint):
+        super().__init__()
+        self.joint = joint
+        self.min_margin = 1e9
+        self.decisions = []
+
+    def forward(self, enc, pred):
+        out = self.joint(enc, pred)
+        top = out.log_softmax(-1).flatten().topk(2)
+        self.min_margin = min(self.min_margin, float(top.values[0] - top.values[1]))
+        self.decisions.append(int(top.indices[0]))
+        return out
+
+
+def per_frame_counts(decisions, n_steps, blank=0):
+    """Tokens emitted on each frame, derived from the decision sequence of the loop (a frame ends on a blank or
+    when n_steps tokens were emitted on it)."""
+    counts, n = [], 0
+    for k in decisions:
+        if k != blank:
+            n += 1
+        if k == blank or n >= n_steps:
+            counts.append(n)
+            n = 0
+    return counts
+
+
+def gen_greedy_stream():
+    """The stateful streaming exports of "wenet/transducer/transducer ref.py":541-606 (reset_cache /
+    forward_greedy_search, consumed by runtime/core/decoder/torch_asr_model.cc:126,313), called unbound on a
+    stand-in `self` that carries the reference predictor / joiner.  The file imports torchaudio and k2.rnnt_loss at
+    module level; neither is used by these two methods, so empty stub modules satisfy the import.
+    reset_cache reads `self.predictor.output_size`, which this fork's RNNPredictor does not define (predictor.py:58-90);
+    the stand-in sets it to the projection width.  The reference's per-chunk token buffer holds one token per chunk
+    frame (:565) and overflows (IndexError) beyond that; the cases stay inside it."""
+    for name in ("torchaudio", "k2", "k2.rnnt_loss"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["k2.rnnt_loss"].rnnt_loss_simple = None
+    sys.modules["k2"].rnnt_loss = sys.modules["k2.rnnt_loss"]
+    path = os.path.join(REF, "wenet", "transducer", "transducer ref.py")
+    spec = importlib.util.spec_from_file_location("ref_transducer_ref", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    T_cls = mod.Transducer
+    V, E, P, J, H = 64, 16, 16, 32, 16
+
+    def run(pred, joint, enc, sizes, n_steps):
+        mj = MarginJoint(joint)
+        st = types.SimpleNamespace(predictor=pred, joint=mj, blank=0)
+        outs, a = [], 0
+        with torch.no_grad():
+            T_cls.reset_cache(st)
+            for n in sizes:
+                outs.append(T_cls.forward_greedy_search(st, enc[:, a:a + n], torch.tensor(n), n_steps))
+                a += n
+        return outs, mj
+
+    cases = [
+        dict(seed=600, T=48, n_steps=64, blank_bias=11.0, chunks="even16"),
+        dict(seed=601, T=40, n_steps=64, blank_bias=9.0, chunks="after_nonblank"),   # every boundary right after an emission
+        dict(seed=602, T=24, n_steps=2, blank_bias=6.0, chunks=[5, 7, 12], want_cap=True),   # cap reached inside a chunk
+        dict(seed=603, T=36, n_steps=64, blank_bias=9.0, chunks=[1, 1, 2, 16, 16]),     # tiny chunks
+        dict(seed=604, T=30, n_steps=1, blank_bias=-30.0, chunks=[10, 10, 10]),         # never blank: cap on every frame
+    ]
+    for i, c in enumerate(cases):
+        for attempt in range(600):
+            seed = c["seed"] + 1000 * attempt
+            pred, joint, _ = build_decode_modules(seed, V, E, P, J, H, 2, blank_bias=c["blank_bias"], weight_scale=2.0)
+            pred.output_size = P
+            g = torch.Generator().manual_seed(seed + 7)
+            enc = dyadic((1, c["T"], E), g, scale=8, lim=2.0)
+            try:
+                _, off = run(pred, joint, enc, [c["T"]], c["n_steps"])          # offline pass: one chunk
+            except IndexError:
+                continue
+            pf = per_frame_counts(off.decisions, c["n_steps"])
+            assert len(pf) == c["T"]
+            if c["chunks"] == "even16":
+                sizes = [16] * (c["T"] // 16)
+            elif c["chunks"] == "after_nonblank":
+                cuts = [t + 1 for t in range(c["T"] - 1) if pf[t] > 0][:4]
+                if len(cuts) < 3:
+                    continue
+                edges = [0] + cuts + [c["T"]]
+                sizes = [b - a for a, b in zip(edges[:-1], edges[1:])]
+            else:
+                sizes = list(c["chunks"])
+            assert sum(sizes) == c["T"]
+            if c.get("want_cap") and not any(n >= c["n_steps"] for n in pf):
+                continue
+            try:
+                outs, mj = run(pred, joint, enc, sizes, c["n_steps"])
+            except IndexError:
+                continue
+            nonempty = sum(1 for o in outs if o)
+            if margins_ok(mj.min_margin) and nonempty >= min(3, len(sizes)):
+                break
+        else:
+            raise AssertionError(f"no usable seed for streaming case {i}")
+        print(f"  streaming case {i}: seed {seed}, chunks {sizes}, tokens per chunk {[len(o) for o in outs]}, "
+              f"min margin {mj.min_margin:.4f}")
+        flat = np.array([t for o in outs for t in o], np.int64)
+        save(f"greedy_stream_{i}", enc=enc.numpy(), T=np.array(c["T"]), n_steps=np.array(c["n_steps"]),
+             chunk_sizes=np.array(sizes, np.int64), chunk_tokens=flat,
+             chunk_token_counts=np.array([len(o) for o in outs], np.int64), min_margin=np.array(mj.min_margin),
+             n_layers=np.array(2), hidden=np.array(H), **{"pred_" + k: v for k, v in sd(pred).items()},
+             **{"joint_" + k: v for k, v in sd(joint).items()})
+
+
 def gen_common():
     from wenet.utils.common import add_blank, log_add
     ys = torch.tensor([[1, 2, 3, 4, 5], [4, 5, 6, -1, -1], [7, 8, 9, -1, -1]])
@@ -443,3 +561,4 @@ if __name__ == "__main__":
     gen_ctc_decode()
     gen_ctc_align()
     gen_greedy_fork()
+    gen_greedy_stream()

@@ -220,6 +220,39 @@ def test_streaming_chunks_equal_offline_and_reference_quirk():
     assert outs[0] == list(d["hyp"])
 
 
+@pytest.mark.parametrize("path", names("greedy_stream_*.npz"))
+def test_streaming_greedy_matches_reference_chunks(path):
+    """reset_cache() + forward_greedy_search(chunk) return, chunk by chunk, exactly the tokens that the reference's
+    own TorchScript exports ("wenet/transducer/transducer ref.py":541-606) returned for the same chunking
+    (fixtures from tests/golden/make_golden.py::gen_greedy_stream) -- including its `new_cache = self.cache` reset
+    at every chunk start; chunk boundaries right after an emission and the n_steps cap are among the cases."""
+    import wenet_celoss_amd as w
+    d = np.load(path)
+    pred, joint, _ = build_modules(d)
+    m = w.Transducer(64, 0, torch.nn.Identity(), pred, joint, ctc_weight=0.0, transducer_weight=1.0, hw_weight=0.0)
+    enc = torch.tensor(d["enc"], device=DEV)
+    n_steps = int(d["n_steps"])
+    for graph in (True, False):
+        m.reset_cache(1, chunk_frames=int(max(d["chunk_sizes"])), n_steps=n_steps)
+        a, k = 0, 0
+        for n, cnt in zip(d["chunk_sizes"].tolist(), d["chunk_token_counts"].tolist()):
+            got = m.forward_greedy_search(enc[:, a:a + n].contiguous(), torch.tensor([n]), n_steps=n_steps)
+            if a == 0:
+                m._stream_dec.set_graph(graph)
+            assert got == d["chunk_tokens"][k:k + cnt].tolist(), (path, a, n, graph)
+            a += n
+            k += cnt
+    # the same utterance as one of several streams (other streams must not disturb it)
+    m.reset_cache(3, chunk_frames=int(max(d["chunk_sizes"])), n_steps=n_steps)
+    encs = torch.cat([enc.flip(1), enc, enc * 0.5], 0)
+    a, k = 0, 0
+    for n, cnt in zip(d["chunk_sizes"].tolist(), d["chunk_token_counts"].tolist()):
+        res = m.forward_greedy_search(encs[:, a:a + n].contiguous(), torch.tensor([n, n, n]), n_steps=n_steps)
+        assert res[1] == d["chunk_tokens"][k:k + cnt].tolist(), (path, a, n)
+        a += n
+        k += cnt
+
+
 @pytest.mark.parametrize("path", names("greedy_fork_*.npz"))
 def test_fork_hotword_greedy_matches_reference(path):
     """The fork's greedy variants (greedy_search.py:34-176 'pred', :297-430 'both'; context filter on/off):

@@ -32,6 +32,7 @@ def test_fixture_inventory():
     assert len(names("ctc_ref_*.npz")) >= 5
     assert len(names("joint_ref_*.npz")) >= 2
     assert len(names("predictor_step_*.npz")) >= 2
+    assert len(names("greedy_stream_*.npz")) >= 5
 
 
 def test_common_helpers():
@@ -69,6 +70,22 @@ def test_greedy(name):
                                    return_margin=True)
     assert hyp == list(d["hyp"])                       # token sequences identical
     assert margin == pytest.approx(float(d["min_margin"]), abs=1e-4)
+
+
+@pytest.mark.parametrize("name", names("greedy_stream_*.npz"))
+def test_streaming_greedy(name):
+    """The restated reset_cache / forward_greedy_search pair returns, chunk by chunk, what the reference's own
+    methods ("transducer ref.py":541-606) returned for the same chunking."""
+    d = load(name)
+    p = do.Predictor(sub(d, "pred_"), int(d["n_layers"]))
+    j = do.Joint(sub(d, "joint_"))
+    st = do.StreamingGreedy(p, j)
+    a, k = 0, 0
+    for n, cnt in zip(d["chunk_sizes"], d["chunk_token_counts"]):
+        got = st.forward_greedy_search(d["enc"][0, a:a + n], int(n), n_steps=int(d["n_steps"]), reference_new_cache=True)
+        assert got == list(d["chunk_tokens"][k:k + cnt]), (name, a, n)
+        a += n
+        k += cnt
 
 
 @pytest.mark.parametrize("name", names("prefix_beam_*.npz"))
