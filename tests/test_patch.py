@@ -1,0 +1,189 @@
+"""The drop-in seam (wenet_celoss_amd.patch) and BASELINE config 1 (CTC on CPU tensors), without a GPU.
+
+* a stub `wenet` package tree whose `utils/init_model.py` binds its classes by the same import statements as the
+  reference's (wenet/utils/init_model.py:16-22) picks up the replacements after `patch.install()`; the stub's own
+  `wenet/transducer/transducer.py` raises on import (as the reference's does here: `import torchaudio`), which
+  proves the swap happened before the import;
+* with the real reference tree present (this container only) the reference's unedited `init_model()` builds a
+  `wenet_celoss_amd.Transducer` around the reference's own ConformerEncoder;
+* `CTC.forward` on CPU tensors runs the reference's statements on stock torch.nn.CTCLoss and reproduces the
+  fixtures generated from the reference module."""
+import glob
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+
+REF = "/root/reference"
+
+
+def _make_stub_tree(root):
+    for d in ("wenet", "wenet/utils", "wenet/transducer", "wenet/transformer"):
+        os.makedirs(os.path.join(root, d))
+        open(os.path.join(root, d, "__init__.py"), "w").close()
+    with open(os.path.join(root, "wenet/transducer/transducer.py"), "w") as f:
+        f.write("import torchaudio_that_does_not_exist\n")
+    for name in ("wenet/transducer/joint.py", "wenet/transducer/predictor.py", "wenet/transformer/ctc.py"):
+        with open(os.path.join(root, name), "w") as f:
+            f.write("raise ImportError('the original module must not be imported after patch.install()')\n")
+    with open(os.path.join(root, "wenet/utils/init_model.py"), "w") as f:
+        f.write(textwrap.dedent("""
+            import torch
+            from wenet.transducer.joint import TransducerJoint
+            from wenet.transducer.predictor import (ConvPredictor, EmbeddingPredictor, RNNPredictor)
+            from wenet.transducer.transducer import Transducer
+            from wenet.transformer.ctc import CTC
+
+            def init_model(configs):
+                v = configs['output_dim']
+                enc = torch.nn.Identity()
+                ctc = CTC(v, configs['enc'])
+                pred = RNNPredictor(v, **configs['predictor_conf'])
+                joint = TransducerJoint(v, enc_output_size=configs['enc'],
+                                        pred_output_size=configs['predictor_conf']['output_size'], **configs['joint_conf'])
+                return Transducer(vocab_size=v, blank=0, predictor=pred, encoder=enc, context_bias=None,
+                                  attention_decoder=None, joint=joint, ctc=ctc, **configs['model_conf'])
+            """))
+
+
+def _run(code, extra_path):
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, extra_path]), PYTHONDONTWRITEBYTECODE="1")
+    return subprocess.run([sys.executable, "-c", textwrap.dedent(code)], env=env, capture_output=True, text=True,
+                          timeout=300)
+
+
+def test_install_swaps_classes_in_stub_tree(tmp_path):
+    _make_stub_tree(str(tmp_path))
+    r = _run("""
+        import wenet_celoss_amd as w
+        import wenet_celoss_amd.patch as patch
+        assert not patch.installed()
+        patch.install()
+        assert patch.installed()
+        from wenet.utils.init_model import init_model
+        m = init_model(dict(output_dim=11, enc=6,
+                            predictor_conf=dict(embed_size=6, output_size=6, embed_dropout=0.1, hidden_size=8, num_layers=2),
+                            joint_conf=dict(join_dim=12),
+                            model_conf=dict(ctc_weight=0.25, transducer_weight=0.75, attention_weight=0.0)))
+        assert type(m) is w.Transducer and type(m.joint) is w.TransducerJoint and type(m.ctc) is w.CTC
+        assert type(m.predictor) is w.RNNPredictor
+        import wenet.transducer.predictor as p
+        try:
+            p.ConvPredictor(3)
+        except NotImplementedError as e:
+            assert "RNNPredictor" in str(e)
+        else:
+            raise AssertionError("ConvPredictor placeholder must refuse")
+        patch.uninstall()
+        assert not patch.installed()
+        print("OK")
+        """, str(tmp_path))
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_without_install_the_stub_tree_fails_like_the_reference(tmp_path):
+    _make_stub_tree(str(tmp_path))
+    r = _run("from wenet.utils.init_model import init_model", str(tmp_path))
+    assert r.returncode != 0 and "must not be imported" in r.stderr
+
+
+def test_install_refuses_after_init_model_import(tmp_path):
+    r = _run("""
+        import sys, types
+        im = types.ModuleType("wenet.utils.init_model")
+        class T: pass
+        T.__module__ = "wenet.transducer.transducer"
+        im.Transducer = T
+        sys.modules["wenet.utils.init_model"] = im
+        import wenet_celoss_amd.patch as patch
+        try:
+            patch.install()
+        except RuntimeError as e:
+            assert "before install" in str(e); print("OK")
+        """, str(tmp_path))
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "wenet")), reason="reference tree only exists in the build container")
+def test_reference_init_model_unedited_builds_our_transducer():
+    """wenet/utils/init_model.py:29-109 of the real reference, imported after patch.install() (plus the two
+    in-process stubs for modules the image lacks), builds wenet_celoss_amd.Transducer around the
+    reference's own ConformerEncoder / BiTransformerDecoder / ContextBias."""
+    r = _run("""
+        import sys, types
+        tg = types.ModuleType("typeguard"); tg.check_argument_types = lambda *a, **k: True
+        sys.modules["typeguard"] = tg
+        tt = types.ModuleType("turtle"); tt.forward = None
+        sys.modules["turtle"] = tt
+        import wenet_celoss_amd as w
+        import wenet_celoss_amd.patch as patch
+        patch.install()
+        from wenet.utils.init_model import init_model
+        cfg = dict(cmvn_file=None, is_json_cmvn=True, input_dim=80, output_dim=50, encoder='conformer',
+                   decoder='bitransformer', context='bias',
+                   encoder_conf=dict(output_size=16, attention_heads=2, linear_units=32, num_blocks=1, dropout_rate=0.0,
+                                     input_layer='conv2d', normalize_before=True),
+                   decoder_conf=dict(attention_heads=2, linear_units=32, num_blocks=1, r_num_blocks=1, dropout_rate=0.0),
+                   context_conf=dict(embedding_size=16, num_layers=1, attention_heads=2, bias_encoder_type='linear',
+                                     context_extractor='BLSTM', unified_hw_odim=8, unified_hw_heads=2),
+                   predictor='rnn',
+                   predictor_conf=dict(embed_size=16, output_size=16, embed_dropout=0.1, hidden_size=16, num_layers=2),
+                   joint_conf=dict(join_dim=32, prejoin_linear=True, postjoin_linear=False, joint_mode='add', activation='tanh'),
+                   model_conf=dict(ctc_weight=0.1, attention_weight=0.15, transducer_weight=0.75, reverse_weight=0.3,
+                                   lsm_weight=0.1, length_normalized_loss=False, loss_mode='both'))
+        m = init_model(cfg)
+        assert type(m) is w.Transducer, type(m)
+        assert type(m.encoder).__module__ == "wenet.transformer.encoder"
+        assert type(m.context_bias).__module__ == "wenet.transformer.context_bias"
+        assert type(m.ctc) is w.CTC and type(m.joint) is w.TransducerJoint
+        keys = set(m.state_dict())
+        for k in ("joint.ffn_out.weight", "ctc.ctc_lo.bias", "predictor.rnn.weight_hh_l1", "encoder.after_norm.weight"):
+            assert k in keys, k
+        print("OK")
+        """, REF)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "ctc_ref_*.npz"))))
+def test_ctc_module_on_cpu_is_the_reference_call(path):
+    """BASELINE config 1: CTC-only plumbing on CPU.  wenet_celoss_amd.CTC on CPU tensors == the reference module's
+    recorded loss and gradients (ctc.py:46-64 on stock torch.nn.CTCLoss)."""
+    import wenet_celoss_amd as w
+    d = np.load(path)
+    V, D = d["w_ctc_lo.weight"].shape
+    ctc = w.CTC(V, D)
+    ctc.load_state_dict({"ctc_lo.weight": torch.tensor(d["w_ctc_lo.weight"]), "ctc_lo.bias": torch.tensor(d["w_ctc_lo.bias"])})
+    hs = torch.tensor(d["hs"], requires_grad=True)
+    loss = ctc(hs, torch.tensor(d["hlens"]), torch.tensor(d["ys"]), torch.tensor(d["ys_lens"]))
+    if np.isfinite(d["loss"]):
+        assert loss.item() == pytest.approx(float(d["loss"]), rel=1e-6)
+        loss.backward()
+        np.testing.assert_allclose(hs.grad.numpy(), d["grad_hs"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(ctc.ctc_lo.weight.grad.numpy(), d["grad_w"], rtol=1e-5, atol=1e-6)
+    else:
+        assert not torch.isfinite(loss)
+    np.testing.assert_allclose(ctc.log_softmax(hs.detach()).detach().numpy(), d["log_softmax"], rtol=1e-6, atol=1e-6)
+
+
+def test_config1_ctc_only_batch2_runs_on_cpu():
+    """configs[0]: batch 2, <= 200 input frames -> <= 49 encoder frames, V = 5000, CTC only, no GPU."""
+    import wenet_celoss_amd as w
+    torch.manual_seed(0)
+    ctc = w.CTC(5000, 256)
+    hs = torch.randn(2, 49, 256, requires_grad=True)
+    ys = torch.randint(1, 5000, (2, 12)); ys[1, 9:] = -1
+    loss = ctc(hs, torch.tensor([49, 40]), ys, torch.tensor([12, 9]))
+    ref = torch.nn.functional.ctc_loss(ctc.ctc_lo(hs).transpose(0, 1).log_softmax(2), ys, torch.tensor([49, 40]),
+                                       torch.tensor([12, 9]), reduction="sum") / 2
+    assert torch.isfinite(loss) and loss.item() == pytest.approx(ref.item(), rel=1e-6)
+    loss.backward()
+    assert torch.isfinite(hs.grad).all() and hs.grad[1, 40:].abs().max() == 0
+    # the functional fused op and the RNN-T / joiner paths still refuse CPU tensors
+    with pytest.raises(RuntimeError, match="HIP device"):
+        w.ctc_loss(torch.zeros(1, 4, 5), torch.ones(1, 1, dtype=torch.long), torch.tensor([4]), torch.tensor([1]))

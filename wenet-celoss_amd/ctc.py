@@ -9,6 +9,12 @@ library GEMM (torch.nn.Linear on rocBLAS); log-softmax, the alpha/beta lattice
 and the gradient w.r.t. the projection output are the fused HIP path
 (``wr_ctc_loss_fwd/bwd``).  Quirk kept: ``F.dropout`` is called with its default
 ``training=True`` (ctc.py:57), so a non-zero ``dropout_rate`` applies in eval too.
+
+CPU tensors (BASELINE config 1: "torch.nn.CTCLoss on CPU, plumbing, runs without a
+GPU"): ``CTC.forward`` then executes the reference's own statement sequence --
+``log_softmax(2)`` + stock ``torch.nn.CTCLoss`` (ctc.py:44,58-63) -- on PyTorch's CPU
+kernels.  That is the reference's call, not a port of the HIP path; the functional
+``ctc_loss`` and every other entry point of this package keep raising on CPU tensors.
 """
 from __future__ import annotations
 
@@ -85,6 +91,9 @@ def ctc_loss(logits: torch.Tensor, targets: torch.Tensor, input_lengths: torch.T
         tg = torch.zeros(B, 1, dtype=torch.int32, device=dev)
     il = input_lengths.to(device=dev, dtype=torch.int32).contiguous()
     tl = target_lengths.to(device=dev, dtype=torch.int32).contiguous()
+    if logits.dtype != torch.float32:
+        logits = logits.float()             # fp16/bf16 activations (AMP or not): the CTC kernels take fp32; the
+                                            # cast is differentiable, so the gradient returns in the input dtype
     nll = _CTCLossFn.apply(logits.contiguous(), tg, il, tl, int(blank))
     if reduction == "sum":
         return nll.sum()
@@ -181,12 +190,17 @@ class CTC(torch.nn.Module):
         self.dropout_rate = dropout_rate
         self.ctc_lo = torch.nn.Linear(eprojs, odim)
         self.reduction_type = "sum" if reduce else "none"
+        self.ctc_loss = torch.nn.CTCLoss(reduction=self.reduction_type)     # ctc.py:44; used for CPU tensors only
 
     @torch.jit.unused      # backed by a ctypes autograd Function: opaque to TorchScript (train.py:203-205 smoke export)
     def forward(self, hs_pad: torch.Tensor, hlens: torch.Tensor, ys_pad: torch.Tensor,
                 ys_lens: torch.Tensor) -> torch.Tensor:
         """hs_pad (B, Tmax, D), hlens (B), ys_pad (B, Lmax) padded with -1, ys_lens (B)."""
         ys_hat = self.ctc_lo(F.dropout(hs_pad, p=self.dropout_rate))      # (B, T, V); ctc.py:57
+        if not ys_hat.is_cuda:
+            # config 1 (CPU plumbing): exactly the reference's statements, on stock PyTorch (ctc.py:58-63)
+            ys_hat = ys_hat.transpose(0, 1).log_softmax(2)
+            return self.ctc_loss(ys_hat, ys_pad, hlens, ys_lens) / ys_hat.size(1)
         loss = ctc_loss(ys_hat, ys_pad, hlens, ys_lens, blank=0, reduction=self.reduction_type)
         return loss / ys_hat.size(0)                                        # batch-size average; ctc.py:63
 
