@@ -154,6 +154,7 @@ class StreamingGreedy:
         self.tok = np.array([self.blank])
         self.per_frame = 0
         self.prev_nblk = True
+        self.min_margin = float("inf")      # smallest top-1 / top-2 log-prob gap over all decisions so far
 
     def forward_greedy_search(self, enc, T, n_steps=64, reference_new_cache=True):
         padding = np.zeros((1, 1), F)
@@ -164,6 +165,8 @@ class StreamingGreedy:
                 self.out, new_cache = self.pred.forward_step(self.tok, padding, self.cache)
             lp = log_softmax(self.joint(enc[t][None, :], self.out))[0]
             k = int(lp.argmax())
+            top2 = np.partition(lp, -2)[-2:]
+            self.min_margin = min(self.min_margin, float(top2[1] - top2[0]))
             if k != self.blank:
                 hyps.append(k)
                 self.prev_nblk = True
@@ -185,11 +188,15 @@ def ctc_log_softmax(w, enc):
 
 
 def prefix_beam_search(pred: Predictor, joint: Joint, ctc_w, enc, T, beam_size=5, ctc_weight=0.3,
-                       transducer_weight=0.7, blank=0):
+                       transducer_weight=0.7, blank=0, return_margin=False):
     """prefix_beam_search.py:42-148 for one utterance.  Returns the pruned beam as a
-    list of dicts {hyp (with the seed blank), score (float64), cache}."""
+    list of dicts {hyp (with the seed blank), score (float64), cache}.
+    return_margin: also return the smallest score gap that decided anything visible in the result -- between
+    neighbours of the sorted fused candidates down to the first pruned one, over all frames.  An implementation
+    whose per-frame log-probs differ in the last fp32 bits can only produce a different beam when this is tiny."""
     ctc_probs = ctc_log_softmax(ctc_w, enc[:T])
     beam = [dict(hyp=[blank], score=0.0, cache=pred.init_state(1))]
+    min_margin = float("inf")
     for i in range(T):
         n = len(beam)
         toks = np.array([s["hyp"][-1] for s in beam])
@@ -221,8 +228,13 @@ def prefix_beam_search(pred: Predictor, joint: Joint, ctc_w, enc, T, beam_size=5
             else:
                 fusion.append(s1)
         fusion.sort(key=lambda s: s["score"], reverse=True)                 # stable, like list.sort
+        if return_margin:
+            sc = [s["score"] for s in fusion[:beam_size + 1]]
+            for a, b in zip(sc[:-1], sc[1:]):
+                if math.isfinite(a) and math.isfinite(b):
+                    min_margin = min(min_margin, a - b)
         beam = fusion[:beam_size]
-    return beam
+    return (beam, min_margin) if return_margin else beam
 
 
 # ---------------------------------------------------------------- CTC decode modes --

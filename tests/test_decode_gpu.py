@@ -182,6 +182,103 @@ def test_config3_shape_streams_match_oracle():
     assert sum(len(h) for h in hyps) > N         # something was emitted
 
 
+def test_config5_full_shape_prefix_beam_matches_oracle():
+    """BASELINE config 5 at full shape: one call with B=16 utterances, T=1500 encoder frames, V=5000, E=P=256,
+    J=512, LSTM 2x256, beam 8, ctc/transducer weights (0.3, 0.7) -- prefix_beam_search.py:42-148 for every
+    utterance.  The ten utterances of at most 150 frames are re-decoded by the numpy oracle; n-best hypotheses and
+    their order must be identical and scores agree to 1e-5 relative for every one whose decisions were clear:
+    random weights give near-degenerate beams (hypotheses whose scores differ by less than an fp32 ulp of the
+    score), so an utterance is compared only if the smallest gap between neighbouring candidates around the prune
+    boundary, over all its frames, exceeds 1e-4 (`return_margin`); at least four must qualify (seven do for this
+    seed on the CPU).  The long utterances are checked for shape, order and against a single-utterance call."""
+    import wenet_celoss_amd as w
+    torch.manual_seed(0)
+    V, E, P, J, H, L, B, T, beam = 5000, 256, 256, 512, 256, 2, 16, 1500, 8
+    pred = w.RNNPredictor(V, P, P, 0.1, H, L).eval()
+    joint = w.TransducerJoint(V, E, P, J).eval()
+    ctc = w.CTC(V, E).eval()
+    with torch.no_grad():
+        joint.ffn_out.weight *= 10
+        joint.ffn_out.bias[0] += 13
+        ctc.ctc_lo.weight *= 10
+        ctc.ctc_lo.bias[0] += 13
+    enc = torch.randn(B, T, E)
+    lens = [1500, 1500, 1000, 700, 400, 250, 150, 120, 100, 90, 80, 70, 60, 50, 40, 30]
+    p = do.Predictor({k: v.detach().numpy() for k, v in pred.state_dict().items()}, L)
+    j = do.Joint({k: v.detach().numpy() for k, v in joint.state_dict().items()})
+    cw = {k: v.detach().numpy() for k, v in ctc.state_dict().items()}
+    pred, joint, ctc = pred.to(DEV), joint.to(DEV), ctc.to(DEV)
+    bs = w.PrefixBeamSearch(torch.nn.Identity(), pred, joint, ctc, 0)
+    enc_d = enc.to(DEV)
+    res = bs.search_encoded(enc_d, torch.tensor(lens), beam, 0.3, 0.7)
+    assert len(res) == B
+    for b in range(B):
+        assert len(res[b]) == beam
+        sc = [s.score for s in res[b]]
+        assert sc == sorted(sc, reverse=True) and all(s.hyp[0] == 0 and len(s.hyp) <= lens[b] + 1 for s in res[b])
+    compared, margins = 0, []
+    for i in range(6, B):
+        ref, margin = do.prefix_beam_search(p, j, cw, enc[i].numpy(), lens[i], beam_size=beam, ctc_weight=0.3,
+                                            transducer_weight=0.7, return_margin=True)
+        margins.append(margin)
+        if margin > 1e-4:
+            assert [s["hyp"] for s in ref] == [s.hyp for s in res[i]], (i, margin)
+            np.testing.assert_allclose([s.score for s in res[i]], [s["score"] for s in ref], rtol=1e-5)
+            compared += 1
+    assert compared >= 4, margins
+    # a full-length utterance decoded alone gives what it gave inside the batch
+    single = bs.search_encoded(enc_d[1:2].contiguous(), torch.tensor([lens[1]]), beam, 0.3, 0.7)[0]
+    assert [s.hyp for s in single] == [s.hyp for s in res[1]]
+    np.testing.assert_allclose([s.score for s in single], [s.score for s in res[1]], rtol=1e-6)
+
+
+def test_config3_chunked_streams_match_reference_loop():
+    """BASELINE config 3 in its deployment form: reset_cache(64) + forward_greedy_search over chunks of 16 encoder
+    frames (67 fbank frames per chunk, asr_model.py:580-581), V=5000, E=P=256, J=512, LSTM 2x256, n_steps=64.
+    EVERY stream is compared, chunk by chunk, with the numpy restatement of the reference's streaming loop
+    ("transducer ref.py":541-606; pinned to the reference by the greedy_stream_* fixtures), and -- with the pending
+    predictor state kept -- with the offline loop on the concatenated frames.  Streams whose smallest top-1 / top-2
+    log-prob gap is below 1e-4 (ambiguous under fp32 summation order) are counted, not compared."""
+    import wenet_celoss_amd as w
+    torch.manual_seed(7)
+    V, E, P, J, H, L, N, C, n_chunks = 5000, 256, 256, 512, 256, 2, 64, 16, 3
+    pred = w.RNNPredictor(V, P, P, 0.1, H, L).to(DEV).eval()
+    joint = w.TransducerJoint(V, E, P, J).to(DEV).eval()
+    with torch.no_grad():                        # spread the logits (clear margins) and favour blank
+        joint.ffn_out.weight *= 10
+        joint.ffn_out.bias[0] += 12.0
+    m = w.Transducer(V, 0, torch.nn.Identity(), pred, joint, ctc_weight=0.0, transducer_weight=1.0, hw_weight=0.0)
+    enc = torch.randn(N, C * n_chunks, E, device=DEV)
+    chunk_lens = [torch.full((N,), C), torch.full((N,), C), torch.randint(5, C + 1, (N,))]
+    p = do.Predictor({k: v.detach().cpu().numpy() for k, v in pred.state_dict().items()}, L)
+    j = do.Joint({k: v.detach().cpu().numpy() for k, v in joint.state_dict().items()})
+    enc_np = enc.cpu().numpy()
+    for quirk in (True, False):
+        m.reset_cache(N, chunk_frames=C, n_steps=64)
+        got = [[] for _ in range(N)]
+        for c in range(n_chunks):
+            res = m.forward_greedy_search(enc[:, c * C:(c + 1) * C].contiguous(), chunk_lens[c], n_steps=64,
+                                          reference_new_cache=quirk)
+            for i in range(N):
+                got[i].append(res[i])
+        compared = 0
+        emitted = 0
+        for i in range(N):
+            ref = do.StreamingGreedy(p, j)
+            want = [ref.forward_greedy_search(enc_np[i, c * C:(c + 1) * C], int(chunk_lens[c][i]), n_steps=64,
+                                              reference_new_cache=quirk) for c in range(n_chunks)]
+            if ref.min_margin > 1e-4:
+                assert got[i] == want, (quirk, i, ref.min_margin)
+                compared += 1
+                emitted += sum(len(x) for x in want)
+            if not quirk and ref.min_margin > 1e-4:  # chunked with the pending state kept == offline on the valid frames
+                cat = np.concatenate([enc_np[i, c * C:c * C + int(chunk_lens[c][i])] for c in range(n_chunks)])
+                off = do.greedy_search(p, j, cat, cat.shape[0], n_steps=64)
+                assert [t for ch in got[i] for t in ch] == off, i
+        assert compared >= 48, compared                # at most a quarter of the streams may be ambiguous
+        assert emitted > compared                      # the scenario emits tokens
+
+
 def test_streaming_chunks_equal_offline_and_reference_quirk():
     """Chunk-synchronous greedy ("transducer ref.py":541-606): with the pending predictor state kept, decoding
     chunk by chunk equals decoding the concatenated frames; with `reference_new_cache=True` it equals the
@@ -403,3 +500,57 @@ def test_prefix_beam_many_utterances_equal_single():
         single = bs.search_encoded(encs[b:b + 1, :int(lens[b])].contiguous(), lens[b:b + 1], beam_size=5)[0]
         assert [s.hyp for s in single] == [s.hyp for s in batch[b]], b
         np.testing.assert_allclose([s.score for s in single], [s.score for s in batch[b]], rtol=1e-6)
+
+
+def test_decoder_cache_sees_data_edits_and_survives_copies():
+    """The handle holds re-laid copies of the weights.  An in-place edit through `.data` (EMA, weight averaging)
+    changes neither data_ptr nor the version counter; the cache's content fingerprint must still rebuild the handle.
+    A model that has decoded can be deep-copied and pickled (the native handle is dropped, rebuilt lazily)."""
+    import copy
+    import io
+    import wenet_celoss_amd as w
+    d = np.load(names("greedy_core_0.npz")[0])
+    pred, joint, _ = build_modules(d)
+    m = w.Transducer(64, 0, torch.nn.Identity(), pred, joint, ctc_weight=0.0, transducer_weight=1.0, hw_weight=0.0)
+    enc = torch.tensor(d["enc"], device=DEV)
+    T, n_steps = int(d["T"]), int(d["n_steps"])
+    first = w.basic_greedy_search(m, enc, torch.tensor(T), n_steps=n_steps)
+    assert first == [list(d["hyp"])]
+    dec0 = m._decoder_cache._dec
+    assert w.basic_greedy_search(m, enc, torch.tensor(T), n_steps=n_steps) == first
+    assert m._decoder_cache._dec is dec0                    # unchanged weights: the handle is reused
+    ver = joint.ffn_out.bias._version
+    joint.ffn_out.bias.data[0] -= 40.0                      # blank can no longer win
+    assert joint.ffn_out.bias._version == ver               # ... and nothing but the content says so
+    second = w.basic_greedy_search(m, enc, torch.tensor(T), n_steps=n_steps)
+    assert m._decoder_cache._dec is not dec0
+    p = do.Predictor(sub(d, "pred_"), int(d["n_layers"]))
+    jw = sub(d, "joint_"); jw["ffn_out.bias"] = jw["ffn_out.bias"].copy(); jw["ffn_out.bias"][0] -= 40.0
+    assert second == [do.greedy_search(p, do.Joint(jw), d["enc"][0], T, n_steps=n_steps)]
+    assert second != first
+    m2 = copy.deepcopy(m)
+    assert w.basic_greedy_search(m2, enc, torch.tensor(T), n_steps=n_steps) == second
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m3 = torch.load(buf, weights_only=False)                # a file this test wrote itself
+    assert w.basic_greedy_search(m3, enc, torch.tensor(T), n_steps=n_steps) == second
+    m._decoder_cache.invalidate()
+    assert m._decoder_cache._dec is None
+
+
+def test_ctc_loss_takes_half_precision_logits_outside_autocast():
+    """ctc.py's custom_fwd casts only under autocast; fp16/bf16 activations handed over directly are cast up too and
+    the gradient returns in the input dtype."""
+    import wenet_celoss_amd as w
+    torch.manual_seed(3)
+    x = torch.randn(2, 12, 9, device=DEV)
+    y = torch.tensor([[1, 2, 3], [4, 4, -1]], device=DEV)
+    il, tl = torch.tensor([12, 9], device=DEV), torch.tensor([3, 2], device=DEV)
+    ref = w.ctc_loss(x.clone().requires_grad_(True), y, il, tl)
+    for dt in (torch.float16, torch.bfloat16):
+        xh = x.to(dt).requires_grad_(True)
+        loss = w.ctc_loss(xh, y, il, tl)
+        loss.backward()
+        assert xh.grad.dtype == dt and torch.isfinite(xh.grad).all()
+        assert loss.item() == pytest.approx(ref.item(), rel=2e-2)

@@ -77,6 +77,90 @@ def test_world_size_2_gloo():
         assert r[2] == pytest.approx(want_true_mean)
 
 
+def _ddp_ctc_worker(rank, world, port, q):
+    """One rank of a CPU data-parallel step over the host logic that has a CPU form: balanced utterance shards
+    (dist.balanced_shards) -> wenet_celoss_amd.CTC (config 1's CPU path) under DistributedDataParallel with
+    join() / no_sync(), as wenet/utils/executor.py:48-53,81-86 drives it."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import wenet_celoss_amd as w
+    from wenet_celoss_amd.dist import balanced_shards, global_mean_of_rank_means
+    torch.manual_seed(3)
+    model = torch.nn.Sequential()
+    model.enc = torch.nn.Linear(6, 8)
+    model.ctc = w.CTC(11, 8)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.enc, self.ctc = model.enc, model.ctc
+
+        def forward(self, x, xl, y, yl):
+            return self.ctc(torch.tanh(self.enc(x)), xl, y, yl)
+    net = Net()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(5, 14, 6, generator=g)
+    xl = torch.tensor([14, 9, 12, 7, 14])
+    y = torch.randint(1, 11, (5, 3), generator=g)
+    yl = torch.tensor([3, 2, 3, 1, 2])
+    mine = balanced_shards([int(a) * (2 * int(b) + 1) for a, b in zip(xl, yl)], world)[rank]
+    ddp = torch.nn.parallel.DistributedDataParallel(net, find_unused_parameters=True)
+    with ddp.join():
+        with ddp.no_sync():
+            ddp(x[mine], xl[mine], y[mine], yl[mine]).backward()
+        loss = ddp(x[mine] * 0.5, xl[mine], y[mine], yl[mine])
+        loss.backward()
+    grads = {n: p.grad.clone() for n, p in net.named_parameters()}
+    q.put((rank, mine, {k: v.numpy() for k, v in grads.items()}, float(global_mean_of_rank_means(loss.detach()))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo_ddp_step_over_balanced_shards():
+    """N > 1 on CPU: two gloo ranks, uneven shards dealt by balanced_shards, DDP join()/no_sync() around the CTC
+    module; every rank ends with the mean over ranks of the accumulated per-rank gradients."""
+    import wenet_celoss_amd as w
+    from wenet_celoss_amd.dist import balanced_shards
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ddp_ctc_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res[0][1] + res[1][1]) == [0, 1, 2, 3, 4] and len(res[0][1]) != len(res[1][1])
+    # single-process reference
+    torch.manual_seed(3)
+    enc = torch.nn.Linear(6, 8)
+    ctc = w.CTC(11, 8)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(5, 14, 6, generator=g)
+    xl = torch.tensor([14, 9, 12, 7, 14])
+    y = torch.randint(1, 11, (5, 3), generator=g)
+    yl = torch.tensor([3, 2, 3, 1, 2])
+    shards = balanced_shards([int(a) * (2 * int(b) + 1) for a, b in zip(xl, yl)], 2)
+    want, losses = None, []
+    for mine in shards:
+        for p in list(enc.parameters()) + list(ctc.parameters()):
+            p.grad = None
+        ctc(torch.tanh(enc(x[mine])), xl[mine], y[mine], yl[mine]).backward()
+        l2 = ctc(torch.tanh(enc(x[mine] * 0.5)), xl[mine], y[mine], yl[mine])
+        l2.backward()
+        losses.append(float(l2))
+        gr = {"enc.weight": enc.weight.grad, "enc.bias": enc.bias.grad, "ctc.ctc_lo.weight": ctc.ctc_lo.weight.grad,
+              "ctc.ctc_lo.bias": ctc.ctc_lo.bias.grad}
+        want = {k: v.clone() / 2 for k, v in gr.items()} if want is None else {k: want[k] + v / 2 for k, v in gr.items()}
+    for r in res:
+        for k, v in want.items():
+            np.testing.assert_allclose(r[2][k], v.numpy(), rtol=1e-5, atol=1e-7, err_msg=k)
+        assert r[3] == pytest.approx(sum(losses) / 2, rel=1e-6)
+
+
 def test_transducer_constructor_contract():
     """Same keyword surface and weight-sum assertion as the reference (transducer.py:23-46)."""
     import wenet_celoss_amd as w
@@ -103,6 +187,11 @@ class _ScriptableEncoder(torch.nn.Module):
         mask = (torch.arange(xs.size(1))[None, :] < xs_lens[:, None]).unsqueeze(1)
         return torch.tanh(self.proj(xs)), mask
 
+    @torch.jit.export
+    def forward_chunk(self, xs: torch.Tensor, offset: int, required_cache_size: int, att_cache: torch.Tensor,
+                      cnn_cache: torch.Tensor):
+        return torch.tanh(self.proj(xs)), att_cache, cnn_cache
+
 
 def test_model_survives_train_py_script_export(tmp_path):
     """wenet/bin/train.py:203-205 does `torch.jit.script(model).save(init.zip)` on rank 0 before training; the
@@ -115,6 +204,29 @@ def test_model_survives_train_py_script_export(tmp_path):
     sm = torch.jit.script(m)
     sm.save(str(tmp_path / "init.zip"))
     assert (tmp_path / "init.zip").stat().st_size > 0
+    # the artefact exposes the reference's four step exports (transducer.py:600-629) and they compute the reference's
+    # module graphs (a scripted file cannot call the HIP library); checked against the modules' own weights
+    ld = torch.jit.load(str(tmp_path / "init.zip")).eval()
+    m.eval()
+    cache = ld.forward_predictor_init_state()
+    assert [tuple(c.shape) for c in cache] == [(2, 1, 14), (2, 1, 14)]
+    tok = torch.tensor([[5]])
+    out, new_cache = ld.forward_predictor_step(tok, cache)
+    with torch.no_grad():
+        ref_out, (rm, rc) = m.predictor.rnn(m.predictor.embed(tok), (cache[0], cache[1]))
+        ref_out = m.predictor.projection(ref_out)
+    torch.testing.assert_close(out, ref_out)
+    torch.testing.assert_close(new_cache[0], rm)
+    enc = torch.randn(1, 1, 12)
+    js = ld.forward_joint_step(enc, out)
+    with torch.no_grad():
+        ref = m.joint.ffn_out(torch.tanh(m.joint.enc_ffn(enc).unsqueeze(2) + m.joint.pred_ffn(out).unsqueeze(1)))
+    torch.testing.assert_close(js, ref)
+    y, _, _ = ld.forward_encoder_chunk(torch.randn(1, 4, 8), 0, -1)
+    assert y.shape == (1, 4, 12)
+    # eager mode never takes the export bodies: CPU tensors are refused by the HIP path
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m.forward_joint_step(enc, out)
 
 
 def test_joint_precision_selection(monkeypatch):

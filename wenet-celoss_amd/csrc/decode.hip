@@ -55,6 +55,7 @@ constexpr int kMaxLanes = 1024;      // streams (greedy) or utterances x beam de
 constexpr int kMaxBeam = 16;
 constexpr int kMaxLook = 4;          // greedy look-ahead: encoder frames evaluated per micro-step against one predictor state
 constexpr int kStepsPerGraph = 16;
+constexpr int kStageSlots = 4;
 
 struct Dims {
     int V, E, P, D, H, L, J;      // vocab, encoder dim, predictor out dim, embed dim, hidden, layers, join dim
@@ -1011,6 +1012,9 @@ struct wr_decoder {
     int max_utt, Tmax, max_hyp, max_beam;
     size_t zero_range[2];
     int32_t *h_active;            // pinned host word
+    DevState *h_stage;            // pinned staging slots for the state block (kStageSlots), so that the upload is a
+    hipEvent_t stage_ev[4];       // true async copy: a slot is reused only after the copy that read it has completed
+    int stage_next;
     hipStream_t work;             // decode work runs here (graph capture is illegal on the legacy default stream)
     hipEvent_t ev_in, ev_out;     // ordering against the caller's stream, no device-wide sync
     hipGraphExec_t greedy_graph[kMaxLook + 1];   // one per look-ahead setting
@@ -1213,15 +1217,22 @@ extern "C" int wr_decoder_create(const wr_transducer_weights *w, int max_lanes, 
     h->look = 0;
     h->stream_lanes = -1;
     h->h_active = nullptr;
-    if (hipHostMalloc(reinterpret_cast<void **>(&h->h_active), 64, hipHostMallocDefault) != hipSuccess) {
+    h->h_stage = nullptr;
+    h->stage_next = 0;
+    if (hipHostMalloc(reinterpret_cast<void **>(&h->h_active), 64, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&h->h_stage), kStageSlots * sizeof(DevState), hipHostMallocDefault) != hipSuccess) {
+        if (h->h_active) (void)hipHostFree(h->h_active);
         delete h;
         set_error("decoder_create: hipHostMalloc failed");
         return WR_ELAUNCH;
     }
-    if (hipStreamCreateWithFlags(&h->work, hipStreamNonBlocking) != hipSuccess ||
+    bool ev_ok = true;
+    for (int i = 0; i < kStageSlots; ++i) ev_ok = ev_ok && hipEventCreateWithFlags(&h->stage_ev[i], hipEventDisableTiming) == hipSuccess;
+    if (!ev_ok || hipStreamCreateWithFlags(&h->work, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) != hipSuccess) {
         (void)hipHostFree(h->h_active);
+        (void)hipHostFree(h->h_stage);
         delete h;
         set_error("decoder_create: stream/event creation failed");
         return WR_ELAUNCH;
@@ -1245,8 +1256,7 @@ extern "C" int wr_decoder_create(const wr_transducer_weights *w, int max_lanes, 
     launch_transpose(w->out_w, d.V, d.J, d.Vp, d.Jp, s.out_wt, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
-        (void)hipHostFree(h->h_active);
-        delete h;
+        (void)wr_decoder_destroy(h);
         set_error("decoder_create: weight preparation failed: %s", hipGetErrorString(e));
         return WR_ELAUNCH;
     }
@@ -1260,8 +1270,10 @@ extern "C" int wr_decoder_destroy(wr_decoder *h)
     for (int i = 0; i <= kMaxLook; ++i)
         if (h->greedy_graph[i]) (void)hipGraphExecDestroy(h->greedy_graph[i]);
     if (h->beam_graph) (void)hipGraphExecDestroy(h->beam_graph);
-    if (h->h_active) (void)hipHostFree(h->h_active);
     (void)hipStreamSynchronize(h->work);
+    if (h->h_active) (void)hipHostFree(h->h_active);
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
+    for (int i = 0; i < kStageSlots; ++i) (void)hipEventDestroy(h->stage_ev[i]);
     (void)hipEventDestroy(h->ev_in);
     (void)hipEventDestroy(h->ev_out);
     (void)hipStreamDestroy(h->work);
@@ -1288,7 +1300,13 @@ namespace {
 
 int upload_state(wr_decoder *h, hipStream_t st)
 {
-    hipError_t e = hipMemcpyAsync(h->dev, &h->host, sizeof(DevState), hipMemcpyHostToDevice, st);
+    // through a pinned slot: a copy from pageable memory would block the host until the work stream has drained
+    const int slot = h->stage_next;
+    h->stage_next = (slot + 1) % kStageSlots;
+    (void)hipEventSynchronize(h->stage_ev[slot]);                  // the copy that last read this slot (long done, normally)
+    h->h_stage[slot] = h->host;
+    hipError_t e = hipMemcpyAsync(h->dev, &h->h_stage[slot], sizeof(DevState), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipEventRecord(h->stage_ev[slot], st);
     if (e != hipSuccess) { set_error("decoder: state upload failed: %s", hipGetErrorString(e)); return WR_ELAUNCH; }
     return WR_OK;
 }
@@ -1334,6 +1352,18 @@ void leave(wr_decoder *h, hipStream_t caller)
     (void)hipStreamWaitEvent(caller, h->ev_out, 0);
 }
 
+// Scope of one entry point on the work stream: leave() runs on EVERY exit path, so the caller's stream is always
+// ordered after whatever was enqueued; unless ok() was called, the handle's streaming state and cached graphs are
+// dropped as well (a failed call leaves the lanes in an undefined state).
+struct WorkScope {
+    wr_decoder *h;
+    hipStream_t caller, st;
+    bool good = false;
+    WorkScope(wr_decoder *h_, hipStream_t caller_) : h(h_), caller(caller_), st(enter(h_, caller_)) {}
+    void ok() { good = true; }
+    ~WorkScope();
+};
+
 // Capture `reps` repetitions of `body` on `st` into an executable graph.
 template <typename F>
 int capture(hipStream_t st, int reps, F body, hipGraphExec_t *out)
@@ -1353,6 +1383,16 @@ int capture(hipStream_t st, int reps, F body, hipGraphExec_t *out)
 }  // namespace
 
 namespace {
+WorkScope::~WorkScope()
+{
+    if (!good) {
+        h->stream_lanes = -1;
+        for (int i = 0; i <= kMaxLook; ++i) h->greedy_graph_key[i] = -1;
+        h->beam_graph_lanes = -1;
+    }
+    leave(h, caller);
+}
+
 // mode 0: fresh utterances; 1: next chunk, keep the pending predictor state; 2: next chunk, reference quirk
 int greedy_run(wr_decoder *h, const float *enc_out_d, const int32_t *enc_lens_d, int N, int T, int n_steps, int blank,
                int32_t *hyps_d, int32_t *hyp_lens_d, void *stream, int mode)
@@ -1363,8 +1403,8 @@ int greedy_run(wr_decoder *h, const float *enc_out_d, const int32_t *enc_lens_d,
     WR_REQUIRE(n_steps >= 1 && blank >= 0 && blank < h->d.V, WR_EINVAL, "greedy_search: bad n_steps/blank");
     WR_REQUIRE(mode == 0 || h->stream_lanes == N, WR_EINVAL,
                "greedy_search_chunk: no stream state for %d lanes (call with reset first)", N);
-    hipStream_t caller = static_cast<hipStream_t>(stream);
-    hipStream_t st = enter(h, caller);
+    WorkScope scope(h, static_cast<hipStream_t>(stream));
+    hipStream_t st = scope.st;
     DevState &s = h->host;
     s.enc = enc_out_d; s.enc_lens = enc_lens_d; s.ctc_logp = nullptr;
     s.n_utt = N; s.T = T; s.lanes_per_utt = 1; s.n_lanes = N;
@@ -1410,8 +1450,8 @@ int greedy_run(wr_decoder *h, const float *enc_out_d, const int32_t *enc_lens_d,
             while (look > 1 && look * N > 256) look >>= 1;
         }
     }
-    leave(h, caller);
     WR_CHECK_LAUNCH("greedy_search");
+    scope.ok();
     return WR_OK;
 }
 }  // namespace
@@ -1444,8 +1484,8 @@ extern "C" int wr_prefix_beam_search(wr_decoder *h, const float *enc_out_d, cons
     WR_REQUIRE(T > 0 && T <= h->Tmax, WR_EINVAL, "prefix_beam_search: T=%d exceeds the decoder's Tmax=%d", T, h->Tmax);
     WR_REQUIRE(blank >= 0 && blank < h->d.V, WR_EINVAL, "prefix_beam_search: bad blank");
     h->stream_lanes = -1;                         // the lanes' streaming state (caches, tokens) is overwritten
-    hipStream_t caller = static_cast<hipStream_t>(stream);
-    hipStream_t st = enter(h, caller);
+    WorkScope scope(h, static_cast<hipStream_t>(stream));
+    hipStream_t st = scope.st;
     DevState &s = h->host;
     s.enc = enc_out_d; s.enc_lens = enc_lens_d; s.ctc_logp = ctc_logp_d;
     s.n_utt = B; s.T = T; s.lanes_per_utt = beam; s.n_lanes = B * beam;
@@ -1473,8 +1513,8 @@ extern "C" int wr_prefix_beam_search(wr_decoder *h, const float *enc_out_d, cons
         }
     }
     hipLaunchKernelGGL(beam_export_kernel, dim3(B), dim3(256), 0, st, h->dev, hyps_d, hyp_lens_d, scores_d, n_hyps_d);
-    leave(h, caller);
     WR_CHECK_LAUNCH("prefix_beam_search");
+    scope.ok();
     return WR_OK;
 }
 
@@ -1521,8 +1561,8 @@ extern "C" int wr_predictor_step(wr_decoder *h, const int32_t *tokens_d, const f
                "predictor_step: null pointer argument");
     WR_REQUIRE(N > 0 && N <= h->d.NL, WR_EINVAL, "predictor_step: N=%d exceeds the decoder's capacity %d", N, h->d.NL);
     h->stream_lanes = -1;                         // the lanes' streaming state (caches, tokens) is overwritten
-    hipStream_t caller = static_cast<hipStream_t>(stream);
-    hipStream_t st = enter(h, caller);
+    WorkScope scope(h, static_cast<hipStream_t>(stream));
+    hipStream_t st = scope.st;
     const Dims &d = h->d;
     DevState &s = h->host;
     s.n_utt = 1; s.T = 1; s.lanes_per_utt = d.NL; s.n_lanes = N; s.enc = nullptr; s.enc_lens = nullptr;
@@ -1535,7 +1575,7 @@ extern "C" int wr_predictor_step(wr_decoder *h, const int32_t *tokens_d, const f
     hipLaunchKernelGGL(cache_from_kmajor_kernel, dim3(32), dim3(256), 0, st, s.outT, N, 1, d.P, d.Pp, d.NLp, out_d);
     hipLaunchKernelGGL(cache_from_kmajor_kernel, dim3(64), dim3(256), 0, st, s.new_hT, N, d.L, d.H, d.Hp, d.NLp, new_h_d);
     hipLaunchKernelGGL(cache_from_kmajor_kernel, dim3(64), dim3(256), 0, st, s.new_cT, N, d.L, d.H, d.Hp, d.NLp, new_c_d);
-    leave(h, caller);
     WR_CHECK_LAUNCH("predictor_step");
+    scope.ok();
     return WR_OK;
 }

@@ -80,6 +80,14 @@ class DeviceDecoder:
         if look is not None:
             self.set_lookahead(int(look))
 
+    def _check(self, rc: int, what: str) -> None:
+        """A failed search leaves the handle's lane state undefined: mark it so that DecoderCache rebuilds it."""
+        if rc != 0:
+            self.poisoned = True
+        _lib.check(rc, what)
+
+    poisoned = False
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
@@ -107,7 +115,7 @@ class DeviceDecoder:
         with torch.cuda.device(self.device):
             rc = self._lib.wr_greedy_search(self._h, _lib.ptr(enc), _lib.ptr(lens), N, T, int(n_steps), int(blank),
                                             _lib.ptr(hyps), _lib.ptr(hl), _lib.current_stream(self.device))
-        _lib.check(rc, "wr_greedy_search")
+        self._check(rc, "wr_greedy_search")
         hl_c, hy_c = hl.cpu().tolist(), hyps.cpu()
         if max(hl_c, default=0) > self.max_hyp:
             raise RuntimeError(f"greedy search produced {max(hl_c)} tokens but the decoder was sized for {self.max_hyp}")
@@ -125,7 +133,7 @@ class DeviceDecoder:
             rc = self._lib.wr_greedy_search_chunk(self._h, _lib.ptr(enc), _lib.ptr(lens), N, T, int(n_steps), int(blank),
                                                   int(reset), int(reference_new_cache), _lib.ptr(hyps), _lib.ptr(hl),
                                                   _lib.current_stream(self.device))
-        _lib.check(rc, "wr_greedy_search_chunk")
+        self._check(rc, "wr_greedy_search_chunk")
         hl_c, hy_c = hl.cpu().tolist(), hyps.cpu()
         if max(hl_c, default=0) > self.max_hyp:
             raise RuntimeError(f"greedy search produced {max(hl_c)} tokens but the decoder was sized for {self.max_hyp}")
@@ -148,7 +156,7 @@ class DeviceDecoder:
             rc = self._lib.wr_prefix_beam_search(self._h, _lib.ptr(enc), _lib.ptr(lens), _lib.ptr(ctc), B, T, int(beam_size),
                                                  float(ctc_weight), float(transducer_weight), int(blank), _lib.ptr(hyps),
                                                  _lib.ptr(hl), _lib.ptr(sc), _lib.ptr(nh), _lib.current_stream(self.device))
-        _lib.check(rc, "wr_prefix_beam_search")
+        self._check(rc, "wr_prefix_beam_search")
         hyps, hl, sc, nh = hyps.cpu(), hl.cpu().tolist(), sc.cpu().tolist(), nh.cpu().tolist()
         out = []
         for b in range(B):
@@ -165,27 +173,62 @@ class DeviceDecoder:
         with torch.cuda.device(self.device):
             rc = self._lib.wr_predictor_step(self._h, _lib.ptr(tok), _lib.ptr(ch), _lib.ptr(cc), N, _lib.ptr(out),
                                              _lib.ptr(nh), _lib.ptr(nc), _lib.current_stream(self.device))
-        _lib.check(rc, "wr_predictor_step")
+        self._check(rc, "wr_predictor_step")
         return out, nh, nc
 
 
-def _weights_key(predictor, joint):
-    ps = list(predictor.parameters()) + list(joint.parameters())
+def _params(predictor, joint):
+    return list(predictor.parameters()) + list(joint.parameters())
+
+
+def _weights_key(ps):
     return tuple((p.data_ptr(), p._version) for p in ps)
 
 
-class DecoderCache:
-    """Keeps a DeviceDecoder alive across calls and rebuilds it when the modules'
-    weights change or a call needs more capacity."""
+def _fingerprint(ps):
+    """Content fingerprint of the weights (L2 norm and plain sum of every parameter, computed on the device):
+    `p.data.mul_()`-style edits (EMA, weight averaging) leave data_ptr and _version unchanged, and the handle holds
+    re-laid copies of the weights, so identity alone would let it decode with stale weights."""
+    with torch.no_grad():
+        flat = [p.detach() for p in ps]
+        return torch.stack(list(torch._foreach_norm(flat)) + [t.sum(dtype=torch.float32) for t in flat])
 
-    def __init__(self):
+
+class DecoderCache:
+    """Keeps a DeviceDecoder alive across calls and rebuilds it when the modules' weights change (identity, version
+    counter or -- with `check_content` -- the content fingerprint above) or a call needs more capacity.
+    `invalidate()` forces a rebuild.  Copies and pickles of a module that owns a cache get an empty cache (the
+    native handle is rebuilt lazily)."""
+
+    def __init__(self, check_content: bool = True):
         self._dec = None
         self._key = None
+        self._fp = None
+        self._check_content = check_content
+
+    def invalidate(self) -> None:
+        self._dec, self._key, self._fp = None, None, None
+
+    def __deepcopy__(self, memo):
+        return DecoderCache(self._check_content)
+
+    def __reduce__(self):
+        return (DecoderCache, (self._check_content,))
+
+    def discard(self, dec) -> None:
+        """Drop `dec` if it is the cached handle (called when a search on it raised: its lane state is undefined)."""
+        if self._dec is dec:
+            self.invalidate()
 
     def get(self, predictor, joint, lanes: int, utts: int, tmax: int, max_hyp: int, beam: int) -> DeviceDecoder:
-        key = _weights_key(predictor, joint)
+        ps = _params(predictor, joint)
+        key = _weights_key(ps)
         d = self._dec
-        same = d is not None and key == self._key
+        same = d is not None and key == self._key and not d.poisoned
+        fp = None
+        if same and self._check_content:
+            fp = _fingerprint(ps)
+            same = self._fp is not None and self._fp.device == fp.device and torch.equal(fp, self._fp)
         if not same or lanes > d.max_lanes or utts > d.max_utt or tmax > d.tmax or max_hyp > d.max_hyp or beam > d.max_beam:
             grow = (lambda new, old: max(new, old)) if same else (lambda new, old: new)
             caps = (grow(lanes, d.max_lanes if d else 0), grow(utts, d.max_utt if d else 0), grow(tmax, d.tmax if d else 0),
@@ -193,4 +236,5 @@ class DecoderCache:
             self._dec = None            # release the old handle before building the new one
             self._dec = DeviceDecoder(predictor, joint, *caps)
             self._key = key
+            self._fp = (fp if fp is not None else _fingerprint(ps)) if self._check_content else None
         return self._dec

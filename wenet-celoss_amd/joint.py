@@ -188,6 +188,18 @@ class TransducerJoint(nn.Module):
         self.post_ffn: Optional[nn.Linear] = None
         self.ffn_out = nn.Linear(join_dim, voca_size)
 
+    def _export_forward(self, enc_out: torch.Tensor, pred_out: torch.Tensor) -> torch.Tensor:
+        """TorchScript-export body of the joiner for the step export `forward_joint_step` (transducer.py:619-622):
+        a scripted artefact cannot reach the ctypes library, so it carries the reference's module graph
+        (joint.py:55-69).  Never executed in eager mode -- `forward` below is the only eager entry."""
+        enc = enc_out
+        pred = pred_out
+        if self.enc_ffn is not None and self.pred_ffn is not None:
+            enc = self.enc_ffn(enc_out)
+            pred = self.pred_ffn(pred_out)
+        out = torch.tanh(enc.unsqueeze(2) + pred.unsqueeze(1))
+        return self.ffn_out(out)
+
     @torch.jit.unused      # backed by a ctypes autograd Function: opaque to TorchScript (train.py:203-205 smoke export)
     def forward(self, enc_out: torch.Tensor, pred_out: torch.Tensor,
                 logit_lengths: Optional[torch.Tensor] = None,

@@ -46,7 +46,8 @@ class RNNPredictor(nn.Module):
         self.rnn = nn.LSTM(input_size=embed_size, hidden_size=hidden_size, num_layers=num_layers, bias=bias,
                            batch_first=True, dropout=dropout)
         self.projection = nn.Linear(hidden_size, output_size)
-        self._step_cache = DecoderCache()
+        self._step_cache = DecoderCache(check_content=False)   # per-token calls: identity + version only;
+                                                               # after editing weights through .data call invalidate()
         self._step_joint = None
 
     def forward(self, input: torch.Tensor, cache: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
@@ -81,7 +82,31 @@ class RNNPredictor(nn.Module):
     def forward_step(self, input: torch.Tensor, padding: torch.Tensor, cache: List[torch.Tensor]
                      ) -> Tuple[torch.Tensor, List[torch.Tensor]]:
         """input (N, 1) tokens, padding (N, 1) (1 keeps the old state), cache [m (L,N,H), c (L,N,H)]
-        -> (out (N, 1, output_size), [m, c])   (predictor.py:179-200; eval semantics: dropout off)."""
+        -> (out (N, 1, output_size), [m, c])   (predictor.py:179-200; eval semantics: dropout off).
+        Eager calls always run the HIP step kernels.  Only inside a TorchScript artefact (torch.jit.script(model),
+        wenet/bin/train.py:203-205, export_jit.py) -- which cannot reach a ctypes library -- the step is the plain
+        module graph `_export_step`, so that the exported file keeps the reference's runtime contract."""
+        if torch.jit.is_scripting():
+            return self._export_step(input, padding, cache)
+        else:
+            return self._hip_step(input, padding, cache)
+
+    def _export_step(self, input: torch.Tensor, padding: torch.Tensor, cache: List[torch.Tensor]
+                     ) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+        """TorchScript-export body of forward_step (never executed in eager mode): the reference's statements,
+        predictor.py:179-200."""
+        assert len(cache) == 2
+        state_m, state_c = cache[0], cache[1]
+        embed = self.dropout(self.embed(input))
+        out, (m, c) = self.rnn(embed, (state_m, state_c))
+        out = self.projection(out)
+        m = ApplyPadding(m, padding.unsqueeze(0), state_m)
+        c = ApplyPadding(c, padding.unsqueeze(0), state_c)
+        return out, [m, c]
+
+    @torch.jit.unused
+    def _hip_step(self, input: torch.Tensor, padding: torch.Tensor, cache: List[torch.Tensor]
+                  ) -> Tuple[torch.Tensor, List[torch.Tensor]]:
         assert len(cache) == 2
         state_m, state_c = cache
         N = input.size(0)

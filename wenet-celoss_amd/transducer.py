@@ -277,7 +277,7 @@ class Transducer(nn.Module):
                                                              num_decoding_left_chunks=num_decoding_left_chunks,
                                                              simulate_streaming=simulate_streaming)
             beam_score = [hyp[1] for hyp in hyps]
-            hyps = [list(hyp[0]) for hyp in hyps]
+            hyps = [hyp[0] for hyp in hyps]                                 # prefix tuples, as the reference keeps them
         else:
             raise ValueError(f"unknown beam_search_type {beam_search_type!r}")
         assert len(hyps) == beam_size
@@ -367,17 +367,31 @@ class Transducer(nn.Module):
         return hyps[0] if N == 1 else hyps
 
     # ----------------------------------------------------- step exports (:600-629) --
-    def forward_encoder_chunk(self, xs, offset: int, required_cache_size: int, att_cache=torch.zeros(0, 0, 0, 0),
-                              cnn_cache=torch.zeros(0, 0, 0, 0)):
+    # @torch.jit.export as in the reference, so that torch.jit.script(model) (train.py:203-205, export_jit.py) yields an
+    # artefact with the four step methods the C++ runtime calls (runtime/core/decoder/torch_asr_model.cc).  Eager calls
+    # run the HIP kernels; inside the scripted artefact -- which cannot reach a ctypes library -- the predictor step and
+    # the joiner are their plain module graphs (`_export_step`, `_export_forward`).
+    @torch.jit.export
+    def forward_encoder_chunk(self, xs: torch.Tensor, offset: int, required_cache_size: int,
+                              att_cache: torch.Tensor = torch.zeros(0, 0, 0, 0),
+                              cnn_cache: torch.Tensor = torch.zeros(0, 0, 0, 0)
+                              ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         return self.encoder.forward_chunk(xs, offset, required_cache_size, att_cache, cnn_cache)
 
-    def forward_predictor_step(self, xs: torch.Tensor, cache: List[torch.Tensor]):
+    @torch.jit.export
+    def forward_predictor_step(self, xs: torch.Tensor, cache: List[torch.Tensor]
+                               ) -> Tuple[torch.Tensor, List[torch.Tensor]]:
         assert len(cache) == 2
         padding = torch.zeros(1, 1, device=xs.device)
         return self.predictor.forward_step(xs, padding, cache)
 
+    @torch.jit.export
     def forward_joint_step(self, enc_out: torch.Tensor, pred_out: torch.Tensor) -> torch.Tensor:
-        return self.joint(enc_out, pred_out)
+        if torch.jit.is_scripting():
+            return self.joint._export_forward(enc_out, pred_out)
+        else:
+            return self.joint(enc_out, pred_out)
 
+    @torch.jit.export
     def forward_predictor_init_state(self) -> List[torch.Tensor]:
         return self.predictor.init_state(1, device=self.joint.ffn_out.weight.device)
