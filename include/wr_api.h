@@ -98,6 +98,18 @@ int wr_rnnt_loss_bwd(const void *logits_d, int dtype,
                      void *grads_d /* same shape/dtype as logits; may alias */,
                      const void *workspace_d, size_t workspace_bytes, void *stream);
 
+/* The lattice sweeps alone, for a workspace whose row statistics (denom and the skip / emit log-probabilities) were
+ * already produced by the joiner's fused epilogue (wr_joint_fwd_lse / wr_joint_fwd_split_lse below): pass 1 -- one
+ * full read of the logits -- is skipped.  The epilogue sums exponentials against the first logit a lane sees instead
+ * of a running maximum; if a row spreads over more than 88 nats that sum overflows, the epilogue raises a flag in
+ * the workspace and this entry point runs the stand-alone pass 1 over `logits_d` (fp32, as written by the joiner)
+ * before the sweeps -- otherwise that kernel returns at once.  costs as wr_rnnt_loss_fwd; wr_rnnt_loss_bwd follows
+ * unchanged. */
+int wr_rnnt_loss_fwd_from_lse(const float *logits_d, const int32_t *targets_d,
+                              const int32_t *logit_lengths_d, const int32_t *target_lengths_d,
+                              int B, int Tmax, int U1max, int V, int blank, float *costs_d /* [B] out */,
+                              void *workspace_d, size_t workspace_bytes, void *stream);
+
 /* Diagnostic view of the lattice state left in the workspace by wr_rnnt_loss_fwd
  * (tests compare alpha/beta with the oracle): copies alpha and beta into plain
  * [B, Tmax, U1max] float arrays (entries outside the valid region are 0). */
@@ -163,6 +175,18 @@ int wr_joint_fwd(const float *ep_d, const float *pp_d, const float *w_out_d, con
                  float *out_d /* [B,T,U1,V] */,
                  void *workspace_d, size_t workspace_bytes, void *stream);
 
+/* wr_joint_fwd with pass 1 of the RNN-T loss fused into its epilogue (transducer.py:132 + the first pass of :142-147):
+ * a forward workgroup owns every column of its 64 lattice cells, so while the logits leave for HBM it also writes
+ * denom(t,u) = logsumexp_v and the blank / label log-probabilities of every valid cell into the RNN-T workspace
+ * (wr_rnnt_workspace_bytes(B, T, U1)); wr_rnnt_loss_fwd_from_lse then only runs the lattice sweeps.  Both length
+ * arrays are required; targets [B, U1-1] as for wr_rnnt_loss_fwd. */
+int wr_joint_fwd_lse(const float *ep_d, const float *pp_d, const float *w_out_d, const float *b_out_d,
+                     const int32_t *logit_lengths_d, const int32_t *target_lengths_d, const int32_t *targets_d,
+                     int B, int T, int U1, int J, int V, int blank,
+                     float *out_d /* [B,T,U1,V] */,
+                     void *workspace_d, size_t workspace_bytes,
+                     void *rnnt_workspace_d, size_t rnnt_workspace_bytes, void *stream);
+
 int wr_joint_bwd_dz(const float *gout_d /* [B,T,U1,V] */, const float *ep_d, const float *pp_d,
                     const float *w_out_d,
                     const int32_t *logit_lengths_d /* nullable */, const int32_t *target_lengths_d /* nullable */,
@@ -183,6 +207,14 @@ int wr_joint_fwd_split(const float *ep_d, const float *pp_d, const float *w_out_
                        int B, int T, int U1, int J, int V, int terms,
                        void *out_d /* [B,T,U1,V] */, int out_dtype,
                        void *workspace_d, size_t workspace_bytes, void *stream);
+
+/* wr_joint_fwd_split with the RNN-T loss's row statistics fused into the epilogue (see wr_joint_fwd_lse); fp32 logits. */
+int wr_joint_fwd_split_lse(const float *ep_d, const float *pp_d, const float *w_out_d, const float *b_out_d,
+                           const int32_t *logit_lengths_d, const int32_t *target_lengths_d, const int32_t *targets_d,
+                           int B, int T, int U1, int J, int V, int blank, int terms,
+                           float *out_d /* [B,T,U1,V] */,
+                           void *workspace_d, size_t workspace_bytes,
+                           void *rnnt_workspace_d, size_t rnnt_workspace_bytes, void *stream);
 
 /* wr_joint_bwd_dz on the bf16 matrix cores, same split as wr_joint_fwd_split (terms = 3: gout and w_out split into
  * bf16 hi + lo, three MFMA terms, fp32 accumulation; terms = 1: single bf16 product).  Same outputs as

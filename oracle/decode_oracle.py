@@ -182,6 +182,136 @@ class StreamingGreedy:
         return hyps
 
 
+# ---------------------------------------------- hot-word greedy search, the fork's default --
+def _layer_norm(x, w, b, eps=1e-5):
+    x = x.astype(F)
+    mu = x.mean(-1, keepdims=True, dtype=F)
+    var = ((x - mu) ** 2).mean(-1, keepdims=True, dtype=F)
+    return ((x - mu) / np.sqrt(var + F(eps)) * w + b).astype(F)
+
+
+class ContextBiasNP:
+    """The per-step part of /root/reference/wenet/transformer/context_bias.py::ContextBias that the greedy loops call
+    (weights keyed like its state_dict):
+      forward_predictor_bias  :375-381  MultiHeadedAttention(query = predictor step, key = value = bias_hidden)
+                              (attention.py:47-113,153-186) -> predictor_bias_bias_norm -> cat -> predictor_bias_combine
+                              -> predictor_bias_out_norm; returns (biased output, bias feature)
+      forward_hw_pred_both    :388-394  hw_output_layer_enc / _dec -> hw_bias attention -> hw_bias_norm -> hw_output_layer
+    The loop-invariant parts (forward_bias_hidden, forward_encoder_bias) are taken as data."""
+
+    def __init__(self, w, heads, hw_heads):
+        self.w = {k: np.asarray(v, F) for k, v in w.items()}
+        self.h, self.hw_h = int(heads), int(hw_heads)
+
+    def _lin(self, name, x):
+        return (x @ self.w[name + ".weight"].T + self.w[name + ".bias"]).astype(F)
+
+    def _mha(self, name, heads, query, memory):
+        """query (Tq, D), memory (Tk, D) -> (Tq, D); no mask, dropout 0 (attention.py:153-186)."""
+        q, k, v = self._lin(name + ".linear_q", query), self._lin(name + ".linear_k", memory), self._lin(name + ".linear_v", memory)
+        D = q.shape[-1]
+        dk = D // heads
+        out = np.zeros_like(q)
+        for h in range(heads):
+            sl = slice(h * dk, (h + 1) * dk)
+            sc = (q[:, sl] @ k[:, sl].T / F(math.sqrt(dk))).astype(F)
+            sc = sc - sc.max(-1, keepdims=True)
+            e = np.exp(sc).astype(F)
+            att = (e / e.sum(-1, keepdims=True, dtype=F)).astype(F)
+            out[:, sl] = att @ v[:, sl]
+        return self._lin(name + ".linear_out", out)
+
+    def forward_predictor_bias(self, hidden, pred):
+        """hidden (Nc, D), pred (1, D) -> (biased (1, D), bias feature (1, D))"""
+        pb = self._mha("predictor_bias", self.h, pred, hidden)
+        pb = _layer_norm(pb, self.w["predictor_bias_bias_norm.weight"], self.w["predictor_bias_bias_norm.bias"])
+        cat = np.concatenate([pred, pb], -1)
+        out = _layer_norm(self._lin("predictor_bias_combine", cat), self.w["predictor_bias_out_norm.weight"],
+                          self.w["predictor_bias_out_norm.bias"])
+        return out, pb
+
+    def forward_hw_pred_both(self, enc_bias_step, pred_bias_step):
+        """(1, D), (1, D) -> gate logits (n_labels,)"""
+        e = self._lin("hw_output_layer_enc", enc_bias_step)
+        d = self._lin("hw_output_layer_dec", pred_bias_step)
+        hb = self._mha("hw_bias", self.hw_h, d, e)
+        hb = _layer_norm(hb, self.w["hw_bias_norm.weight"], self.w["hw_bias_norm.bias"])
+        return self._lin("hw_output_layer", hb)[0]
+
+
+def greedy_search_both(pred: Predictor, joint: Joint, cb: ContextBiasNP, hidden, hidden_empty, enc_hot, enc_hot_feat,
+                       enc_cold, T, labels, blank=0, n_steps=64, filter_on=False):
+    """/root/reference/wenet/transducer/search/greedy_search.py:297-430 (`basic_greedy_search_both`) for one
+    utterance, from the loop-invariant tensors on: hidden (Nc, D) / hidden_empty (1, D) = forward_bias_hidden of the
+    hot-word list / of the empty list (:327-333), enc_hot / enc_hot_feat / enc_cold (T, D) = forward_encoder_bias
+    (:335-336).  Returns (hyps, dist, gate trace, number of joiner decisions)."""
+    cache = pred.init_state(1)
+    new_cache = cache
+    tok = np.array([blank])
+    padding = np.zeros((1, 1), F)
+    t, hyps, result = 0, [], []
+    prev_nblk, per_frame = True, 0
+    go_back, go_back_end, last_t = False, -1, 0
+    steps, caches, inputs = [], [], []
+    out, decisions = None, 0
+    while t < T:
+        if prev_nblk:
+            raw, new_cache = pred.forward_step(tok, padding, cache)
+            steps.append(raw); caches.append(cache); inputs.append(tok)
+            out, feat = cb.forward_predictor_bias(hidden, raw)
+            gate = int(np.argmax(cb.forward_hw_pred_both(enc_hot_feat[t][None, :], feat)))   # topk(1): first maximum
+            if filter_on:
+                if not go_back:
+                    if gate == 0:
+                        result.append(0)
+                        last_t = t
+                    else:
+                        if result and result[-1] == 0:
+                            go_back_end, t, go_back = t, last_t, True
+                            result.pop(); hyps.pop(); inputs.pop()
+                            per_frame -= 1
+                            steps.pop(); caches.pop()
+                            out, cache, tok = steps[-1], caches[-1], inputs[-1]
+                            continue
+                        result.append(1)
+                else:
+                    result.append(1)
+                    if t >= go_back_end:
+                        go_back = False
+            else:
+                result.append(1)
+            if result[-1] == 0:
+                out, _ = cb.forward_predictor_bias(hidden_empty, raw)
+        e = (enc_hot if result[-1] == 1 else enc_cold)[t][None, :]
+        lp = log_softmax(joint(e, out))[0]
+        k = int(lp.argmax())
+        decisions += 1
+        if k != blank:
+            hyps.append(k)
+            prev_nblk = True
+            per_frame += 1
+            tok = np.array([k])
+            cache = new_cache
+        if k == blank or per_frame >= n_steps:
+            if k == blank:
+                prev_nblk = False
+            t += 1
+            per_frame = 0
+    return hyps, edit_distance(list(labels), result), result, decisions
+
+
+def edit_distance(a, b):
+    """greedy_search.py:6-32"""
+    m, n = len(a), len(b)
+    prev = list(range(n + 1))
+    for i in range(1, m + 1):
+        cur = [i] + [0] * n
+        for j in range(1, n + 1):
+            cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (0 if int(a[i - 1]) == int(b[j - 1]) else 1))
+        prev = cur
+    return float(prev[n])
+
+
 def ctc_log_softmax(w, enc):
     """ctc.py:66-75: log_softmax(ctc_lo(hs)).  enc (T,E) -> (T,V)"""
     return log_softmax(enc @ np.asarray(w["ctc_lo.weight"], F).T + np.asarray(w["ctc_lo.bias"], F))

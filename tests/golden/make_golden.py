@@ -530,6 +530,94 @@ def gen_greedy_stream():
              **{"joint_" + k: v for k, v in sd(joint).items()})
 
 
+def gen_greedy_both_real():
+    """The fork's default decode path with the REAL hot-word module: wenet/transducer/search/greedy_search.py:297-430
+    (`basic_greedy_search_both`) driving wenet/transformer/context_bias.py::ContextBias (BLSTM extractor, 'linear'
+    context encoder, MultiHeadedAttention biasing, hot-word classifier), context filter on and off.  The module's
+    weights travel as data; so do the loop-invariant tensors it computes before the loop (bias_hidden for the real and
+    the empty list, the two biased encoder outputs and the encoder-side bias feature), which pin the GPU tests'
+    mirror module (tests/context_bias_mirror.py).  The gate trace is the list the reference prints last
+    (greedy_search.py:428-429)."""
+    import ast
+    from wenet.transformer.context_bias import ContextBias
+    from wenet.transducer.search import greedy_search as gs
+    V, E, P, J, H = 64, 16, 16, 32, 16
+    HW = 8
+    cases = [dict(seed=700, T=40, filt="on", n_ctx=3, n_steps=64), dict(seed=701, T=40, filt="off", n_ctx=3, n_steps=64),
+             dict(seed=702, T=60, filt="on", n_ctx=5, n_steps=64), dict(seed=703, T=50, filt="on", n_ctx=2, n_steps=2, blank_bias=4.0),
+             dict(seed=704, T=70, filt="on", n_ctx=4, n_steps=64), dict(seed=705, T=30, filt="on", n_ctx=2, n_steps=64)]
+    for i, c in enumerate(cases):
+        for attempt in range(300):
+            seed = c["seed"] + 1000 * attempt
+            pred, joint, _ = build_decode_modules(seed, V, E, P, J, H, 2, blank_bias=c.get("blank_bias", 10.0), weight_scale=2.0)
+            torch.manual_seed(seed)
+            cb = ContextBias(input_size=E, output_size=E, vocab_size=V, embedding_size=E, num_layers=1, attention_heads=2,
+                             bias_encoder_type="linear", context_extractor="BLSTM", unified_hw_odim=HW,
+                             unified_hw_heads=2).eval()
+            with torch.no_grad():           # make the 2-class gate flip between frames: spread its input projection
+                cb.hw_output_layer_enc.weight.mul_(6.0)
+                cb.hw_output_layer.weight.mul_(4.0)
+            mj = MarginJoint(joint)
+            model = types.SimpleNamespace(blank=0, predictor=pred, joint=mj, context_bias=cb)
+            g = torch.Generator().manual_seed(seed + 7)
+            enc = dyadic((1, c["T"], E), g, scale=8, lim=2.0)
+            ctx = torch.randint(1, V, (c["n_ctx"], 4), generator=g)
+            ctx_len = torch.randint(2, 5, (c["n_ctx"],), generator=g).to(torch.int32)
+            ctx[0, 0], ctx_len[0] = 0, 1                               # row 0 = [0]: the "no hot word" entry the data
+            for r in range(c["n_ctx"]):                                # pipeline always puts first (processor.py:763-804)
+                ctx[r, ctx_len[r]:] = -1                               # IGNORE_ID padding as processor.padding produces
+            labels = torch.randint(0, 2, (1, 12), generator=g)
+            with torch.no_grad():           # centre the gate: shift its bias so that about half of the frames answer 1
+                hid = cb.forward_bias_hidden(ctx, ctx_len)
+                _, feat = cb.forward_encoder_bias(hid, enc)
+                gl = cb.forward_hw_pred_both(feat.transpose(0, 1), torch.zeros(c["T"], 1, E))[:, 0, :]
+                dsort = (gl[:, 0] - gl[:, 1]).sort().values
+                shift = float((dsort[c["T"] // 2 - 1] + dsort[c["T"] // 2]) / 2)
+                cb.hw_output_layer.bias[1] += shift
+                if float((dsort - shift).abs().min()) < 1e-3:
+                    continue                # a frame whose two gate logits nearly tie
+            buf = io.StringIO()
+            try:
+                with torch.no_grad(), contextlib.redirect_stdout(buf):
+                    hyps, dist = gs.basic_greedy_search_both(model, enc, torch.tensor(c["T"]), ctx, ctx_len,
+                                                             n_steps=c["n_steps"], context_filter_state=c["filt"],
+                                                             context_decoder_labels_padded=labels)
+            except IndexError:
+                continue
+            trace = ast.literal_eval(buf.getvalue().strip().splitlines()[-1])
+            n0, n1 = trace.count(0), trace.count(1)
+            # gate margins: the reference prints the 2-class gate logits of every predictor step
+            want_both = c["filt"] == "on"
+            if len(hyps[0]) < 5 or len(hyps[0]) > 4 * c["T"] or not margins_ok(mj.min_margin) or \
+                    (want_both and (n0 < 2 or n1 < 2)):
+                continue
+            if c["n_steps"] == 64 and len(hyps[0]) > 2 * c["T"]:
+                continue                    # a frame ran into the 64-token cap: keep these cases speech-like
+            # re-run to count go-backs (a 1 right after a 0 in the reference's own trace cannot occur with the filter on:
+            # the 0 is popped) -- use the number of joiner decisions beyond tokens + frames as the witness
+            break
+        else:
+            raise AssertionError(f"no usable seed for real-ContextBias case {i}")
+        with torch.no_grad():
+            hidden = cb.forward_bias_hidden(ctx, ctx_len)
+            hidden_empty = cb.forward_bias_hidden(torch.zeros((1, 1), dtype=torch.int), ctx_len[0].unsqueeze(0))
+            enc_hot, enc_hot_feat = cb.forward_encoder_bias(hidden, enc)
+            enc_cold, _ = cb.forward_encoder_bias(hidden_empty, enc.clone())
+            gate_logits = cb.forward_hw_pred_both(enc_hot_feat.transpose(0, 1), torch.zeros(c["T"], 1, E))[:, 0, :]
+        gmargin = float((gate_logits[:, 0] - gate_logits[:, 1]).abs().min())
+        print(f"  real-bias case {i}: seed {seed}, {len(hyps[0])} tokens, dist {dist}, trace zeros/ones {n0}/{n1}, "
+              f"{len(mj.decisions)} joiner decisions for {c['T']} frames, min margin {mj.min_margin:.4f}, gate margin {gmargin:.4f}")
+        save(f"greedy_both_real_{i}", enc=enc.numpy(), T=np.array(c["T"]), filt=np.array(c["filt"]),
+             n_steps=np.array(c["n_steps"]), seed=np.array(seed), ctx=ctx.numpy(), ctx_len=ctx_len.numpy(), labels=labels.numpy(),
+             hyp=np.array(hyps[0], np.int64), dist=np.array(float(dist)), trace=np.array(trace, np.int64),
+             n_decisions=np.array(len(mj.decisions)), min_margin=np.array(mj.min_margin), gate_margin=np.array(gmargin),
+             hidden=hidden.numpy(), hidden_empty=hidden_empty.numpy(), enc_hot=enc_hot.numpy(),
+             enc_hot_feat=enc_hot_feat.numpy(), enc_cold=enc_cold.numpy(), gate_logits=gate_logits.numpy(),
+             n_layers=np.array(2), hidden_size=np.array(H), heads=np.array(2), hw_dim=np.array(HW), hw_heads=np.array(2),
+             **{"pred_" + k: v for k, v in sd(pred).items()}, **{"joint_" + k: v for k, v in sd(joint).items()},
+             **{"cb_" + k: v for k, v in sd(cb).items()})
+
+
 def gen_common():
     from wenet.utils.common import add_blank, log_add
     ys = torch.tensor([[1, 2, 3, 4, 5], [4, 5, 6, -1, -1], [7, 8, 9, -1, -1]])
@@ -562,3 +650,4 @@ if __name__ == "__main__":
     gen_ctc_align()
     gen_greedy_fork()
     gen_greedy_stream()
+    gen_greedy_both_real()

@@ -33,6 +33,7 @@ def test_fixture_inventory():
     assert len(names("joint_ref_*.npz")) >= 2
     assert len(names("predictor_step_*.npz")) >= 2
     assert len(names("greedy_stream_*.npz")) >= 5
+    assert len(names("greedy_both_real_*.npz")) >= 6
 
 
 def test_common_helpers():
@@ -86,6 +87,28 @@ def test_streaming_greedy(name):
         assert got == list(d["chunk_tokens"][k:k + cnt]), (name, a, n)
         a += n
         k += cnt
+
+
+@pytest.mark.parametrize("name", names("greedy_both_real_*.npz"))
+def test_greedy_both_with_real_context_bias(name):
+    """The restated hot-word loop + ContextBias step arithmetic reproduce what the reference's
+    basic_greedy_search_both produced with its real ContextBias module: tokens, edit distance, gate trace and even the
+    number of joiner decisions (go-back re-decoding included)."""
+    d = load(name)
+    p = do.Predictor(sub(d, "pred_"), int(d["n_layers"]))
+    j = do.Joint(sub(d, "joint_"))
+    cb = do.ContextBiasNP(sub(d, "cb_"), int(d["heads"]), int(d["hw_heads"]))
+    hyps, dist, trace, n_dec = do.greedy_search_both(p, j, cb, d["hidden"][0], d["hidden_empty"][0], d["enc_hot"][0],
+                                                     d["enc_hot_feat"][0], d["enc_cold"][0], int(d["T"]), d["labels"][0],
+                                                     n_steps=int(d["n_steps"]), filter_on=str(d["filt"]) == "on")
+    assert hyps == list(d["hyp"])
+    assert trace == list(d["trace"])
+    assert dist == float(d["dist"])
+    assert n_dec == int(d["n_decisions"])
+    # the gate depends on the frame only: with a single key the attention weight is exactly 1 (see DESIGN.md)
+    for t in range(int(d["T"])):
+        g = cb.forward_hw_pred_both(d["enc_hot_feat"][0][t][None, :], np.zeros((1, d["enc_hot_feat"].shape[-1]), np.float32))
+        np.testing.assert_allclose(g, d["gate_logits"][t], rtol=1e-4, atol=1e-5)
 
 
 @pytest.mark.parametrize("name", names("prefix_beam_*.npz"))

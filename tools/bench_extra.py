@@ -310,9 +310,11 @@ def bench_step(args):
     y = torch.randint(1, V, (B, U), dtype=torch.int32, device=dev)
     ll = torch.full((B,), T, dtype=torch.int32, device=dev); tl = torch.full((B,), U, dtype=torch.int32, device=dev)
     base = None
-    for prec in ("fp32", "bf16x3", "bf16-autocast"):
+    for prec in ("fp32", "fp32-fused", "bf16x3", "bf16x3-fused", "bf16-autocast"):
         amp = prec == "bf16-autocast"                  # the --use_amp configuration (executor.py:91)
-        joint = w.TransducerJoint(V, E, P, J, precision="bf16" if amp else prec).to(dev)
+        fused = prec.endswith("-fused")                # joiner + loss as one node (fused.py): no pass 1, gradient in place
+        jprec = "bf16" if amp else prec.replace("-fused", "")
+        joint = w.TransducerJoint(V, E, P, J, precision=jprec).to(dev)
         torch.manual_seed(4)
         with torch.no_grad():
             for prm in joint.parameters():
@@ -321,8 +323,12 @@ def bench_step(args):
         def step():
             joint.zero_grad(set_to_none=True); enc.grad = None; pred.grad = None
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-                logits = joint(enc, pred)
-                loss = w.rnnt_loss(logits, y, ll, tl, blank=0, reduction="mean", inplace_grad=True)
+                if fused:
+                    loss = w.joint_rnnt_loss(joint.enc_ffn(enc), joint.pred_ffn(pred), joint.ffn_out.weight,
+                                             joint.ffn_out.bias, y, ll, tl, blank=0, reduction="mean", precision=jprec)
+                else:
+                    logits = joint(enc, pred)
+                    loss = w.rnnt_loss(logits, y, ll, tl, blank=0, reduction="mean", inplace_grad=True)
             loss.backward()
             return loss
         loss = step()

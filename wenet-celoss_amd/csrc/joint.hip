@@ -21,6 +21,7 @@
 //   written out for the weight-gradient GEMM.  d ep = sum_u dZ, d pp = sum_t dZ and
 //   dW = dY^T H are left to library reductions/GEMMs on the host side.
 #include "wr_common.hpp"
+#include "joint_lse.hpp"
 
 namespace wr {
 namespace {
@@ -74,116 +75,28 @@ __device__ __forceinline__ void fill_h_tile(float *__restrict__ Ht, const float 
 }
 
 // ---------------------------------------------------------------- forward --
-__global__ __launch_bounds__(256) void joint_fwd_kernel(
-    const float *__restrict__ ep, const float *__restrict__ pp, const float *__restrict__ wt /* [J, Vp] */,
-    const float *__restrict__ bias, const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens,
-    int B, int T, int U1, int J, int Jp, int V, int Vp, float *__restrict__ out)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *Ht = lds;                                  // [Jp][65]
-    float *Ws = lds + (size_t)Jp * kHPad;             // [2][kBK][kBN]
-    const long M = (long)B * T * U1;
-    const long m0 = (long)blockIdx.x * kBM;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-    // Skip tiles that lie entirely in the padded region of the lattice (never read by the loss).
-    if (llens != nullptr && tlens != nullptr) {
-        int valid = 0;
-        const long m = m0 + tid;
-        if (tid < kBM && m < M) {
-            const long bt = m / U1;
-            const int u = (int)(m - bt * U1);
-            const int b = (int)(bt / T), t = (int)(bt - (long)b * T);
-            valid = (t < llens[b]) && (u <= tlens[b]);
-        }
-        if (!__syncthreads_or(valid)) return;
-    }
-
-    fill_h_tile(Ht, ep, pp, m0, M, T, U1, J, Jp);
-
-    const int nslices = Jp / kBK;
-    const int nchunks = Vp / kBN;
-    // staging map: 256 threads x 2 float4 cover one [8][256] slice
-    const int srow = tid >> 6;            // 0..3 (+4 for the second half)
-    const int scol = (tid & 63) * 4;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int wcol = wave * 64;
-
-    for (int nc = 0; nc < nchunks; ++nc) {
-        const int v0 = nc * kBN;
-        f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-        // prologue: slice 0 -> buffer 0
-        {
-            const f32x4 r0 = *reinterpret_cast<const f32x4 *>(wt + (size_t)srow * Vp + v0 + scol);
-            const f32x4 r1 = *reinterpret_cast<const f32x4 *>(wt + (size_t)(srow + 4) * Vp + v0 + scol);
-            __syncthreads();              // previous chunk's readers are done with both buffers (and Ht is filled)
-            *reinterpret_cast<f32x4 *>(Ws + srow * kBN + scol) = r0;
-            *reinterpret_cast<f32x4 *>(Ws + (srow + 4) * kBN + scol) = r1;
-        }
-        __syncthreads();
-        for (int s = 0; s < nslices; ++s) {
-            const float *cur = Ws + (s & 1) * (kBK * kBN);
-            float *nxt = Ws + ((s + 1) & 1) * (kBK * kBN);
-            f32x4 r0 = {0, 0, 0, 0}, r1 = {0, 0, 0, 0};
-            const bool more = (s + 1 < nslices);
-            if (more) {
-                const int k = (s + 1) * kBK;
-                r0 = *reinterpret_cast<const f32x4 *>(wt + (size_t)(k + srow) * Vp + v0 + scol);
-                r1 = *reinterpret_cast<const f32x4 *>(wt + (size_t)(k + srow + 4) * Vp + v0 + scol);
-            }
-            const int kbase = s * kBK;
-#pragma unroll
-            for (int kk = 0; kk < kBK; kk += 2) {
-                const float a0 = Ht[(kbase + kk + half) * kHPad + l31];
-                const float a1 = Ht[(kbase + kk + half) * kHPad + 32 + l31];
-                const float b0 = cur[(kk + half) * kBN + wcol + l31];
-                const float b1 = cur[(kk + half) * kBN + wcol + 32 + l31];
-                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
-                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
-                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
-            }
-            if (more) {
-                *reinterpret_cast<f32x4 *>(nxt + srow * kBN + scol) = r0;
-                *reinterpret_cast<f32x4 *>(nxt + (srow + 4) * kBN + scol) = r1;
-            }
-            __syncthreads();
-        }
-        // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-        const int c0 = v0 + wcol + l31, c1 = c0 + 32;
-        const float bias0 = (c0 < V) ? bias[c0] : 0.f;
-        const float bias1 = (c1 < V) ? bias[c1] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const long ma = m0 + row, mb = m0 + 32 + row;
-            if (ma < M) {
-                if (c0 < V) out[(size_t)ma * V + c0] = acc00[r] + bias0;
-                if (c1 < V) out[(size_t)ma * V + c1] = acc01[r] + bias1;
-            }
-            if (mb < M) {
-                if (c0 < V) out[(size_t)mb * V + c0] = acc10[r] + bias0;
-                if (c1 < V) out[(size_t)mb * V + c1] = acc11[r] + bias1;
-            }
-        }
-    }
-}
-
-// Forward, variant 2: the streamed operand never touches LDS.  Each wave owns its own 64 output columns, so
+// The streamed operand never touches LDS.  Each wave owns its own 32 output columns per 256-column chunk, so
 // its B fragments (k-major W^T rows, 128 contiguous bytes per 32 columns) are not shared with the other
 // waves: they are loaded straight from L2 into registers, PFK k-steps ahead, and the k-loop has no barrier
 // and no LDS write at all -- only the read-only activation tile lives in LDS.
-template <int PFK, int CT /* 32-column tiles per wave: 2 -> 4 waves, 1 -> 8 waves */>
+// LSE = true: the epilogue also produces the RNN-T loss's row statistics (joint_lse.hpp) -- the workgroup owns
+// every column of its 64 cells, so pass 1 of the loss never has to read the logits back.
+template <int PFK, int CT /* 32-column tiles per wave: 1 -> 8 waves */, bool LSE>
 __global__ __launch_bounds__(CT == 2 ? 256 : 512) void joint_fwd_direct_kernel(
     const float *__restrict__ ep, const float *__restrict__ pp, const float *__restrict__ wt /* [Jp, Vp] */,
     const float *__restrict__ bias, const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens,
-    int B, int T, int U1, int J, int Jp, int V, int Vp, float *__restrict__ out)
+    int B, int T, int U1, int J, int Jp, int V, int Vp, float *__restrict__ out, JointLse lse)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *Ht = lds;                                  // [Jp][65]
     const long M = (long)B * T * U1;
     const long m0 = (long)blockIdx.x * kBM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float rm[32], rs[32];                             // LSE: this lane's (reference, partial sum) of its 32 rows
+    if (LSE) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { rm[i] = -3.0e38f; rs[i] = 0.f; }
+    }
 
     if (llens != nullptr && tlens != nullptr) {
         int valid = 0;
@@ -255,9 +168,15 @@ __global__ __launch_bounds__(CT == 2 ? 256 : 512) void joint_fwd_direct_kernel(
                 for (int r = 0; r < 16; ++r) {
                     const int row = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * half;   // C/D layout of the 32x32 MFMA
                     const long m = m0 + row;
-                    if (m < M && col < V) out[(size_t)m * V + col] = acc[rt][c][r] + bv;
+                    const float x = acc[rt][c][r] + bv;
+                    if (m < M && col < V) out[(size_t)m * V + col] = x;
+                    if (LSE) joint_lse_add(rm[rt * 16 + r], rs[rt * 16 + r], x, col < V, nc == 0 && c == 0);
                 }
         }
+    }
+    if (LSE) {
+        __syncthreads();                               // every wave is done with the activation tile: reuse its storage
+        joint_lse_finish<CT == 2 ? 4 : 8>(lse, lds, rm, rs, llens, tlens, out, m0, M, T, U1, V);
     }
 }
 
@@ -572,6 +491,40 @@ extern "C" size_t wr_joint_workspace_bytes(int J, int V)
     return align_up((size_t)joint_jpad(J) * joint_vpad(V) * sizeof(float), 256);
 }
 
+namespace {
+// shared body of wr_joint_fwd / wr_joint_fwd_lse
+int joint_fwd_launch(const float *ep_d, const float *pp_d, const float *w_out_d, const float *b_out_d,
+                     const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B, int T, int U1, int J, int V,
+                     float *out_d, void *workspace_d, size_t workspace_bytes, const JointLse *lse, hipStream_t st)
+{
+    const int Vp = joint_vpad(V), Jp = joint_jpad(J);
+    WR_REQUIRE(workspace_bytes >= (size_t)Jp * Vp * sizeof(float), WR_EWORKSPACE, "joint_fwd: workspace too small");
+    float *wt = static_cast<float *>(workspace_d);
+    hipLaunchKernelGGL(joint_transpose_w_kernel, dim3(Vp / 32, (Jp + 31) / 32), dim3(256), 0, st, w_out_d, V, J, Jp, Vp,
+                       wt);
+    WR_CHECK_LAUNCH("joint_transpose_w_kernel");
+    const long M = (long)B * T * U1;
+    const dim3 grid((unsigned)((M + kBM - 1) / kBM));
+    const size_t tile = (size_t)Jp * kHPad * sizeof(float);
+    if (lse == nullptr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_fwd_direct_kernel<8, 1, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile);
+        hipLaunchKernelGGL((joint_fwd_direct_kernel<8, 1, false>), grid, dim3(512), tile, st, ep_d, pp_d, wt, b_out_d,
+                           logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, out_d, JointLse{});
+    } else {
+        // the statistics exchange reuses the activation tile's storage
+        const size_t lds = tile > joint_lse_exchange_bytes(8) ? tile : joint_lse_exchange_bytes(8);
+        (void)hipMemsetAsync(lse->repair, 0, sizeof(int32_t), st);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_fwd_direct_kernel<8, 1, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((joint_fwd_direct_kernel<8, 1, true>), grid, dim3(512), lds, st, ep_d, pp_d, wt, b_out_d,
+                           logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, out_d, *lse);
+    }
+    WR_CHECK_LAUNCH("joint_fwd_direct_kernel");
+    return WR_OK;
+}
+}  // namespace
+
 extern "C" int wr_joint_fwd(const float *ep_d, const float *pp_d, const float *w_out_d, const float *b_out_d,
                             const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B, int T, int U1,
                             int J, int V, float *out_d, void *workspace_d, size_t workspace_bytes, void *stream)
@@ -580,34 +533,31 @@ extern "C" int wr_joint_fwd(const float *ep_d, const float *pp_d, const float *w
     WR_REQUIRE(ep_d && pp_d && w_out_d && b_out_d && out_d && workspace_d, WR_EINVAL, "joint_fwd: null pointer argument");
     WR_REQUIRE((logit_lengths_d == nullptr) == (target_lengths_d == nullptr), WR_EINVAL,
                "joint_fwd: pass both length arrays or neither");
-    const int Vp = joint_vpad(V), Jp = joint_jpad(J);
-    WR_REQUIRE(workspace_bytes >= (size_t)Jp * Vp * sizeof(float), WR_EWORKSPACE, "joint_fwd: workspace too small");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    float *wt = static_cast<float *>(workspace_d);
-    hipLaunchKernelGGL(joint_transpose_w_kernel, dim3(Vp / 32, (Jp + 31) / 32), dim3(256), 0, st, w_out_d, V, J, Jp, Vp,
-                       wt);
-    WR_CHECK_LAUNCH("joint_transpose_w_kernel");
-    const size_t lds = ((size_t)Jp * kHPad + 2 * kBK * kBN) * sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lds);
-    const long M = (long)B * T * U1;
-    const int variant = tune_get(kTuneJointFwdVariant);
-    if (variant == 0) {
-        hipLaunchKernelGGL(joint_fwd_kernel, dim3((unsigned)((M + kBM - 1) / kBM)), dim3(256), lds, st, ep_d, pp_d, wt,
-                           b_out_d, logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, out_d);
-    } else {
-        const size_t lds2 = (size_t)Jp * kHPad * sizeof(float);
-#define WR_LAUNCH_FWD2(PFK, CT)                                                                                      \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_fwd_direct_kernel<PFK, CT>),                    \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);                              \
-        hipLaunchKernelGGL((joint_fwd_direct_kernel<PFK, CT>), dim3((unsigned)((M + kBM - 1) / kBM)),                  \
-                           dim3(CT == 2 ? 256 : 512), lds2, st, ep_d, pp_d, wt, b_out_d, logit_lengths_d,              \
-                           target_lengths_d, B, T, U1, J, Jp, V, Vp, out_d)
-        if (variant == 2) { WR_LAUNCH_FWD2(8, 1); } else { WR_LAUNCH_FWD2(8, 2); }
-#undef WR_LAUNCH_FWD2
-    }
-    WR_CHECK_LAUNCH("joint_fwd_kernel");
-    return WR_OK;
+    return joint_fwd_launch(ep_d, pp_d, w_out_d, b_out_d, logit_lengths_d, target_lengths_d, B, T, U1, J, V, out_d,
+                            workspace_d, workspace_bytes, nullptr, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int wr_joint_fwd_lse(const float *ep_d, const float *pp_d, const float *w_out_d, const float *b_out_d,
+                                const int32_t *logit_lengths_d, const int32_t *target_lengths_d,
+                                const int32_t *targets_d, int B, int T, int U1, int J, int V, int blank, float *out_d,
+                                void *workspace_d, size_t workspace_bytes, void *rnnt_workspace_d,
+                                size_t rnnt_workspace_bytes, void *stream)
+{
+    if (int rc = joint_check(B, T, U1, J, V)) return rc;
+    WR_REQUIRE(ep_d && pp_d && w_out_d && b_out_d && out_d && workspace_d && rnnt_workspace_d, WR_EINVAL,
+               "joint_fwd_lse: null pointer argument");
+    WR_REQUIRE(logit_lengths_d && target_lengths_d, WR_EINVAL, "joint_fwd_lse: both length arrays are required");
+    WR_REQUIRE(targets_d || U1 == 1, WR_EINVAL, "joint_fwd_lse: targets is null");
+    WR_REQUIRE(blank >= 0 && blank < V, WR_EINVAL, "joint_fwd_lse: blank %d out of range [0,%d)", blank, V);
+    WR_REQUIRE(rnnt_cols_per_lane(U1) <= 8, WR_EUNSUPPORTED, "joint_fwd_lse: U1=%d exceeds the loss's limit of 512", U1);
+    const RnntWs w = rnnt_ws_layout(B, T, U1);
+    WR_REQUIRE(rnnt_workspace_bytes >= w.total, WR_EWORKSPACE, "joint_fwd_lse: RNN-T workspace %zu < required %zu",
+               rnnt_workspace_bytes, w.total);
+    char *rws = static_cast<char *>(rnnt_workspace_d);
+    JointLse lse{targets_d, blank, w.S, reinterpret_cast<float2 *>(rws + w.lp_off), reinterpret_cast<float *>(rws + w.denom_off),
+                 reinterpret_cast<int32_t *>(rws + w.flag_off)};
+    return joint_fwd_launch(ep_d, pp_d, w_out_d, b_out_d, logit_lengths_d, target_lengths_d, B, T, U1, J, V, out_d,
+                            workspace_d, workspace_bytes, &lse, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int wr_joint_bwd_dz(const float *gout_d, const float *ep_d, const float *pp_d, const float *w_out_d,

@@ -25,6 +25,7 @@
 //   busy (SQ_VALU_MFMA_BUSY_CYCLES) -- with one wave per SIMD the tile build, the k-loop and the epilogue of a
 //   workgroup do not overlap, and 138 KB of LDS per workgroup rules out a second one per CU.
 #include "wr_common.hpp"
+#include "joint_lse.hpp"
 
 namespace wr {
 namespace {
@@ -102,11 +103,12 @@ template <> __device__ __forceinline__ float to_out<float>(float x) { return x; 
 template <> __device__ __forceinline__ _Float16 to_out<_Float16>(float x) { return (_Float16)x; }
 template <> __device__ __forceinline__ __bf16 to_out<__bf16>(float x) { return (__bf16)x; }
 
-template <int TERMS, typename OutT>
+// LSE = true (float logits, npart = 1): the epilogue also produces the RNN-T loss's row statistics (joint_lse.hpp).
+template <int TERMS, typename OutT, bool LSE = false>
 __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
     const float *__restrict__ ep, const float *__restrict__ pp, const u32x4 *__restrict__ wh, const u32x4 *__restrict__ wl,
     const float *__restrict__ bias, const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens, int B, int T,
-    int U1, int J, int Jp, int V, int Vp, int npart, OutT *__restrict__ out)
+    int U1, int J, int Jp, int V, int Vp, int npart, OutT *__restrict__ out, JointLse lse = JointLse{})
 {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds_s[];
     const int JS = Jp + 8;                                 // padded row stride (bf16 elements): 16-byte pad
@@ -120,6 +122,11 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
     const long m0 = (long)(blockIdx.x / npart) * kSM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
+    float rm[32], rs[32];                                   // LSE: this lane's (reference, partial sum) of its 32 rows
+    if (LSE) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { rm[i] = -3.0e38f; rs[i] = 0.f; }
+    }
 
     if (llens != nullptr && tlens != nullptr) {
         int valid = 0;
@@ -271,6 +278,11 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
             OutT *__restrict__ ocol = out + (size_t)m0 * V + (colin ? col : 0);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
+                if (LSE) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        joint_lse_add(rm[rt * 16 + q], rs[rt * 16 + q], acc[rt][c][q] + bv, colin, r == 0 && c == 0);
+                }
                 if (full) {
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
@@ -307,6 +319,11 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
         mfma_set(ci + 2, rbh, rbl);
         finish_round(ci + 2);
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if (LSE) {
+        __syncthreads();                                    // every wave is done with the activation images: reuse them
+        joint_lse_finish<kSWaves>(lse, reinterpret_cast<float *>(lds_s), rm, rs, llens, tlens,
+                                  reinterpret_cast<const float *>(out), m0, M, T, U1, V);
     }
 }
 
@@ -1251,20 +1268,15 @@ extern "C" size_t wr_joint_split_workspace_bytes(int J, int V)
     return 2 * align_up((size_t)split_jpad(J) * split_vpad(V) * sizeof(unsigned short), 256);
 }
 
-extern "C" int wr_joint_fwd_split(const float *ep_d, const float *pp_d, const float *w_out_d, const float *b_out_d,
-                                  const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B, int T, int U1,
-                                  int J, int V, int terms, void *out_d, int out_dtype, void *workspace_d,
-                                  size_t workspace_bytes, void *stream)
+namespace {
+int joint_fwd_split_launch(const float *ep_d, const float *pp_d, const float *w_out_d, const float *b_out_d,
+                           const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B, int T, int U1, int J,
+                           int V, int terms, void *out_d, int out_dtype, void *workspace_d, size_t workspace_bytes,
+                           const JointLse *lse, hipStream_t st)
 {
-    if (int rc = split_check(B, T, U1, J, V, terms, out_dtype)) return rc;
-    WR_REQUIRE(ep_d && pp_d && w_out_d && b_out_d && out_d && workspace_d, WR_EINVAL,
-               "joint_fwd_split: null pointer argument");
-    WR_REQUIRE((logit_lengths_d == nullptr) == (target_lengths_d == nullptr), WR_EINVAL,
-               "joint_fwd_split: pass both length arrays or neither");
     const int Vp = split_vpad(V), Jp = split_jpad(J);
     const size_t img = align_up((size_t)Jp * Vp * sizeof(unsigned short), 256);
     WR_REQUIRE(workspace_bytes >= 2 * img, WR_EWORKSPACE, "joint_fwd_split: workspace too small");
-    hipStream_t st = static_cast<hipStream_t>(stream);
     unsigned short *wh = static_cast<unsigned short *>(workspace_d);
     unsigned short *wl = reinterpret_cast<unsigned short *>(static_cast<char *>(workspace_d) + img);
     hipLaunchKernelGGL(split_w_kernel, dim3(512), dim3(256), 0, st, w_out_d, V, J, Vp, Jp, wh, wl);
@@ -1275,13 +1287,18 @@ extern "C" int wr_joint_fwd_split(const float *ep_d, const float *pp_d, const fl
     // cost more, so one part is the default; wr_tune_set(7, n) overrides for experiments.
     int npart = 1;
     if (const int forced = tune_get(kTuneSplitParts)) npart = forced;
-    const size_t tile_lds = (size_t)(terms == 3 ? 2 : 1) * kSM * (Jp + 8) * sizeof(unsigned short);
-    while (npart < 64 && tile_lds + (size_t)((Vp / (32 * kSCT) + npart - 1) / npart) * 32 * kSCT * sizeof(float) > 160 * 1024)
+    if (lse) npart = 1;                                     // the row statistics need every column in one workgroup
+    size_t tile_lds = (size_t)(terms == 3 ? 2 : 1) * kSM * (Jp + 8) * sizeof(unsigned short);
+    if (lse && tile_lds < joint_lse_exchange_bytes(kSWaves)) tile_lds = joint_lse_exchange_bytes(kSWaves);
+    const size_t extra = 0;
+    if (lse) (void)hipMemsetAsync(lse->repair, 0, sizeof(int32_t), st);
+    while (!lse && npart < 64 &&
+           tile_lds + (size_t)((Vp / (32 * kSCT) + npart - 1) / npart) * 32 * kSCT * sizeof(float) > 160 * 1024)
         npart *= 2;                                         // large vocabularies: the bias slab must fit beside the tile
     WR_REQUIRE((M + kSM - 1) / kSM * npart < (1L << 31), WR_EUNSUPPORTED, "joint_fwd_split: too many lattice cells");
     const int pairs_per_part = (Vp / (32 * kSCT) + npart - 1) / npart;
-    const size_t lds = (size_t)(terms == 3 ? 2 : 1) * kSM * (Jp + 8) * sizeof(unsigned short) +
-                       (size_t)pairs_per_part * 32 * kSCT * sizeof(float);
+    const size_t bias_lds = (size_t)pairs_per_part * 32 * kSCT * sizeof(float);
+    const size_t lds = tile_lds + bias_lds + extra;
     WR_REQUIRE(lds <= 160 * 1024, WR_EUNSUPPORTED, "joint_fwd_split: V=%d needs %zu bytes of LDS", V, lds);
     const dim3 grid((unsigned)((M + kSM - 1) / kSM * npart));
 #define WR_LAUNCH_SPLIT(TERMS, OutT)                                                                                  \
@@ -1290,9 +1307,21 @@ extern "C" int wr_joint_fwd_split(const float *ep_d, const float *pp_d, const fl
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
         hipLaunchKernelGGL((joint_fwd_split_kernel<TERMS, OutT>), grid, dim3(64 * kSWaves), lds, st, ep_d, pp_d,       \
                            reinterpret_cast<const u32x4 *>(wh), reinterpret_cast<const u32x4 *>(wl), b_out_d,          \
-                           logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, npart, static_cast<OutT *>(out_d));     \
+                           logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, npart, static_cast<OutT *>(out_d), \
+                           JointLse{});                                                                               \
     } while (0)
-    if (terms == 3) {
+#define WR_LAUNCH_SPLIT_LSE(TERMS)                                                                                    \
+    do {                                                                                                              \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_fwd_split_kernel<TERMS, float, true>),           \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+        hipLaunchKernelGGL((joint_fwd_split_kernel<TERMS, float, true>), grid, dim3(64 * kSWaves), lds, st, ep_d, pp_d, \
+                           reinterpret_cast<const u32x4 *>(wh), reinterpret_cast<const u32x4 *>(wl), b_out_d,          \
+                           logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, npart, static_cast<float *>(out_d), \
+                           *lse);                                                                                     \
+    } while (0)
+    if (lse) {
+        if (terms == 3) WR_LAUNCH_SPLIT_LSE(3); else WR_LAUNCH_SPLIT_LSE(1);
+    } else if (terms == 3) {
         if (out_dtype == 0) WR_LAUNCH_SPLIT(3, float);
         else if (out_dtype == 1) WR_LAUNCH_SPLIT(3, _Float16);
         else WR_LAUNCH_SPLIT(3, __bf16);
@@ -1302,8 +1331,47 @@ extern "C" int wr_joint_fwd_split(const float *ep_d, const float *pp_d, const fl
         else WR_LAUNCH_SPLIT(1, __bf16);
     }
 #undef WR_LAUNCH_SPLIT
+#undef WR_LAUNCH_SPLIT_LSE
     WR_CHECK_LAUNCH("joint_fwd_split_kernel");
     return WR_OK;
+}
+}  // namespace
+
+extern "C" int wr_joint_fwd_split(const float *ep_d, const float *pp_d, const float *w_out_d, const float *b_out_d,
+                                  const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B, int T, int U1,
+                                  int J, int V, int terms, void *out_d, int out_dtype, void *workspace_d,
+                                  size_t workspace_bytes, void *stream)
+{
+    if (int rc = split_check(B, T, U1, J, V, terms, out_dtype)) return rc;
+    WR_REQUIRE(ep_d && pp_d && w_out_d && b_out_d && out_d && workspace_d, WR_EINVAL,
+               "joint_fwd_split: null pointer argument");
+    WR_REQUIRE((logit_lengths_d == nullptr) == (target_lengths_d == nullptr), WR_EINVAL,
+               "joint_fwd_split: pass both length arrays or neither");
+    return joint_fwd_split_launch(ep_d, pp_d, w_out_d, b_out_d, logit_lengths_d, target_lengths_d, B, T, U1, J, V, terms,
+                                  out_d, out_dtype, workspace_d, workspace_bytes, nullptr, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int wr_joint_fwd_split_lse(const float *ep_d, const float *pp_d, const float *w_out_d, const float *b_out_d,
+                                      const int32_t *logit_lengths_d, const int32_t *target_lengths_d,
+                                      const int32_t *targets_d, int B, int T, int U1, int J, int V, int blank, int terms,
+                                      float *out_d, void *workspace_d, size_t workspace_bytes, void *rnnt_workspace_d,
+                                      size_t rnnt_workspace_bytes, void *stream)
+{
+    if (int rc = split_check(B, T, U1, J, V, terms, WR_F32)) return rc;
+    WR_REQUIRE(ep_d && pp_d && w_out_d && b_out_d && out_d && workspace_d && rnnt_workspace_d, WR_EINVAL,
+               "joint_fwd_split_lse: null pointer argument");
+    WR_REQUIRE(logit_lengths_d && target_lengths_d, WR_EINVAL, "joint_fwd_split_lse: both length arrays are required");
+    WR_REQUIRE(targets_d || U1 == 1, WR_EINVAL, "joint_fwd_split_lse: targets is null");
+    WR_REQUIRE(blank >= 0 && blank < V, WR_EINVAL, "joint_fwd_split_lse: blank %d out of range [0,%d)", blank, V);
+    WR_REQUIRE(rnnt_cols_per_lane(U1) <= 8, WR_EUNSUPPORTED, "joint_fwd_split_lse: U1=%d exceeds the loss's limit of 512", U1);
+    const RnntWs w = rnnt_ws_layout(B, T, U1);
+    WR_REQUIRE(rnnt_workspace_bytes >= w.total, WR_EWORKSPACE, "joint_fwd_split_lse: RNN-T workspace %zu < required %zu",
+               rnnt_workspace_bytes, w.total);
+    char *rws = static_cast<char *>(rnnt_workspace_d);
+    JointLse lse{targets_d, blank, w.S, reinterpret_cast<float2 *>(rws + w.lp_off), reinterpret_cast<float *>(rws + w.denom_off),
+                 reinterpret_cast<int32_t *>(rws + w.flag_off)};
+    return joint_fwd_split_launch(ep_d, pp_d, w_out_d, b_out_d, logit_lengths_d, target_lengths_d, B, T, U1, J, V, terms,
+                                  out_d, WR_F32, workspace_d, workspace_bytes, &lse, static_cast<hipStream_t>(stream));
 }
 
 extern "C" size_t wr_joint_dz_split_workspace_bytes(int J, int V)

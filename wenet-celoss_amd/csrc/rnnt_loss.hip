@@ -10,13 +10,14 @@
 //           denom(t,u) and the two log-probs the lattice needs
 //           (skip = blank, emit = label) into a *diagonal-skewed* array.
 //           HBM-bound: 4*V bytes read per cell.
-//   pass 2  rnnt_sweep_kernel  one wave per (utterance, direction).  Lane l owns
-//           K = ceil(U1max/64) adjacent label columns; at step s it works on
-//           frame t = s - l, so the cross-lane dependency alpha(t,u-1) /
-//           beta(t,u+1) is exactly the neighbour lane's value from the
-//           previous step: one DPP wave shift, no LDS, no barrier.  Because
-//           pass 1 stored log-probs skewed by the same rule, step s reads one
-//           contiguous row.  Latency-bound (T + 63 dependent steps), ~0.1 ms.
+//   pass 2  rnnt_sweep_kernel  one workgroup per (utterance, direction), one lane per label column
+//           (64 * ceil(U1max/64) threads).  At step s every lane works on the cell (t = s - u, u) of
+//           anti-diagonal s; from diagonal s-1 it needs its own previous value and its neighbour
+//           lane's: inside a wave one DPP wave shift, across a wave boundary an 8-byte LDS slot
+//           (double buffered) and one s_barrier per step.  Because pass 1 stored the log-probs skewed
+//           by the same rule, step s reads one contiguous row; PF rows are kept in flight under counted
+//           waits.  State in fp64, the bounded log1p(exp(-|a-b|)) term in fp32.  Latency-bound
+//           (T + U dependent steps, ~0.26 us each: 0.30 ms at the BASELINE shape).
 //   pass 3  rnnt_grad_kernel   one wave per cell again: re-reads the V logits,
 //           writes grad = g_b * (exp(logit + alpha + beta + cost - denom) with
 //           the blank / label corrections), zero in the padded region.
@@ -27,32 +28,6 @@
 
 namespace wr {
 namespace {
-
-struct RnntWs {
-    int K;            // label columns per lane in the sweep (lane l owns u = l, l+64, ...)
-    int S;            // number of anti-diagonals per utterance
-    size_t lp_off, alpha_off, beta_off, denom_off, ll_off, cost_off, dump_off, total;
-};
-
-__host__ __device__ inline int rnnt_cols_per_lane(int U1max) { return (U1max + kWave - 1) / kWave; }
-
-inline RnntWs rnnt_ws_layout(int B, int Tmax, int U1max)
-{
-    RnntWs w;
-    w.K = rnnt_cols_per_lane(U1max);
-    w.S = Tmax + U1max - 1;          // anti-diagonals s = t + u
-    const size_t diag = (size_t)B * w.S * U1max;
-    size_t off = 0;
-    w.lp_off = off;    off = align_up(off + diag * sizeof(float2), 256);
-    w.alpha_off = off; off = align_up(off + diag * sizeof(double), 256);
-    w.beta_off = off;  off = align_up(off + diag * sizeof(double), 256);
-    w.denom_off = off; off = align_up(off + (size_t)B * Tmax * U1max * sizeof(float), 256);
-    w.ll_off = off;    off = align_up(off + (size_t)B * sizeof(double), 256);
-    w.cost_off = off;  off = align_up(off + (size_t)B * sizeof(double), 256);
-    w.dump_off = off;  off = align_up(off + (size_t)B * 2 * 512 * sizeof(double), 256);
-    w.total = off;
-    return w;
-}
 
 // ------------------------------------------------------------------ pass 1 --
 // Element types: float (the parity bar), _Float16 and __bf16 (AMP logits; arithmetic stays fp32).
@@ -158,8 +133,9 @@ __global__ __launch_bounds__(256) void rnnt_lse_kernel(
     const T *__restrict__ logits, const int32_t *__restrict__ targets,
     const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens,
     int B, int Tmax, int U1max, int V, int blank, int K, int S,
-    float2 *__restrict__ lp_skew, float *__restrict__ denom)
+    float2 *__restrict__ lp_skew, float *__restrict__ denom, const int32_t *__restrict__ run_if)
 {
+    if (run_if != nullptr && *run_if == 0) return;     // repair pass behind the joiner's fused epilogue: usually nothing to do
     const int lane = threadIdx.x & (kWave - 1);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int waves_per_block = blockDim.x >> 6;
@@ -506,8 +482,10 @@ int stream_grid(long nrows, int blocks_per_cu)
     return (int)blocks;
 }
 
-void launch_sweep(const RnntWs &w, char *ws, const int32_t *llens, const int32_t *tlens, int B, int Tmax,
-                  int U1max, float *costs, hipStream_t st)
+}  // namespace
+
+void rnnt_launch_sweep(const RnntWs &w, char *ws, const int32_t *llens, const int32_t *tlens, int B, int Tmax,
+                       int U1max, float *costs, hipStream_t st)
 {
     hipLaunchKernelGGL((rnnt_sweep_kernel<8>), dim3(B, 2), dim3(64 * w.K), 0, st,
                        reinterpret_cast<const float2 *>(ws + w.lp_off), llens, tlens, Tmax, U1max, w.S,
@@ -516,7 +494,6 @@ void launch_sweep(const RnntWs &w, char *ws, const int32_t *llens, const int32_t
                        reinterpret_cast<double *>(ws + w.dump_off));
 }
 
-}  // namespace
 }  // namespace wr
 
 using namespace wr;
@@ -549,7 +526,7 @@ extern "C" int wr_rnnt_loss_fwd(const void *logits_d, int dtype, const int32_t *
 #define WR_LAUNCH_LSE_U(T, NT, UN)                                                                                  \
     hipLaunchKernelGGL((rnnt_lse_kernel<T, NT, UN>), grid1, dim3(256), 0, st, static_cast<const T *>(logits_d), targets_d, \
                        logit_lengths_d, target_lengths_d, B, Tmax, U1max, V, blank, w.K, w.S,                        \
-                       reinterpret_cast<float2 *>(ws + w.lp_off), reinterpret_cast<float *>(ws + w.denom_off))
+                       reinterpret_cast<float2 *>(ws + w.lp_off), reinterpret_cast<float *>(ws + w.denom_off), nullptr)
     const bool nt = (tune_get(kTuneNonTemporal) & 4) != 0;
     if (dtype == WR_F32) { if (nt) { WR_LAUNCH_LSE(float, true); } else { WR_LAUNCH_LSE(float, false); } }
     else if (dtype == WR_F16) { if (nt) { WR_LAUNCH_LSE(_Float16, true); } else { WR_LAUNCH_LSE(_Float16, false); } }
@@ -557,7 +534,33 @@ extern "C" int wr_rnnt_loss_fwd(const void *logits_d, int dtype, const int32_t *
 #undef WR_LAUNCH_LSE
 #undef WR_LAUNCH_LSE_U
     WR_CHECK_LAUNCH("rnnt_lse_kernel");
-    launch_sweep(w, ws, logit_lengths_d, target_lengths_d, B, Tmax, U1max, costs_d, st);
+    rnnt_launch_sweep(w, ws, logit_lengths_d, target_lengths_d, B, Tmax, U1max, costs_d, st);
+    WR_CHECK_LAUNCH("rnnt_sweep_kernel");
+    return WR_OK;
+}
+
+extern "C" int wr_rnnt_loss_fwd_from_lse(const float *logits_d, const int32_t *targets_d, const int32_t *logit_lengths_d,
+                                         const int32_t *target_lengths_d, int B, int Tmax, int U1max, int V, int blank,
+                                         float *costs_d, void *workspace_d, size_t workspace_bytes, void *stream)
+{
+    if (int rc = check_shape(B, Tmax, U1max, V, blank)) return rc;
+    WR_REQUIRE(logits_d && logit_lengths_d && target_lengths_d && costs_d && workspace_d, WR_EINVAL,
+               "rnnt_loss_fwd_from_lse: null pointer argument");
+    WR_REQUIRE(targets_d || U1max == 1, WR_EINVAL, "rnnt_loss_fwd_from_lse: targets is null");
+    const RnntWs w = rnnt_ws_layout(B, Tmax, U1max);
+    WR_REQUIRE(workspace_bytes >= w.total, WR_EWORKSPACE, "rnnt_loss_fwd_from_lse: workspace %zu < required %zu",
+               workspace_bytes, w.total);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char *ws = static_cast<char *>(workspace_d);
+    // repair pass: the stand-alone row statistics, executed only if the joiner's epilogue raised the flag (a partial
+    // sum overflowed: more than 88 nats of spread inside one row); otherwise every workgroup leaves at once
+    const long nrows = (long)B * Tmax * U1max;
+    hipLaunchKernelGGL((rnnt_lse_kernel<float, false, 8>), dim3(stream_grid(nrows, tune_get(kTuneLseBlocksPerCu))), dim3(256), 0, st,
+                       logits_d, targets_d, logit_lengths_d, target_lengths_d, B, Tmax, U1max, V, blank, w.K, w.S,
+                       reinterpret_cast<float2 *>(ws + w.lp_off), reinterpret_cast<float *>(ws + w.denom_off),
+                       reinterpret_cast<const int32_t *>(ws + w.flag_off));
+    WR_CHECK_LAUNCH("rnnt_lse_kernel (repair)");
+    rnnt_launch_sweep(w, ws, logit_lengths_d, target_lengths_d, B, Tmax, U1max, costs_d, st);
     WR_CHECK_LAUNCH("rnnt_sweep_kernel");
     return WR_OK;
 }

@@ -53,6 +53,38 @@ int joint_bwd_dz_block(const float *gout_d, const float *ep_d, const float *pp_d
 int joint_bwd_dw_block(const float *gout_d, const float *h_d, const int32_t *llens_d, const int32_t *tlens_d, int B, int T,
                        int U1, int J, int V, int max_parts, float *dw_d, float *db_d, float *part_dw, hipStream_t st);
 
+// ---- RNN-T loss workspace (rnnt_loss.hip; the joiner's fused row-statistics epilogue writes into it too) ----
+struct RnntWs {
+    int K;            // label columns per lane in the sweep (lane l owns u = l, l+64, ...)
+    int S;            // number of anti-diagonals per utterance
+    size_t lp_off, alpha_off, beta_off, denom_off, ll_off, cost_off, dump_off, flag_off, total;
+};
+
+__host__ __device__ inline int rnnt_cols_per_lane(int U1max) { return (U1max + kWave - 1) / kWave; }
+
+inline RnntWs rnnt_ws_layout(int B, int Tmax, int U1max)
+{
+    RnntWs w;
+    w.K = rnnt_cols_per_lane(U1max);
+    w.S = Tmax + U1max - 1;          // anti-diagonals s = t + u
+    const size_t diag = (size_t)B * w.S * U1max;
+    size_t off = 0;
+    w.lp_off = off;    off = align_up(off + diag * sizeof(float2), 256);
+    w.alpha_off = off; off = align_up(off + diag * sizeof(double), 256);
+    w.beta_off = off;  off = align_up(off + diag * sizeof(double), 256);
+    w.denom_off = off; off = align_up(off + (size_t)B * Tmax * U1max * sizeof(float), 256);
+    w.ll_off = off;    off = align_up(off + (size_t)B * sizeof(double), 256);
+    w.cost_off = off;  off = align_up(off + (size_t)B * sizeof(double), 256);
+    w.dump_off = off;  off = align_up(off + (size_t)B * 2 * 512 * sizeof(double), 256);
+    w.flag_off = off;  off = align_up(off + 64, 256);   // "row statistics need the stand-alone pass" (joint_lse.hpp)
+    w.total = off;
+    return w;
+}
+
+// rnnt_loss.hip: lattice sweeps over a workspace whose row statistics (denom, skip/emit log-probs) are in place
+void rnnt_launch_sweep(const RnntWs &w, char *ws, const int32_t *llens, const int32_t *tlens, int B, int Tmax, int U1max,
+                       float *costs, hipStream_t st);
+
 // ---- device helpers ---------------------------------------------------------
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }

@@ -87,60 +87,67 @@ class _JointFn(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, gout):
         ep, pp, w, llens, tlens = ctx.saved_tensors
-        lib = _lib.load()
-        B, T, J = ep.shape
-        U1 = pp.shape[1]
-        V = w.shape[0]
-        dev = ep.device
-        gout = gout.float().contiguous()
-        dz = torch.empty(B, T, U1, J, dtype=torch.float32, device=dev)
-        need_w = ctx.needs_input_grad[2]
-        h = torch.empty_like(dz) if need_w else None
-        if ctx.terms != 0 and V % 4 == 0 and V >= 32:       # same split as the forward (gradient rows 16-byte aligned)
-            wsb = lib.wr_joint_dz_split_workspace_bytes(J, V)
+        d_ep, d_pp, d_w, d_b = joint_backward(gout, ep, pp, w, llens, tlens, ctx.terms, ctx.needs_input_grad[2],
+                                              ctx.needs_input_grad[3])
+        return d_ep, d_pp, d_w, d_b, None, None, None, None
+
+
+def joint_backward(gout, ep, pp, w, llens, tlens, terms: int, need_w: bool, need_b: bool):
+    """Backward of the joiner from the logits gradient `gout` (B,T,U1,V): returns (d_ep, d_pp, d_w, d_b).
+    Shared by the joiner's autograd Function and by the fused joiner + RNN-T loss Function (fused.py)."""
+    lib = _lib.load()
+    B, T, J = ep.shape
+    U1 = pp.shape[1]
+    V = w.shape[0]
+    dev = ep.device
+    gout = gout.float().contiguous()
+    dz = torch.empty(B, T, U1, J, dtype=torch.float32, device=dev)
+    h = torch.empty_like(dz) if need_w else None
+    if terms != 0 and V % 4 == 0 and V >= 32:       # same split as the forward (gradient rows 16-byte aligned)
+        wsb = lib.wr_joint_dz_split_workspace_bytes(J, V)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.wr_joint_bwd_dz_split(_lib.ptr(gout), _lib.ptr(ep), _lib.ptr(pp), _lib.ptr(w), _lib.ptr(llens),
+                                           _lib.ptr(tlens), B, T, U1, J, V, terms, _lib.ptr(dz), _lib.ptr(h),
+                                           _lib.ptr(ws), wsb, _lib.current_stream(dev))
+        _lib.check(rc, "wr_joint_bwd_dz_split")
+    else:
+        with torch.cuda.device(dev):
+            rc = lib.wr_joint_bwd_dz(_lib.ptr(gout), _lib.ptr(ep), _lib.ptr(pp), _lib.ptr(w), _lib.ptr(llens),
+                                     _lib.ptr(tlens), B, T, U1, J, V, _lib.ptr(dz), _lib.ptr(h),
+                                     _lib.current_stream(dev))
+        _lib.check(rc, "wr_joint_bwd_dz")
+    d_ep = dz.sum(dim=2)
+    d_pp = dz.sum(dim=1)
+    d_w = d_b = None
+    if need_w:
+        d_w = torch.empty(V, J, dtype=torch.float32, device=dev)
+        d_b = torch.empty(V, dtype=torch.float32, device=dev)
+        if terms != 0 and V % 4 == 0 and J % 4 == 0:
+            wsb = lib.wr_joint_dw_split_workspace_bytes(B, T, U1, J, V)
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
             with torch.cuda.device(dev):
-                rc = lib.wr_joint_bwd_dz_split(_lib.ptr(gout), _lib.ptr(ep), _lib.ptr(pp), _lib.ptr(w), _lib.ptr(llens),
-                                               _lib.ptr(tlens), B, T, U1, J, V, ctx.terms, _lib.ptr(dz), _lib.ptr(h),
-                                               _lib.ptr(ws), wsb, _lib.current_stream(dev))
-            _lib.check(rc, "wr_joint_bwd_dz_split")
+                rc = lib.wr_joint_bwd_dw_split(_lib.ptr(gout), _lib.ptr(h), _lib.ptr(llens), _lib.ptr(tlens), B, T, U1,
+                                               J, V, terms, _lib.ptr(d_w), _lib.ptr(d_b), _lib.ptr(ws), wsb,
+                                               _lib.current_stream(dev))
+            _lib.check(rc, "wr_joint_bwd_dw_split")
         else:
+            wsb = lib.wr_joint_dw_workspace_bytes(J, V)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
             with torch.cuda.device(dev):
-                rc = lib.wr_joint_bwd_dz(_lib.ptr(gout), _lib.ptr(ep), _lib.ptr(pp), _lib.ptr(w), _lib.ptr(llens),
-                                         _lib.ptr(tlens), B, T, U1, J, V, _lib.ptr(dz), _lib.ptr(h),
-                                         _lib.current_stream(dev))
-            _lib.check(rc, "wr_joint_bwd_dz")
-        d_ep = dz.sum(dim=2)
-        d_pp = dz.sum(dim=1)
-        d_w = d_b = None
-        if need_w:
-            d_w = torch.empty(V, J, dtype=torch.float32, device=dev)
-            d_b = torch.empty(V, dtype=torch.float32, device=dev)
-            if ctx.terms != 0 and V % 4 == 0 and J % 4 == 0:
-                wsb = lib.wr_joint_dw_split_workspace_bytes(B, T, U1, J, V)
-                ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-                with torch.cuda.device(dev):
-                    rc = lib.wr_joint_bwd_dw_split(_lib.ptr(gout), _lib.ptr(h), _lib.ptr(llens), _lib.ptr(tlens), B, T, U1,
-                                                   J, V, ctx.terms, _lib.ptr(d_w), _lib.ptr(d_b), _lib.ptr(ws), wsb,
-                                                   _lib.current_stream(dev))
-                _lib.check(rc, "wr_joint_bwd_dw_split")
-            else:
-                wsb = lib.wr_joint_dw_workspace_bytes(J, V)
-                ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-                with torch.cuda.device(dev):
-                    rc = lib.wr_joint_bwd_dw(_lib.ptr(gout), _lib.ptr(h), _lib.ptr(llens), _lib.ptr(tlens), B, T, U1, J, V,
-                                             _lib.ptr(d_w), _lib.ptr(d_b), _lib.ptr(ws), wsb, _lib.current_stream(dev))
-                _lib.check(rc, "wr_joint_bwd_dw")
-        elif ctx.needs_input_grad[3]:
-            g2 = gout.view(-1, V)
-            if llens is not None:
-                tt = torch.arange(T, device=dev)[None, :, None] < llens[:, None, None]
-                uu = torch.arange(U1, device=dev)[None, None, :] <= tlens[:, None, None]
-                g2 = torch.where((tt & uu).view(-1, 1), g2, torch.zeros((), device=dev))
-            d_b = g2.sum(0)
-        if not ctx.needs_input_grad[3]:
-            d_b = None
-        return d_ep, d_pp, d_w, d_b, None, None, None, None
+                rc = lib.wr_joint_bwd_dw(_lib.ptr(gout), _lib.ptr(h), _lib.ptr(llens), _lib.ptr(tlens), B, T, U1, J, V,
+                                         _lib.ptr(d_w), _lib.ptr(d_b), _lib.ptr(ws), wsb, _lib.current_stream(dev))
+            _lib.check(rc, "wr_joint_bwd_dw")
+    elif need_b:
+        g2 = gout.view(-1, V)
+        if llens is not None:
+            tt = torch.arange(T, device=dev)[None, :, None] < llens[:, None, None]
+            uu = torch.arange(U1, device=dev)[None, None, :] <= tlens[:, None, None]
+            g2 = torch.where((tt & uu).view(-1, 1), g2, torch.zeros((), device=dev))
+        d_b = g2.sum(0)
+    if not need_b:
+        d_b = None
+    return d_ep, d_pp, d_w, d_b
 
 
 def joint_logits(ep: torch.Tensor, pp: torch.Tensor, w_out: torch.Tensor, b_out: torch.Tensor,

@@ -21,6 +21,7 @@ over the HIP step kernels).
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -29,6 +30,8 @@ from torch.nn.utils.rnn import pad_sequence
 
 from .common import IGNORE_ID, LabelSmoothingLoss, add_blank, add_sos_eos, end_blank, reverse_pad_list
 from .decoder import DecoderCache
+from .fused import joint_rnnt_loss
+from .joint import TransducerJoint, _resolve_precision
 from .rnnt_loss import rnnt_loss
 from .search.greedy_search import basic_greedy_search, basic_greedy_search_both, basic_greedy_search_hw
 from .search.prefix_beam_search import PrefixBeamSearch
@@ -70,18 +73,28 @@ class Transducer(nn.Module):
             self.criterion_att = LabelSmoothingLoss(size=vocab_size, padding_idx=ignore_id, smoothing=lsm_weight,
                                                     normalize_length=length_normalized_loss)
         self._decoder_cache = DecoderCache()
+        # joiner + RNN-T loss as one autograd node (fused.py): pass 1 of the loss rides on the joiner's epilogue and the
+        # logits never leave the node (half the footprint).  Opt-in: WR_FUSED_LOSS=1 or this attribute.
+        self.fused_loss = os.environ.get("WR_FUSED_LOSS", "0") == "1"
 
     # ------------------------------------------------------------- training --
     def compute_loss(self, encoder_out: torch.Tensor, encoder_out_lens: torch.Tensor, predictor_out: torch.Tensor,
                      text: torch.Tensor, text_lengths: torch.Tensor, skip_padding: bool = False
                      ) -> Tuple[torch.Tensor, torch.Tensor]:
         """The loss block of the reference forward (transducer.py:131-147): joiner -> int32 label prep -> RNN-T loss.
-        Returns (joint_out, loss_rnnt).  `skip_padding=True` (extension) lets the joiner skip lattice cells
+        Returns (joint_out, loss_rnnt).  With `fused_loss` the two run as one autograd node and joint_out is
+        None (the logits never leave it); otherwise `skip_padding=True` (extension) lets the joiner skip lattice cells
         that the loss never reads."""
         rnnt_text = text.to(torch.int64)
         rnnt_text = torch.where(rnnt_text == self.ignore_id, 0, rnnt_text).to(torch.int32)
         rnnt_text_lengths = text_lengths.to(torch.int32)
         encoder_out_lens = encoder_out_lens.to(torch.int32)
+        if self._can_fuse_loss():
+            jt = self.joint
+            loss = joint_rnnt_loss(jt.enc_ffn(encoder_out), jt.pred_ffn(predictor_out), jt.ffn_out.weight, jt.ffn_out.bias,
+                                   rnnt_text, encoder_out_lens, rnnt_text_lengths, blank=self.blank, reduction="mean",
+                                   precision=jt.precision)
+            return None, loss
         if skip_padding:
             joint_out = self.joint(encoder_out, predictor_out, encoder_out_lens, rnnt_text_lengths)
         else:
@@ -89,6 +102,11 @@ class Transducer(nn.Module):
         loss = rnnt_loss(joint_out, rnnt_text.contiguous(), encoder_out_lens.contiguous(),
                          rnnt_text_lengths.contiguous(), blank=self.blank, reduction="mean")
         return joint_out, loss
+
+    def _can_fuse_loss(self) -> bool:
+        jt = self.joint
+        return (self.fused_loss and isinstance(jt, TransducerJoint) and jt.enc_ffn is not None and jt.pred_ffn is not None
+                and _resolve_precision(jt.precision) != "bf16")        # the AMP single-term mode keeps 16-bit logits
 
     @torch.jit.unused      # wenet/bin/train.py:203-205 scripts the model as an export smoke test; the HIP-backed forward
     def forward(self, speech: torch.Tensor, speech_lengths: torch.Tensor, text: torch.Tensor,  # is opaque to TorchScript
