@@ -36,15 +36,12 @@ def bench_joint(args):
     st = _lib.current_stream(dev); P = _lib.ptr
     f = lambda: _lib.check(lib.wr_joint_fwd(P(ep), P(pp), P(w), P(b), None, None, B, T, U1, J, V, P(out), P(ws), ws_bytes, st))
     flops = 2.0 * B * T * U1 * J * V
-    for variant in (0, 1, 2):
-        lib.wr_tune_set(5, variant)
-        ms = timeit(f, args.steps)
-        chk = float(out[0, 0, 0, :8].abs().sum())
-        print(json.dumps({"what": "joint_fwd", "variant": variant, "shape": [B, T, U1, J, V], "ms": round(ms, 3),
-                          "TFLOPs": round(flops / ms / 1e9, 2), "peak_f32_mfma": 157.3,
-                          "frac": round(flops / ms / 1e9 / 157.3, 4), "probe": chk}), flush=True)
-    lib.wr_tune_set(5, 2)
-    f()
+    ms = timeit(f, args.steps)
+    print(json.dumps({"what": "joint_fwd", "shape": [B, T, U1, J, V], "ms": round(ms, 3),
+                      "TFLOPs": round(flops / ms / 1e9, 2), "peak_f32_mfma": 157.3,
+                      "frac": round(flops / ms / 1e9 / 157.3, 4), "probe": float(out[0, 0, 0, :8].abs().sum())}), flush=True)
+    if args.fwd_only:
+        return
     # split-precision variants on the bf16 matrix cores, checked against the exact-fp32 logits just computed
     wsb_s = lib.wr_joint_split_workspace_bytes(J, V)
     ws_s = torch.empty(wsb_s, dtype=torch.uint8, device=dev)
@@ -310,7 +307,10 @@ def bench_step(args):
     y = torch.randint(1, V, (B, U), dtype=torch.int32, device=dev)
     ll = torch.full((B,), T, dtype=torch.int32, device=dev); tl = torch.full((B,), U, dtype=torch.int32, device=dev)
     base = None
-    for prec in ("fp32", "fp32-fused", "bf16x3", "bf16x3-fused", "bf16-autocast"):
+    precs = ("fp32", "fp32-fused", "bf16x3", "bf16x3-fused", "bf16-autocast")
+    if args.only:
+        precs = tuple(x for x in precs if x in args.only.split(","))
+    for prec in precs:
         amp = prec == "bf16-autocast"                  # the --use_amp configuration (executor.py:91)
         fused = prec.endswith("-fused")                # joiner + loss as one node (fused.py): no pass 1, gradient in place
         jprec = "bf16" if amp else prec.replace("-fused", "")
@@ -357,6 +357,8 @@ if __name__ == "__main__":
     ap.add_argument("--V", type=int, default=5000)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--dw", action="store_true")
+    ap.add_argument("--fwd-only", action="store_true", help="joint: stop after the exact forward sweep")
+    ap.add_argument("--only", default="", help="step: comma-separated subset of the configurations")
     ap.add_argument("--streams", type=int, default=64, help="greedy: independent streams decoded together")
     ap.add_argument("--tile", type=int, default=0, help="lane-GEMM tile policy of the decoders (wr_tune_set key 6)")
     a = ap.parse_args()

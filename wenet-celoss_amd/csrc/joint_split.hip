@@ -907,15 +907,27 @@ __global__ __launch_bounds__(256) void joint_bwd_dw_block_kernel(
     const long me = mb + rows_per_part < M ? mb + rows_per_part : M;
     const int steps = me > mb ? (int)((me - mb + 15) / 16) : 0;
 
-    const int c4 = tid & 63, r4 = tid >> 6;                           // staging: float4 column c4, rows r4 + 4 i
+    // staging: float4 column c4, rows r4 + 4 i.  r4 is the wave index: made scalar, so that a row's (utterance, frame,
+    // label position) and its validity are scalar arithmetic and scalar loads, off the vector pipe
+    const int c4 = tid & 63, r4 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool a_in = v0 + 4 * c4 < V, b_in = j0 + 4 * c4 < J;
     const float *__restrict__ ga = gout + (a_in ? v0 + 4 * c4 : 0);
     const float *__restrict__ gb = h + (b_in ? j0 + 4 * c4 : 0);
-    struct Regs { f32x4 a[4], b[4]; };
+    struct Regs { f32x4 a[4], b[4]; int on; };
     auto gload = [&](int s, Regs &z) {
+        z.on = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             long m = mb + 16L * s + r4 + 4 * i;
+            // validity of the row, evaluated here -- two steps ahead of its use -- so that the length loads travel with
+            // the operand loads
+            bool on = m < me;
+            if (on && llens != nullptr) {                             // M < 2^31 (checked by the caller): 32-bit divisions
+                const unsigned mu = (unsigned)m, bt = mu / (unsigned)U1, u = mu - bt * (unsigned)U1;
+                const unsigned b = bt / (unsigned)T, t = bt - b * (unsigned)T;
+                on = ((int)t < llens[b]) && ((int)u <= tlens[b]);
+            }
+            z.on |= (on ? 1 : 0) << i;
             m = m < me ? m : me - 1;
             z.a[i] = *reinterpret_cast<const f32x4 *>(ga + (size_t)m * V);
             z.b[i] = *reinterpret_cast<const f32x4 *>(gb + (size_t)m * J);
@@ -927,13 +939,7 @@ __global__ __launch_bounds__(256) void joint_bwd_dw_block_kernel(
         float *sb = sa + 16 * kWB;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const long m = mb + 16L * s + r4 + 4 * i;
-            bool on = m < me;
-            if (on && llens != nullptr) {                             // M < 2^31 (checked by the caller): 32-bit divisions
-                const unsigned mu = (unsigned)m, bt = mu / (unsigned)U1, u = mu - bt * (unsigned)U1;
-                const unsigned b = bt / (unsigned)T, t = bt - b * (unsigned)T;
-                on = ((int)t < llens[b]) && ((int)u <= tlens[b]);
-            }
+            const bool on = (z.on >> i) & 1;
             const f32x4 zero = (f32x4){0, 0, 0, 0};
             const f32x4 av = (on && a_in) ? z.a[i] : zero;
             const f32x4 bv = (on && b_in) ? z.b[i] : zero;

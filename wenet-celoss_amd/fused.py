@@ -76,7 +76,7 @@ class _JointRnntFn(torch.autograd.Function):
                                       _lib.ptr(rws), rws.numel(), _lib.current_stream(dev))
         _lib.check(rc, "wr_rnnt_loss_bwd")
         d_ep, d_pp, d_w, d_b = joint_backward(logits, ep, pp, w, llens, tlens, ctx.terms, ctx.needs_input_grad[2],
-                                              ctx.needs_input_grad[3])
+                                              ctx.needs_input_grad[3], gout_zero_in_padding=True)
         return d_ep, d_pp, d_w, d_b, None, None, None, None, None, None
 
 

@@ -92,9 +92,13 @@ class _JointFn(torch.autograd.Function):
         return d_ep, d_pp, d_w, d_b, None, None, None, None
 
 
-def joint_backward(gout, ep, pp, w, llens, tlens, terms: int, need_w: bool, need_b: bool):
+def joint_backward(gout, ep, pp, w, llens, tlens, terms: int, need_w: bool, need_b: bool,
+                   gout_zero_in_padding: bool = False):
     """Backward of the joiner from the logits gradient `gout` (B,T,U1,V): returns (d_ep, d_pp, d_w, d_b).
-    Shared by the joiner's autograd Function and by the fused joiner + RNN-T loss Function (fused.py)."""
+    Shared by the joiner's autograd Function and by the fused joiner + RNN-T loss Function (fused.py).
+    `gout_zero_in_padding`: the caller guarantees gout == 0 outside [0,T_b) x [0,U_b] (the RNN-T gradient pass
+    zero-fills there).  The activation gradient still gets the lengths (it skips padded tiles and writes H = 0 in
+    padded cells), but the weight-gradient reduction then needs no per-row mask: padded rows contribute 0 * 0."""
     lib = _lib.load()
     B, T, J = ep.shape
     U1 = pp.shape[1]
@@ -120,6 +124,8 @@ def joint_backward(gout, ep, pp, w, llens, tlens, terms: int, need_w: bool, need
     d_ep = dz.sum(dim=2)
     d_pp = dz.sum(dim=1)
     d_w = d_b = None
+    if gout_zero_in_padding:
+        llens = tlens = None
     if need_w:
         d_w = torch.empty(V, J, dtype=torch.float32, device=dev)
         d_b = torch.empty(V, dtype=torch.float32, device=dev)

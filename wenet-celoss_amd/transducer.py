@@ -74,8 +74,8 @@ class Transducer(nn.Module):
                                                     normalize_length=length_normalized_loss)
         self._decoder_cache = DecoderCache()
         # joiner + RNN-T loss as one autograd node (fused.py): pass 1 of the loss rides on the joiner's epilogue and the
-        # logits never leave the node (half the footprint).  Opt-in: WR_FUSED_LOSS=1 or this attribute.
-        self.fused_loss = os.environ.get("WR_FUSED_LOSS", "0") == "1"
+        # logits never leave the node (half the footprint).  WR_FUSED_LOSS=0 (or this attribute) selects the two separate ops.
+        self.fused_loss = os.environ.get("WR_FUSED_LOSS", "1") != "0"
 
     # ------------------------------------------------------------- training --
     def compute_loss(self, encoder_out: torch.Tensor, encoder_out_lens: torch.Tensor, predictor_out: torch.Tensor,
