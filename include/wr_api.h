@@ -349,6 +349,65 @@ int wr_predictor_step(wr_decoder *h, const int32_t *tokens_d, const float *cache
                       void *stream);
 
 /* ------------------------------------------------------------------------
+ * Hot-word greedy search with the gate inside the device step: the fork's default
+ * decode path, wenet/transducer/search/greedy_search.py:297-430 (`basic_greedy_search_both`, selected by
+ * loss_mode='both', wenet/transducer/transducer.py:43,559-597), around wenet/transformer/context_bias.py::ContextBias.
+ *
+ * Per predictor step the reference calls ContextBias.forward_predictor_bias (:375-381: multi-head attention of the
+ * predictor output over the encoded hot-word list, LayerNorm, Linear over the concatenation, LayerNorm) and
+ * ContextBias.forward_hw_pred_both (:388-394: the two-class "is a hot word being spoken" gate), takes the gate's
+ * top-1 on the host (.item()), and with context_filter_state == 'on' runs the "go-back" (:365-392): when the gate
+ * flips 0 -> 1 the token emitted after the gate-0 step is withdrawn and decoding resumes from that step's frame with
+ * biasing forced on until the frame of the flip.  Here all of it lives in the captured micro-step:
+ *   - gate: the classifier attends from ONE query to ONE key (the encoder bias feature of frame t), so its softmax
+ *     weight is exactly 1 and its output is a function of the frame alone (q / k projections cannot influence it):
+ *     the gate of every frame is evaluated up front by one kernel (hw_gate_table_kernel) and looked up per step;
+ *   - predictor biasing: one fused kernel per micro-step (query projection, attention over the list, output
+ *     projection, LayerNorm, combine Linear, LayerNorm) for the variant -- hot-word list or empty list -- that the gate
+ *     selected; the joiner activation picks the matching biased encoder stream;
+ *   - gate trace, go-back rewind and the withdrawn token are part of the update kernel's state machine; the host
+ *     reads back once per graph replay, exactly as in wr_greedy_search.
+ * The loop-invariant tensors are the caller's (the reference computes them before its loop, :327-336, with the same
+ * module): bias_hidden of the hot-word list and of the empty list, and the biased encoder outputs.
+ *
+ * Weights in the reference module's layouts (nn.Linear [out, in], LayerNorm [dim]); LayerNorm eps = 1e-5.
+ * dim = embedding_size = encoder output size = predictor output size (the module requires all three equal);
+ * dim <= 512, hw_dim <= 256, n_labels <= 8, heads divides dim, lists of at most max_ctx entries.
+ * ---------------------------------------------------------------------- */
+typedef struct wr_hotword_weights {
+    int32_t dim, heads, hw_dim, n_labels;
+    /* ContextBias.predictor_bias (MultiHeadedAttention, attention.py:35-45) */
+    const float *q_w, *q_b, *k_w, *k_b, *v_w, *v_b, *o_w, *o_b;          /* linear_q / _k / _v / _out: [dim, dim], [dim] */
+    const float *bias_norm_w, *bias_norm_b;                              /* predictor_bias_bias_norm */
+    const float *combine_w, *combine_b;                                  /* predictor_bias_combine [dim, 2 dim], [dim] */
+    const float *out_norm_w, *out_norm_b;                                /* predictor_bias_out_norm */
+    /* gate: hw_output_layer_enc -> hw_bias.linear_v -> hw_bias.linear_out -> hw_bias_norm -> hw_output_layer */
+    const float *hw_enc_w, *hw_enc_b;                                    /* [hw_dim, dim], [hw_dim] */
+    const float *hw_v_w, *hw_v_b, *hw_o_w, *hw_o_b;                      /* [hw_dim, hw_dim], [hw_dim] */
+    const float *hw_norm_w, *hw_norm_b;                                  /* [hw_dim] */
+    const float *hw_out_w, *hw_out_b;                                    /* [n_labels, hw_dim], [n_labels] */
+} wr_hotword_weights;
+
+size_t wr_hotword_workspace_bytes(const wr_decoder *h, const wr_hotword_weights *hw, int max_ctx);
+
+/* Attach the hot-word module to a decoder handle (weights re-laid k-major once into `workspace_d`, which the caller
+ * keeps alive with the handle). */
+int wr_decoder_attach_hotword(wr_decoder *h, const wr_hotword_weights *hw, int max_ctx,
+                              void *workspace_d, size_t workspace_bytes, void *stream);
+
+/* enc_hot / enc_cold [N, T, dim]: ContextBias.forward_encoder_bias of the encoder output with the hot-word list /
+ * the empty list (first return value); enc_feat [N, T, dim]: its second return value for the hot-word list;
+ * hidden_hot [n_ctx_hot, dim], hidden_cold [n_ctx_cold, dim]: ContextBias.forward_bias_hidden of the two lists
+ * (shared by all N streams).  filter_on = (context_filter_state == 'on').  Out: hyps [N, max_hyp] / hyp_lens [N] as
+ * wr_greedy_search; trace [N, trace_cap] / trace_lens [N]: the gate trace (`result` in the reference, whose edit
+ * distance to the hot-word labels is the second return value of the reference function). */
+int wr_greedy_search_hotword(wr_decoder *h, const float *enc_hot_d, const float *enc_cold_d, const float *enc_feat_d,
+                             const int32_t *enc_lens_d, const float *hidden_hot_d, int n_ctx_hot,
+                             const float *hidden_cold_d, int n_ctx_cold, int N, int T, int n_steps, int blank,
+                             int filter_on, int32_t *hyps_d, int32_t *hyp_lens_d, int32_t *trace_d, int trace_cap,
+                             int32_t *trace_lens_d, void *stream);
+
+/* ------------------------------------------------------------------------
  * CTC decode modes, from the ctc_lo output on; the log-softmax is fused.
  * Replaces ASRModel.ctc_greedy_search (wenet/transformer/asr_model.py:281-324) and
  * ASRModel._ctc_prefix_beam_search (:326-409; C++ twin runtime/core/decoder/ctc_prefix_beam_search.cc:107-238,

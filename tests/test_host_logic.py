@@ -161,6 +161,32 @@ def test_world_size_2_gloo_ddp_step_over_balanced_shards():
         assert r[3] == pytest.approx(sum(losses) / 2, rel=1e-6)
 
 
+def test_context_bias_mirror_matches_reference_intermediates():
+    """tests/context_bias_mirror.py (the stand-in that carries the reference ContextBias weights on the GPU box) reproduces
+    the tensors the reference module computed before its greedy loop, and its per-step methods the recorded gate."""
+    import glob
+    from context_bias_mirror import from_fixture
+    paths = sorted(glob.glob(os.path.join(GOLDEN, "greedy_both_real_*.npz")))
+    assert len(paths) >= 6
+    for path in paths:
+        d = np.load(path)
+        cb = from_fixture(d)
+        ctx, ctx_len, enc = torch.tensor(d["ctx"]), torch.tensor(d["ctx_len"]), torch.tensor(d["enc"])
+        with torch.no_grad():
+            hidden = cb.forward_bias_hidden(ctx, ctx_len)
+            hidden_empty = cb.forward_bias_hidden(torch.zeros((1, 1), dtype=torch.int), ctx_len[0].unsqueeze(0))
+            enc_hot, feat = cb.forward_encoder_bias(hidden, enc)
+            enc_cold, _ = cb.forward_encoder_bias(hidden_empty, enc.clone())
+            gl = cb.forward_hw_pred_both(feat.transpose(0, 1), torch.zeros(enc.shape[1], 1, enc.shape[2]))[:, 0, :]
+        for got, key in ((hidden, "hidden"), (hidden_empty, "hidden_empty"), (enc_hot, "enc_hot"), (feat, "enc_hot_feat"),
+                         (enc_cold, "enc_cold"), (gl, "gate_logits")):
+            np.testing.assert_allclose(got.numpy(), d[key], rtol=1e-5, atol=1e-6, err_msg=f"{os.path.basename(path)}:{key}")
+        from wenet_celoss_amd.hotword import device_capable
+        assert device_capable(cb)
+    from bias_stub import TinyBias
+    assert not device_capable(TinyBias(64, 16, 16))        # other hot-word modules keep the host-driven loop
+
+
 def test_transducer_constructor_contract():
     """Same keyword surface and weight-sum assertion as the reference (transducer.py:23-46)."""
     import wenet_celoss_amd as w

@@ -295,6 +295,52 @@ def bench_beam(args):
                           "utt_per_s": round(B / dt, 2), "best_len": len(out[0][0].hyp)}), flush=True)
 
 
+def bench_hotword(args):
+    """Hot-word greedy search (the fork's default decode path, greedy_search.py:297-430) at the shipped dimensions:
+    the loop on the device (gate table + fused predictor biasing + state machine in the update kernel, hipGraph) next
+    to the host-driven loop of round 1, one utterance as the reference decodes, and several streams together."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from context_bias_mirror import ContextBiasMirror
+    import wenet_celoss_amd as w
+    from wenet_celoss_amd.hotword import greedy_search_both_device
+    dev = torch.device("cuda:0")
+    torch.manual_seed(12)
+    V, D, J, H, L, HW, T = args.V, 256, 512, 256, 2, 100, args.T
+    pred = w.RNNPredictor(V, D, D, 0.1, H, L).eval()
+    joint = w.TransducerJoint(V, D, D, J).eval()
+    cb = ContextBiasMirror(V, D, layers=1, heads=4, hw_dim=HW, hw_heads=4).eval()
+    with torch.no_grad():
+        joint.ffn_out.weight *= 10
+        joint.ffn_out.bias[0] += 10.0
+        cb.hw_output_layer_enc.weight.mul_(6.0)
+        cb.hw_output_layer.weight.mul_(4.0)
+    n_ctx = 50
+    ctx = torch.randint(1, V, (n_ctx, 6)); ctx_len = torch.randint(2, 7, (n_ctx,)).to(torch.int32); ctx[0, 0] = 0; ctx_len[0] = 1
+    m = w.Transducer(V, 0, torch.nn.Identity(), pred.to(dev), joint.to(dev), context_bias=cb.to(dev), ctc_weight=0.0,
+                     transducer_weight=1.0, loss_mode="both")
+    for N in (1, args.streams):
+        enc = torch.randn(N, T, D, device=dev)
+        lens = torch.full((N,), T)
+        run = lambda: greedy_search_both_device(m, enc, lens, ctx, ctx_len, n_steps=args.n_steps, filter_on=True)
+        hyps, traces = run()
+        ms = timeit(run, args.steps)
+        ntok = sum(len(h) for h in hyps)
+        decisions = ntok + N * T                       # lower bound: go-back re-decodes more
+        print(json.dumps({"what": "hotword_greedy device", "streams": N, "T": T, "V": V, "n_ctx": n_ctx, "ms_per_call": round(ms, 2),
+                          "tokens": ntok, "gate_zeros": sum(t.count(0) for t in traces), "gate_ones": sum(t.count(1) for t in traces),
+                          "us_per_decision": round(ms * 1e3 / (decisions / N), 1), "utt_per_s": round(N / ms * 1e3, 1)}), flush=True)
+    os.environ["WR_HOTWORD_HOST"] = "1"
+    enc = torch.randn(1, T, D, device=dev)
+    run = lambda: w.basic_greedy_search_both(m, enc, torch.tensor(T), ctx, ctx_len, n_steps=args.n_steps, context_filter_state="on",
+                                             context_decoder_labels_padded=torch.zeros(1, 4, dtype=torch.long))
+    out = run()
+    ms = timeit(run, max(1, args.steps // 2))
+    print(json.dumps({"what": "hotword_greedy host-driven (round 1)", "streams": 1, "T": T, "ms_per_call": round(ms, 2),
+                      "tokens": len(out[0][0]), "us_per_decision": round(ms * 1e3 / (len(out[0][0]) + T), 1)}), flush=True)
+    os.environ.pop("WR_HOTWORD_HOST")
+
+
 def bench_step(args):
     """The loss block of Transducer.forward (transducer.py:131-147) through the autograd path: pre-join
     projections -> joiner -> RNN-T loss -> backward to enc/pred outputs and all joiner weights."""
@@ -349,7 +395,8 @@ def bench_step(args):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["joint", "ctc", "ctcdec", "greedy", "beam", "step"])
+    ap.add_argument("what", choices=["joint", "ctc", "ctcdec", "greedy", "beam", "step", "hotword"])
+    ap.add_argument("--n-steps", type=int, default=64)
     ap.add_argument("--chunks", type=int, default=4)
     ap.add_argument("--B", type=int, default=32)
     ap.add_argument("--T", type=int, default=1000)
@@ -365,4 +412,4 @@ if __name__ == "__main__":
     if a.tile:
         from wenet_celoss_amd import _lib
         _lib.load().wr_tune_set(6, a.tile)
-    {"joint": bench_joint, "ctc": bench_ctc, "greedy": bench_greedy, "beam": bench_beam, "step": bench_step, "ctcdec": bench_ctcdec}[a.what](a)
+    {"joint": bench_joint, "ctc": bench_ctc, "greedy": bench_greedy, "beam": bench_beam, "step": bench_step, "ctcdec": bench_ctcdec, "hotword": bench_hotword}[a.what](a)

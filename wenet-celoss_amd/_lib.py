@@ -127,6 +127,9 @@ SIGNATURES = {
     "wr_greedy_search": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "wr_greedy_search_chunk": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "wr_prefix_beam_search": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "wr_hotword_workspace_bytes": (_sz, [_vp, _vp, _i]),
+    "wr_decoder_attach_hotword": (_i, [_vp, _vp, _i, _vp, _sz, _vp]),
+    "wr_greedy_search_hotword": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "wr_predictor_step": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "wr_ctc_align_workspace_bytes": (_sz, [_i, _i, _i]),
     "wr_ctc_forced_align": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
@@ -149,6 +152,15 @@ class TransducerWeights(ctypes.Structure):
                 ("enc_ffn_w", ctypes.c_void_p), ("enc_ffn_b", ctypes.c_void_p),
                 ("pred_ffn_w", ctypes.c_void_p), ("pred_ffn_b", ctypes.c_void_p),
                 ("out_w", ctypes.c_void_p), ("out_b", ctypes.c_void_p)]
+
+
+class HotwordWeights(ctypes.Structure):
+    """ctypes mirror of `wr_hotword_weights` (include/wr_api.h)."""
+    _PTRS = ["q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "o_w", "o_b", "bias_norm_w", "bias_norm_b", "combine_w", "combine_b",
+             "out_norm_w", "out_norm_b", "hw_enc_w", "hw_enc_b", "hw_v_w", "hw_v_b", "hw_o_w", "hw_o_b", "hw_norm_w",
+             "hw_norm_b", "hw_out_w", "hw_out_b"]
+    _fields_ = [("dim", ctypes.c_int32), ("heads", ctypes.c_int32), ("hw_dim", ctypes.c_int32), ("n_labels", ctypes.c_int32)] + \
+               [(n, ctypes.c_void_p) for n in _PTRS]
 
 
 def load():

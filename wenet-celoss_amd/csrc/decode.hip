@@ -107,6 +107,15 @@ struct DevState {
     int32_t *frame;               // [n_utt]
     int32_t *hyp_sel;             // [n_utt]
     int Lmax;
+    // hot-word greedy (wr_greedy_search_hotword): the state machine of greedy_search.py:297-430 on the device
+    int hw_on, hw_filter;         // mode flag; context_filter_state == 'on'
+    int hw_nctx[2];               // entries of the empty list (0) and of the hot-word list (1)
+    const int32_t *gate_tab;      // [n_utt, T]   top-1 of the hot-word gate per frame (hw_gate_table_kernel)
+    int32_t *cur_gate;            // [NLp] result[-1]: 1 = hot-word biasing, 0 = empty-list biasing
+    int32_t *gb_flag, *gb_end, *last_t;   // [NLp] go_back_flag, go_back_end, last_t
+    int32_t *trace, *trace_len;   // [NL, trace_cap] / [NL]: `result`, the gate trace
+    int trace_cap;
+    float *biasT;                 // [Pp][NLp] biased predictor output (input of pred_ffn in hot-word mode)
 };
 
 struct GemmArgs {
@@ -125,6 +134,8 @@ struct GemmArgs {
     const float *ep_all;          // [n_utt, T, J]
     int H, J;
     int look, lane_stride;        // joiner activation: frames per lane and the column stride between frames (NLp)
+    const int32_t *ep_gate;       // hot-word mode: per-lane selector of the encoder stream (ep_all + gate * ep_gate_stride)
+    size_t ep_gate_stride;
 };
 
 enum GemmEpilogue { kEpiKMajor = 0, kEpiRowMajor = 1, kEpiLstmCell = 2, kEpiJointAct = 3 };
@@ -154,7 +165,7 @@ __global__ void add_bias_kernel(const float *a, const float *b, int n, float *ou
 }
 
 // ep_all[row, :] = enc[row, :] @ enc_ffn^T + b     (rows = n_utt * T)
-__global__ __launch_bounds__(256) void ep_all_kernel(DevState *s)
+__global__ __launch_bounds__(256) void ep_all_kernel(DevState *s, const float *__restrict__ enc, float *__restrict__ ep_out)
 {
     extern __shared__ float xs[];              // [8][E]
     const Dims &d = s->d;
@@ -162,7 +173,7 @@ __global__ __launch_bounds__(256) void ep_all_kernel(DevState *s)
     const long r0 = (long)blockIdx.x * 8;
     for (int i = threadIdx.x; i < 8 * d.E; i += blockDim.x) {
         const long r = r0 + i / d.E;
-        xs[i] = (r < rows) ? s->enc[(size_t)r * d.E + i % d.E] : 0.f;
+        xs[i] = (r < rows) ? enc[(size_t)r * d.E + i % d.E] : 0.f;
     }
     __syncthreads();
     for (int j = threadIdx.x; j < d.J; j += blockDim.x) {
@@ -177,7 +188,7 @@ __global__ __launch_bounds__(256) void ep_all_kernel(DevState *s)
         const float b = s->encffn_b[j];
 #pragma unroll
         for (int r = 0; r < 8; ++r)
-            if (r0 + r < rows) s->ep_all[(size_t)(r0 + r) * d.J + j] = acc[r] + b;
+            if (r0 + r < rows) ep_out[(size_t)(r0 + r) * d.J + j] = acc[r] + b;
     }
 }
 
@@ -310,7 +321,8 @@ __global__ __launch_bounds__(64 * kGemmWaves) void lane_gemm_kernel(GemmArgs g)
                 const int i = tid + it * NT;
                 const int v = n0 + ((i & 1023) >> 5), n = lane0 + (i >> 10) * 32 + (i & 31);
                 const int t = tt[it] + f < T ? tt[it] + f : T - 1;
-                act_ep[f][it] = (act_on[it] && f < g.look) ? g.ep_all[((size_t)(n / lpu) * T + t) * g.J + v] : 0.f;
+                const size_t sel = g.ep_gate ? (size_t)g.ep_gate[act_on[it] ? n : 0] * g.ep_gate_stride : 0;
+                act_ep[f][it] = (act_on[it] && f < g.look) ? g.ep_all[sel + ((size_t)(n / lpu) * T + t) * g.J + v] : 0.f;
             }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -444,7 +456,13 @@ __global__ void greedy_chunk_init_kernel(DevState *s, int ref_new_cache)
 // NV = logits held per thread (V <= 256 * NV): the row is read once, all loads in flight together.  The lane's
 // scalars are fetched up front and the state machine runs redundantly in every thread (thread 0 stores), so the
 // kernel has one memory round trip before the reductions and one after.
-template <int NV>
+// HW = true: the hot-word variant (greedy_search.py:297-430).  The gate decision of the NEXT predictor step is made
+// here, right after the emission that causes that step -- the gate is a function of the frame alone (see
+// hw_gate_table_kernel), so it does not have to wait for the predictor.  A "go-back" (:369-385) withdraws exactly
+// the emission this kernel has just decided on (the reference pops the last token, predictor output, cache and
+// input and steps the predictor again from the popped state), so it costs nothing to undo: the token is not
+// appended, the cache not committed, the next input not replaced.
+template <int NV, bool HW>
 __global__ __launch_bounds__(256) void greedy_update_kernel(DevState *sp)
 {
     __shared__ float sv[4];
@@ -460,6 +478,15 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(DevState *sp)
     int nic = S.new_is_cache[n];
     const int len = S.hyp_lens[n];
     const int enc_len = S.enc_lens[n];
+    int gate_cur = 1, gb_flag = 0, gb_end = 0, last_t = 0, tlen = 0, gate_t0 = 1, gate_t1 = 1, last_gate = 1;
+    if (HW) {
+        gate_cur = S.cur_gate[n]; gb_flag = S.gb_flag[n]; gb_end = S.gb_end[n]; last_t = S.last_t[n];
+        tlen = S.trace_len[n];
+        const int tc = t < S.T ? t : S.T - 1, tn = t + 1 < S.T ? t + 1 : S.T - 1;
+        gate_t0 = S.gate_tab[(size_t)n * S.T + tc];                  // the next predictor step sees frame t or t + 1
+        gate_t1 = S.gate_tab[(size_t)n * S.T + tn];
+        last_gate = S.trace[(size_t)n * S.trace_cap + (tlen > 0 ? (tlen <= S.trace_cap ? tlen - 1 : S.trace_cap - 1) : 0)];
+    }
     const float *__restrict__ x = S.logits + (size_t)n * d.V;
     // log_softmax as the reference evaluates it: (x - max) - log(sum(exp(x - max)))
     float xv[NV];
@@ -490,8 +517,9 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(DevState *sp)
     const int k = bi;
     const bool emit = (k != S.blank);
     if (need) nic = 0;                             // the predictor stepped in this micro-step
-    const bool commit = emit && !nic;
+    bool commit = emit && !nic;
     int need_next = need;
+    const int t_dec = t;                           // the frame this decision was made on
     if (emit) { need_next = 1; nb += 1; }
     if (!emit || nb >= S.n_steps) {
         if (!emit) need_next = 0;
@@ -499,10 +527,38 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(DevState *sp)
         nb = 0;
     }
     const int T = enc_len < S.T ? enc_len : S.T;
+    // hot-word gate of the predictor step this emission leads to (greedy_search.py:357-392)
+    bool withdraw = false;
+    int push0 = -1, push1 = -1;                    // values appended to the trace (after an optional pop)
+    bool pop = false;
+    if (HW && emit && t < T) {
+        const int gt = (t == t_dec) ? gate_t0 : gate_t1;
+        if (S.hw_filter) {
+            if (!gb_flag) {
+                if (gt == 0) { push0 = 0; last_t = t; gate_cur = 0; }
+                else if (tlen > 0 && last_gate == 0) {
+                    // go-back: forget the gate-0 step and the token it produced, resume from its frame with biasing on
+                    withdraw = true;
+                    gb_end = t; t = last_t; gb_flag = 1;
+                    pop = true;
+                    nb -= 1;
+                    push0 = 1;                     // the re-run step is recorded with the gate forced to 1 (:388-391)
+                    if (t >= gb_end) gb_flag = 0;
+                    gate_cur = 1;
+                } else { push0 = 1; gate_cur = 1; }
+            } else {
+                push0 = 1;
+                if (t >= gb_end) gb_flag = 0;
+                gate_cur = 1;
+            }
+        } else { push0 = 1; gate_cur = 1; }
+    }
+    (void)push1;
+    if (withdraw) commit = false;
     if (tid == 0) {
         atomicAdd(S.active_count + (emit ? 2 : 1), 1);               // decision statistics for the look-ahead policy
         if (need) S.new_is_cache[n] = 0;
-        if (emit) {
+        if (emit && !withdraw) {
             if (len < S.max_hyp) S.hyps[(size_t)n * S.max_hyp + len] = k;
             S.hyp_lens[n] = len + 1;
             S.token[n] = k;
@@ -510,12 +566,24 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(DevState *sp)
         S.need_pred[n] = need_next;
         S.lane_t[n] = t;
         S.noblk[n] = nb;
+        if (HW) {
+            int tl = tlen - (pop ? 1 : 0);
+            if (push0 >= 0) {
+                if (tl < S.trace_cap) S.trace[(size_t)n * S.trace_cap + tl] = push0;
+                tl += 1;
+            }
+            S.trace_len[n] = tl;
+            S.cur_gate[n] = gate_cur;
+            S.gb_flag[n] = gb_flag;
+            S.gb_end[n] = gb_end;
+            S.last_t[n] = last_t;
+        }
         if (t >= T) {
             S.lane_active[n] = 0;
             atomicSub(S.active_count, 1);
         }
     }
-    if (emit) {                                    // next predictor input
+    if (emit && !withdraw) {                       // next predictor input
         for (int q = tid; q < d.D; q += 256) S.xT[(size_t)q * d.NLp + n] = S.embed[(size_t)k * d.D + q];
     }
     if (commit) {                                  // cache = new_cache (greedy_search copy.py:52)
@@ -638,6 +706,229 @@ __global__ __launch_bounds__(256) void greedy_resolve_kernel(DevState *sp, int l
             S.cache_cT[o] = S.new_cT[o];
         }
     }
+}
+
+// ------------------------------------------------------- hot-word greedy --
+// Device copy of the ContextBias weights the greedy loop uses (wenet/transformer/context_bias.py:375-394), re-laid
+// k-major where a thread block streams them (see wr_decoder_attach_hotword).
+struct HwDev {
+    int D, heads, HW, NLAB, max_ctx;
+    const float *q_wt, *q_b;          // [D][D] k-major
+    const float *k_w, *k_b, *v_w, *v_b;   // row-major (nn.Linear), used once per call for the list projections
+    const float *o_wt, *o_b;          // [D][D] k-major
+    const float *bn_w, *bn_b;         // predictor_bias_bias_norm
+    const float *c_wt, *c_b;          // [2D][D] k-major
+    const float *on_w, *on_b;         // predictor_bias_out_norm
+    const float *he_w, *he_b, *hv_w, *hv_b, *ho_w, *ho_b, *hn_w, *hn_b, *hl_w, *hl_b;   // gate chain, row-major
+    float *kbuf[2], *vbuf[2];         // [max_ctx][D]: K / V of the empty list (0) and of the hot-word list (1)
+    int32_t *gate_tab;                // [max_utt * Tmax]
+};
+
+// K / V projections of an encoded context list: out[c][j] = b[j] + sum_k hidden[c][k] * W[j][k].
+// grid (n_ctx, 2): y = 0 -> K, 1 -> V.  A wave per output, lanes over k (row-major weights: coalesced), wave_sum.
+__global__ __launch_bounds__(256) void hw_kv_kernel(HwDev hw, const float *__restrict__ hidden, int list)
+{
+    const int c = blockIdx.x, which = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *__restrict__ W = which ? hw.v_w : hw.k_w;
+    const float *__restrict__ bb = which ? hw.v_b : hw.k_b;
+    float *__restrict__ out = (which ? hw.vbuf[list] : hw.kbuf[list]) + (size_t)c * hw.D;
+    const float *__restrict__ x = hidden + (size_t)c * hw.D;
+    for (int j = wave; j < hw.D; j += 4) {
+        float acc = 0.f;
+        for (int k = lane; k < hw.D; k += 64) acc = fmaf(W[(size_t)j * hw.D + k], x[k], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) out[j] = acc + bb[j];
+    }
+}
+
+// y[j] = b[j] + sum_k W[j][k] * x[k] for a small row-major Linear inside one workgroup (x, y in LDS): a wave per output
+__device__ __forceinline__ void block_linear_rowmajor(const float *__restrict__ W, const float *__restrict__ b, const float *x,
+                                                      int K, int N, float *y)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int j = wave; j < N; j += nw) {
+        float acc = 0.f;
+        for (int k = lane; k < K; k += 64) acc = fmaf(W[(size_t)j * K + k], x[k], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) y[j] = acc + b[j];
+    }
+    __syncthreads();
+}
+
+// LayerNorm over v[0..N) (LDS) as torch.nn.LayerNorm: biased variance, eps = 1e-5.  Result through `emit(j, value)`.
+template <typename F>
+__device__ __forceinline__ void block_layer_norm(const float *v, int N, const float *__restrict__ w, const float *__restrict__ b,
+                                                 float *sv, F emit)
+{
+    float s = 0.f;
+    for (int j = threadIdx.x; j < N; j += blockDim.x) s += v[j];
+    const float mean = block_sum(s, sv) / (float)N;
+    float q = 0.f;
+    for (int j = threadIdx.x; j < N; j += blockDim.x) { const float dlt = v[j] - mean; q += dlt * dlt; }
+    const float var = block_sum(q, sv) / (float)N;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    for (int j = threadIdx.x; j < N; j += blockDim.x) emit(j, (v[j] - mean) * rstd * w[j] + b[j]);
+    __syncthreads();
+}
+
+// The hot-word gate of every frame (ContextBias.forward_hw_pred_both, context_bias.py:388-394, then topk(1) as
+// greedy_search.py:359-364).  hw_bias attends from one query (the predictor-side feature) to ONE key / value (the
+// encoder-side feature of frame t): softmax over a single score is exactly 1.0, so the attention output is exactly
+// linear_out(linear_v(hw_output_layer_enc(enc_feat[t]))) whatever the query is -- the gate depends on the frame
+// alone and is evaluated for all frames before the loop.  One workgroup per frame.
+__global__ __launch_bounds__(256) void hw_gate_table_kernel(HwDev hw, const float *__restrict__ enc_feat, long rows)
+{
+    extern __shared__ float sm[];                   // x[D] | a[HW] | b[HW]
+    __shared__ float sv[4];
+    float *x = sm, *a = sm + hw.D, *bq = a + hw.HW;
+    const long r = blockIdx.x;
+    if (r >= rows) return;
+    for (int k = threadIdx.x; k < hw.D; k += blockDim.x) x[k] = enc_feat[(size_t)r * hw.D + k];
+    __syncthreads();
+    block_linear_rowmajor(hw.he_w, hw.he_b, x, hw.D, hw.HW, a);         // hw_output_layer_enc
+    block_linear_rowmajor(hw.hv_w, hw.hv_b, a, hw.HW, hw.HW, bq);       // hw_bias.linear_v  (attention weight == 1)
+    block_linear_rowmajor(hw.ho_w, hw.ho_b, bq, hw.HW, hw.HW, a);       // hw_bias.linear_out
+    block_layer_norm(a, hw.HW, hw.hn_w, hw.hn_b, sv, [&](int j, float v) { bq[j] = v; });   // hw_bias_norm
+    block_linear_rowmajor(hw.hl_w, hw.hl_b, bq, hw.HW, hw.NLAB, a);     // hw_output_layer
+    if (threadIdx.x == 0) {
+        int best = 0;
+        for (int j = 1; j < hw.NLAB; ++j)
+            if (a[j] > a[best]) best = j;            // topk(1): the largest, first index on ties
+        hw.gate_tab[r] = best;
+    }
+}
+
+// y[j] = b[j] + sum_k WT[k][j] * x[k] with the K range split over the 16 waves of the workgroup (every wave has its
+// whole share of the k-major weight rows in flight at once), partial sums through LDS.  x, y, part in LDS.
+constexpr int kHwThreads = 1024;
+__device__ __forceinline__ void block_gemv_kmajor(const float *__restrict__ WT, int ldw, const float *__restrict__ b, const float *x,
+                                                  int K, int N, float *part, float *y)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = kHwThreads / 64;
+    const int kper = (K + NW - 1) / NW;
+    const int k0 = wave * kper;
+    int k1 = k0 + kper;
+    k1 = k1 < K ? k1 : K;
+    for (int j0 = 0; j0 < N; j0 += 256) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int k = k0; k < k1; ++k) {
+            const float xv = x[k];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = j0 + lane + 64 * i;
+                acc[i] = fmaf(WT[(size_t)k * ldw + (j < N ? j : N - 1)], xv, acc[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = j0 + lane + 64 * i;
+            if (j < N) part[wave * N + j] = acc[i];
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < N; j += kHwThreads) {
+        float sacc = b[j];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sacc += part[w * N + j];
+        y[j] = sacc;
+    }
+    __syncthreads();
+}
+
+// ContextBias.forward_predictor_bias (context_bias.py:375-381) for the lanes whose predictor has just stepped, with
+// the list the gate selected (cur_gate: 1 = hot words, 0 = empty list -- greedy_search.py:357,394-395 evaluate the hot
+// variant first and replace it when the gate says 0; only the one that reaches the joiner is computed here):
+//   pb  = predictor_bias_bias_norm(MultiHeadedAttention(query = pred, key = value = bias_hidden))
+//   out = predictor_bias_out_norm(predictor_bias_combine(cat(pred, pb)))
+// One workgroup per lane; K / V of both lists were projected once per call (hw_kv_kernel).
+__global__ __launch_bounds__(kHwThreads) void hw_bias_kernel(DevState *sp, HwDev hw)
+{
+    extern __shared__ float sm[];                   // x[D] q[D] ctx[D] o[D] pb[D] | part[16][D] | p[heads * max_ctx]
+    __shared__ float sv[kHwThreads / 64];
+    const DevState S = *sp;
+    const Dims &d = S.d;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    if (!S.lane_active[n] || !S.need_pred[n]) return;             // after a blank the predictor output is kept
+    const int D = hw.D, g = S.cur_gate[n] ? 1 : 0;
+    const int nctx = S.hw_nctx[g];
+    const float *__restrict__ Kb = hw.kbuf[g];
+    const float *__restrict__ Vb = hw.vbuf[g];
+    float *x = sm, *q = sm + D, *ctx = sm + 2 * D, *o = sm + 3 * D, *pb = sm + 4 * D;
+    float *part = sm + 5 * D, *p = part + (kHwThreads / 64) * D;
+    for (int j = tid; j < D; j += kHwThreads) x[j] = S.outT[(size_t)j * d.NLp + n];
+    __syncthreads();
+    block_gemv_kmajor(hw.q_wt, D, hw.q_b, x, D, D, part, q);         // linear_q
+    // scores[h][c] = q_h . k_{c,h} / sqrt(d_k)   (attention.py:185)
+    const int dk = D / hw.heads;
+    const float sq = sqrtf((float)dk);
+    for (int idx = tid; idx < hw.heads * nctx; idx += kHwThreads) {
+        const int hh = idx / nctx, c = idx - hh * nctx;
+        const float *__restrict__ kr = Kb + (size_t)c * D + hh * dk;
+        float acc = 0.f;
+        for (int e = 0; e < dk; ++e) acc = fmaf(q[hh * dk + e], kr[e], acc);
+        p[idx] = acc / sq;
+    }
+    __syncthreads();
+    {   // softmax over the list, one wave per head (torch.softmax: exp(x - max) / sum)
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int hh = wave; hh < hw.heads; hh += kHwThreads / 64) {
+            float mx = -3.0e38f;
+            for (int c = lane; c < nctx; c += 64) mx = fmaxf(mx, p[hh * nctx + c]);
+            mx = wave_max(mx);
+            float ssum = 0.f;
+            for (int c = lane; c < nctx; c += 64) { const float e = expf(p[hh * nctx + c] - mx); p[hh * nctx + c] = e; ssum += e; }
+            ssum = wave_sum(ssum);
+            for (int c = lane; c < nctx; c += 64) p[hh * nctx + c] = p[hh * nctx + c] / ssum;
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < D; j += kHwThreads) {                      // context = attn @ v
+        const int hh = j / dk;
+        float acc = 0.f;
+        for (int c = 0; c < nctx; ++c) acc = fmaf(p[hh * nctx + c], Vb[(size_t)c * D + j], acc);
+        ctx[j] = acc;
+    }
+    __syncthreads();
+    block_gemv_kmajor(hw.o_wt, D, hw.o_b, ctx, D, D, part, o);       // linear_out
+    block_layer_norm(o, D, hw.bn_w, hw.bn_b, sv, [&](int j, float v) { pb[j] = v; });
+    // combine over cat(pred, pb): two K segments of the k-major [2D][D] weight; q / ctx are free again
+    block_gemv_kmajor(hw.c_wt, D, hw.c_b, x, D, D, part, q);
+    block_gemv_kmajor(hw.c_wt + (size_t)D * D, D, q, pb, D, D, part, ctx);   // "bias" = the first segment's sums
+    block_layer_norm(ctx, D, hw.on_w, hw.on_b, sv, [&](int j, float v) { S.biasT[(size_t)j * d.NLp + n] = v; });
+}
+
+__global__ void greedy_hw_init_kernel(DevState *s)
+{
+    const Dims &d = s->d;
+    const int n = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < d.L * d.Hp; i += blockDim.x) {
+        const size_t o = (size_t)i * d.NLp + n;
+        s->cache_hT[o] = 0.f; s->cache_cT[o] = 0.f; s->new_hT[o] = 0.f; s->new_cT[o] = 0.f;
+    }
+    if (tid == 0) {
+        const int T = s->enc_lens[n] < s->T ? s->enc_lens[n] : s->T;
+        s->token[n] = s->blank;
+        s->lane_t[n] = 0;
+        s->noblk[n] = 0;
+        s->need_pred[n] = 1;
+        s->new_is_cache[n] = 0;
+        s->hyp_lens[n] = 0;
+        const int act = T > 0;
+        s->lane_active[n] = act;
+        if (act) atomicAdd(s->active_count, 1);
+        // gate of the first predictor step (frame 0): nothing to go back to yet (greedy_search.py:365-368,386)
+        int gate = 1;
+        if (act && s->hw_filter && s->gate_tab[(size_t)n * s->T] == 0) gate = 0;
+        s->cur_gate[n] = gate;
+        s->gb_flag[n] = 0; s->gb_end[n] = -1; s->last_t[n] = 0;
+        if (act && s->trace_cap > 0) s->trace[(size_t)n * s->trace_cap] = gate;
+        s->trace_len[n] = act ? 1 : 0;
+    }
+    write_embedding_column(s, n, s->blank);
 }
 
 // ------------------------------------------------------------------ beam --
@@ -1023,6 +1314,14 @@ struct wr_decoder {
     int beam_graph_lanes;
     int stream_lanes;             // lanes whose streaming state (cache, token, flags) is live; -1: none
     int look;                     // greedy look-ahead: frames per micro-step (1..kMaxLook), 0: chosen per replay
+    // hot-word greedy (wr_decoder_attach_hotword)
+    bool hw_attached;
+    HwDev hw;
+    float *hw_ep2;                // [2][max_utt * Tmax * J] enc_ffn of the empty-list (0) / hot-word (1) encoder stream
+    int32_t *hw_state;            // cur_gate | gb_flag | gb_end | last_t, NLp each
+    float *hw_biasT;              // [Pp][NLp]
+    hipGraphExec_t hw_graph;
+    int hw_graph_key;
     bool use_graph;               // greedy micro-steps replayed from a hipGraph (default on)
     bool use_graph_beam;          // beam frames: plain launches measured faster (no host polling to amortise), default off
 };
@@ -1212,6 +1511,7 @@ extern "C" int wr_decoder_create(const wr_transducer_weights *w, int max_lanes, 
     h->max_utt = max_utt; h->Tmax = Tmax; h->max_hyp = max_hyp; h->max_beam = max_beam;
     for (int i = 0; i <= kMaxLook; ++i) { h->greedy_graph[i] = nullptr; h->greedy_graph_key[i] = -1; }
     h->beam_graph = nullptr; h->beam_graph_lanes = -1;
+    h->hw_attached = false; h->hw_graph = nullptr; h->hw_graph_key = -1;
     h->use_graph = true;
     h->use_graph_beam = false;
     h->look = 0;
@@ -1270,6 +1570,7 @@ extern "C" int wr_decoder_destroy(wr_decoder *h)
     for (int i = 0; i <= kMaxLook; ++i)
         if (h->greedy_graph[i]) (void)hipGraphExecDestroy(h->greedy_graph[i]);
     if (h->beam_graph) (void)hipGraphExecDestroy(h->beam_graph);
+    if (h->hw_graph) (void)hipGraphExecDestroy(h->hw_graph);
     (void)hipStreamSynchronize(h->work);
     if (h->h_active) (void)hipHostFree(h->h_active);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -1316,9 +1617,9 @@ void greedy_micro_step(wr_decoder *h, int n_lanes, hipStream_t st, int look)
     launch_predictor_and_joint(h, n_lanes, st, look);
     const int V = h->d.V;                           // <= 16384 (check_weights)
     if (look == 1) {
-        if (V <= 256 * 8) hipLaunchKernelGGL(greedy_update_kernel<8>, dim3(n_lanes), dim3(256), 0, st, h->dev);
-        else if (V <= 256 * 24) hipLaunchKernelGGL(greedy_update_kernel<24>, dim3(n_lanes), dim3(256), 0, st, h->dev);
-        else hipLaunchKernelGGL(greedy_update_kernel<64>, dim3(n_lanes), dim3(256), 0, st, h->dev);
+        if (V <= 256 * 8) hipLaunchKernelGGL((greedy_update_kernel<8, false>), dim3(n_lanes), dim3(256), 0, st, h->dev);
+        else if (V <= 256 * 24) hipLaunchKernelGGL((greedy_update_kernel<24, false>), dim3(n_lanes), dim3(256), 0, st, h->dev);
+        else hipLaunchKernelGGL((greedy_update_kernel<64, false>), dim3(n_lanes), dim3(256), 0, st, h->dev);
         return;
     }
     const dim3 grid(n_lanes, look);
@@ -1389,6 +1690,7 @@ WorkScope::~WorkScope()
         h->stream_lanes = -1;
         for (int i = 0; i <= kMaxLook; ++i) h->greedy_graph_key[i] = -1;
         h->beam_graph_lanes = -1;
+        h->hw_graph_key = -1;
     }
     leave(h, caller);
 }
@@ -1413,7 +1715,7 @@ int greedy_run(wr_decoder *h, const float *enc_out_d, const int32_t *enc_lens_d,
     (void)hipMemsetAsync(s.active_count, 0, 3 * sizeof(int32_t), st);    // lanes active, blank decisions, emissions
     (void)hipMemsetAsync(s.lane_active, 0, sizeof(int32_t) * h->d.NLp, st);
     hipLaunchKernelGGL(ep_all_kernel, dim3((unsigned)(((long)N * T + 7) / 8)), dim3(256), (size_t)8 * h->d.E * sizeof(float), st,
-                       h->dev);
+                       h->dev, enc_out_d, s.ep_all);
     if (mode == 0) hipLaunchKernelGGL(greedy_init_kernel, dim3(N), dim3(128), 0, st, h->dev);
     else hipLaunchKernelGGL(greedy_chunk_init_kernel, dim3(N), dim3(128), 0, st, h->dev, mode == 2 ? 1 : 0);
     WR_CHECK_LAUNCH("greedy_init");
@@ -1495,7 +1797,7 @@ extern "C" int wr_prefix_beam_search(wr_decoder *h, const float *enc_out_d, cons
     (void)hipMemsetAsync(s.lane_active, 0, sizeof(int32_t) * h->d.NLp, st);
     const int NLn = B * beam;
     hipLaunchKernelGGL(ep_all_kernel, dim3((unsigned)(((long)B * T + 7) / 8)), dim3(256), (size_t)8 * h->d.E * sizeof(float), st,
-                       h->dev);
+                       h->dev, enc_out_d, s.ep_all);
     hipLaunchKernelGGL(beam_init_kernel, dim3(NLn), dim3(128), 0, st, h->dev);
     WR_CHECK_LAUNCH("beam_init");
     const int key = NLn * 1000 + beam;
@@ -1576,6 +1878,190 @@ extern "C" int wr_predictor_step(wr_decoder *h, const int32_t *tokens_d, const f
     hipLaunchKernelGGL(cache_from_kmajor_kernel, dim3(64), dim3(256), 0, st, s.new_hT, N, d.L, d.H, d.Hp, d.NLp, new_h_d);
     hipLaunchKernelGGL(cache_from_kmajor_kernel, dim3(64), dim3(256), 0, st, s.new_cT, N, d.L, d.H, d.Hp, d.NLp, new_c_d);
     WR_CHECK_LAUNCH("predictor_step");
+    scope.ok();
+    return WR_OK;
+}
+
+// ------------------------------------------------------------ hot-word greedy: host side --
+namespace {
+
+struct HwCarve {
+    size_t q_wt, o_wt, c_wt, kbuf[2], vbuf[2], gate_tab, ep2, state, biasT, total;
+};
+
+HwCarve hw_carve(const wr_decoder *h, int D, int max_ctx)
+{
+    HwCarve c;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = align_up(off, 256); off = o + bytes; return o; };
+    const Dims &d = h->d;
+    c.q_wt = take((size_t)D * D * sizeof(float));
+    c.o_wt = take((size_t)D * D * sizeof(float));
+    c.c_wt = take((size_t)2 * D * D * sizeof(float));
+    for (int i = 0; i < 2; ++i) { c.kbuf[i] = take((size_t)max_ctx * D * sizeof(float)); c.vbuf[i] = take((size_t)max_ctx * D * sizeof(float)); }
+    c.gate_tab = take((size_t)h->max_utt * h->Tmax * sizeof(int32_t));
+    c.ep2 = take((size_t)2 * h->max_utt * h->Tmax * d.J * sizeof(float));
+    c.state = take((size_t)4 * d.NLp * sizeof(int32_t));
+    c.biasT = take((size_t)d.Pp * d.NLp * sizeof(float));
+    c.total = align_up(off, 256);
+    return c;
+}
+
+int hw_check(const wr_decoder *h, const wr_hotword_weights *hw, int max_ctx)
+{
+    WR_REQUIRE(h && hw, WR_EINVAL, "hotword: null pointer argument");
+    WR_REQUIRE(hw->dim > 0 && hw->heads > 0 && hw->hw_dim > 0 && hw->n_labels > 0 && max_ctx > 0, WR_EINVAL,
+               "hotword: non-positive dimension");
+    WR_REQUIRE(hw->dim == h->d.E && hw->dim == h->d.P, WR_EINVAL,
+               "hotword: dim=%d must equal the encoder (%d) and predictor (%d) output sizes", hw->dim, h->d.E, h->d.P);
+    WR_REQUIRE(hw->dim <= 512 && hw->hw_dim <= 256 && hw->n_labels <= 8 && hw->dim % hw->heads == 0 && hw->heads <= 16, WR_EUNSUPPORTED,
+               "hotword: dim=%d (<= 512), hw_dim=%d (<= 256), n_labels=%d (<= 8), heads=%d (divides dim, <= 16)", hw->dim,
+               hw->hw_dim, hw->n_labels, hw->heads);
+    WR_REQUIRE((size_t)(21 * hw->dim + hw->heads * max_ctx) * sizeof(float) <= 60 * 1024, WR_EUNSUPPORTED,
+               "hotword: max_ctx=%d does not fit the bias kernel's LDS", max_ctx);
+    WR_REQUIRE(hw->q_w && hw->q_b && hw->k_w && hw->k_b && hw->v_w && hw->v_b && hw->o_w && hw->o_b && hw->bias_norm_w &&
+                   hw->bias_norm_b && hw->combine_w && hw->combine_b && hw->out_norm_w && hw->out_norm_b && hw->hw_enc_w &&
+                   hw->hw_enc_b && hw->hw_v_w && hw->hw_v_b && hw->hw_o_w && hw->hw_o_b && hw->hw_norm_w && hw->hw_norm_b &&
+                   hw->hw_out_w && hw->hw_out_b, WR_EINVAL, "hotword: null weight pointer");
+    return WR_OK;
+}
+
+void hw_micro_step(wr_decoder *h, int n_lanes, hipStream_t st)
+{
+    const Dims &d = h->d;
+    const DevState &s = h->host;
+    auto up = [](int x, int m) { return (x + m - 1) / m * m; };
+    launch_predictor(h, n_lanes, st);
+    const size_t lds = (size_t)(21 * h->hw.D + h->hw.heads * h->hw.max_ctx) * sizeof(float);
+    hipLaunchKernelGGL(hw_bias_kernel, dim3(n_lanes), dim3(kHwThreads), lds, st, h->dev, h->hw);
+    {   // pred_ffn of the biased predictor output; the joiner activation takes the encoder stream the gate selected
+        GemmArgs g{};
+        g.A0 = h->hw_biasT; g.B0 = s.predffn_wt; g.K0 = d.Pp;
+        g.lda = d.NLp; g.ldb = up(d.J, 32); g.bias = s.predffn_b; g.C = s.ht; g.ldc = kMaxLook * d.NLp; g.N = d.J; g.n_lanes = n_lanes;
+        g.st = h->dev; g.lane_active = s.lane_active; g.lane_t = s.lane_t; g.ep_all = h->hw_ep2; g.J = d.J;
+        g.look = 1; g.lane_stride = d.NLp;
+        g.ep_gate = h->hw_state; g.ep_gate_stride = (size_t)h->max_utt * h->Tmax * d.J;
+        launch_gemm<kEpiJointAct>(g, up(d.J, 32), n_lanes, st);
+    }
+    GemmArgs g{};
+    g.A0 = s.ht; g.B0 = s.out_wt; g.K0 = d.Jp;
+    g.lda = kMaxLook * d.NLp; g.ldb = d.Vp; g.bias = s.out_b; g.C = s.logits; g.ldc = d.V; g.N = d.V; g.n_lanes = n_lanes;
+    launch_gemm<kEpiRowMajor>(g, d.Vp, n_lanes, st);
+    const int V = d.V;
+    if (V <= 256 * 8) hipLaunchKernelGGL((greedy_update_kernel<8, true>), dim3(n_lanes), dim3(256), 0, st, h->dev);
+    else if (V <= 256 * 24) hipLaunchKernelGGL((greedy_update_kernel<24, true>), dim3(n_lanes), dim3(256), 0, st, h->dev);
+    else hipLaunchKernelGGL((greedy_update_kernel<64, true>), dim3(n_lanes), dim3(256), 0, st, h->dev);
+}
+
+}  // namespace
+
+extern "C" size_t wr_hotword_workspace_bytes(const wr_decoder *h, const wr_hotword_weights *hw, int max_ctx)
+{
+    if (!h || !hw || hw->dim <= 0 || max_ctx <= 0) return 0;
+    return hw_carve(h, hw->dim, max_ctx).total;
+}
+
+extern "C" int wr_decoder_attach_hotword(wr_decoder *h, const wr_hotword_weights *hw, int max_ctx, void *workspace_d,
+                                         size_t workspace_bytes, void *stream)
+{
+    if (int rc = hw_check(h, hw, max_ctx)) return rc;
+    WR_REQUIRE(workspace_d != nullptr, WR_EINVAL, "decoder_attach_hotword: null workspace");
+    const HwCarve c = hw_carve(h, hw->dim, max_ctx);
+    WR_REQUIRE(workspace_bytes >= c.total, WR_EWORKSPACE, "decoder_attach_hotword: workspace %zu < required %zu", workspace_bytes,
+               c.total);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char *ws = static_cast<char *>(workspace_d);
+    const int D = hw->dim;
+    HwDev &v = h->hw;
+    v.D = D; v.heads = hw->heads; v.HW = hw->hw_dim; v.NLAB = hw->n_labels; v.max_ctx = max_ctx;
+    float *q_wt = reinterpret_cast<float *>(ws + c.q_wt), *o_wt = reinterpret_cast<float *>(ws + c.o_wt);
+    float *c_wt = reinterpret_cast<float *>(ws + c.c_wt);
+    launch_transpose(hw->q_w, D, D, D, D, q_wt, st);                  // [out][in] -> [in][out]
+    launch_transpose(hw->o_w, D, D, D, D, o_wt, st);
+    launch_transpose(hw->combine_w, D, 2 * D, D, 2 * D, c_wt, st);    // [D][2D] -> [2D][D]
+    WR_CHECK_LAUNCH("decoder_attach_hotword (weight transposes)");
+    v.q_wt = q_wt; v.q_b = hw->q_b; v.k_w = hw->k_w; v.k_b = hw->k_b; v.v_w = hw->v_w; v.v_b = hw->v_b;
+    v.o_wt = o_wt; v.o_b = hw->o_b; v.bn_w = hw->bias_norm_w; v.bn_b = hw->bias_norm_b;
+    v.c_wt = c_wt; v.c_b = hw->combine_b; v.on_w = hw->out_norm_w; v.on_b = hw->out_norm_b;
+    v.he_w = hw->hw_enc_w; v.he_b = hw->hw_enc_b; v.hv_w = hw->hw_v_w; v.hv_b = hw->hw_v_b; v.ho_w = hw->hw_o_w;
+    v.ho_b = hw->hw_o_b; v.hn_w = hw->hw_norm_w; v.hn_b = hw->hw_norm_b; v.hl_w = hw->hw_out_w; v.hl_b = hw->hw_out_b;
+    for (int i = 0; i < 2; ++i) {
+        v.kbuf[i] = reinterpret_cast<float *>(ws + c.kbuf[i]);
+        v.vbuf[i] = reinterpret_cast<float *>(ws + c.vbuf[i]);
+    }
+    v.gate_tab = reinterpret_cast<int32_t *>(ws + c.gate_tab);
+    h->hw_ep2 = reinterpret_cast<float *>(ws + c.ep2);
+    h->hw_state = reinterpret_cast<int32_t *>(ws + c.state);
+    h->hw_biasT = reinterpret_cast<float *>(ws + c.biasT);
+    (void)hipMemsetAsync(h->hw_biasT, 0, (size_t)h->d.Pp * h->d.NLp * sizeof(float), st);   // padded rows / lanes stay zero
+    h->hw_attached = true;
+    h->hw_graph_key = -1;
+    return WR_OK;
+}
+
+extern "C" int wr_greedy_search_hotword(wr_decoder *h, const float *enc_hot_d, const float *enc_cold_d, const float *enc_feat_d,
+                                        const int32_t *enc_lens_d, const float *hidden_hot_d, int n_ctx_hot,
+                                        const float *hidden_cold_d, int n_ctx_cold, int N, int T, int n_steps, int blank,
+                                        int filter_on, int32_t *hyps_d, int32_t *hyp_lens_d, int32_t *trace_d, int trace_cap,
+                                        int32_t *trace_lens_d, void *stream)
+{
+    WR_REQUIRE(h && enc_hot_d && enc_cold_d && enc_feat_d && enc_lens_d && hidden_hot_d && hidden_cold_d && hyps_d &&
+                   hyp_lens_d && trace_d && trace_lens_d, WR_EINVAL, "greedy_search_hotword: null pointer argument");
+    WR_REQUIRE(h->hw_attached, WR_EINVAL, "greedy_search_hotword: call wr_decoder_attach_hotword first");
+    WR_REQUIRE(N > 0 && N <= h->d.NL && N <= h->max_utt, WR_EINVAL, "greedy_search_hotword: N=%d exceeds the decoder's capacity", N);
+    WR_REQUIRE(T > 0 && T <= h->Tmax, WR_EINVAL, "greedy_search_hotword: T=%d exceeds the decoder's Tmax=%d", T, h->Tmax);
+    WR_REQUIRE(n_steps >= 1 && blank >= 0 && blank < h->d.V && trace_cap >= 1, WR_EINVAL, "greedy_search_hotword: bad n_steps/blank/trace_cap");
+    WR_REQUIRE(n_ctx_hot >= 1 && n_ctx_hot <= h->hw.max_ctx && n_ctx_cold >= 1 && n_ctx_cold <= h->hw.max_ctx, WR_EINVAL,
+               "greedy_search_hotword: context lists of %d / %d entries (1..%d)", n_ctx_hot, n_ctx_cold, h->hw.max_ctx);
+    h->stream_lanes = -1;                         // the lanes' streaming state is overwritten
+    WorkScope scope(h, static_cast<hipStream_t>(stream));
+    hipStream_t st = scope.st;
+    const Dims &d = h->d;
+    DevState &s = h->host;
+    s.enc = enc_hot_d; s.enc_lens = enc_lens_d; s.ctc_logp = nullptr;
+    s.n_utt = N; s.T = T; s.lanes_per_utt = 1; s.n_lanes = N;
+    s.hyps = hyps_d; s.hyp_lens = hyp_lens_d; s.max_hyp = h->max_hyp; s.n_steps = n_steps; s.blank = blank; s.beam = 1;
+    s.hw_on = 1; s.hw_filter = filter_on ? 1 : 0; s.hw_nctx[0] = n_ctx_cold; s.hw_nctx[1] = n_ctx_hot;
+    s.gate_tab = h->hw.gate_tab;
+    s.cur_gate = h->hw_state; s.gb_flag = h->hw_state + d.NLp; s.gb_end = h->hw_state + 2 * d.NLp; s.last_t = h->hw_state + 3 * d.NLp;
+    s.trace = trace_d; s.trace_len = trace_lens_d; s.trace_cap = trace_cap;
+    s.biasT = h->hw_biasT;
+    const int rc_up = upload_state(h, st);
+    s.hw_on = 0;                                  // the host copy goes back to plain greedy for the other entry points
+    if (rc_up) return rc_up;
+    (void)hipMemsetAsync(s.active_count, 0, 3 * sizeof(int32_t), st);
+    (void)hipMemsetAsync(s.lane_active, 0, sizeof(int32_t) * d.NLp, st);
+    // loop-invariant work: list projections, the gate of every frame, enc_ffn of both encoder streams
+    hipLaunchKernelGGL(hw_kv_kernel, dim3(n_ctx_cold, 2), dim3(256), 0, st, h->hw, hidden_cold_d, 0);
+    hipLaunchKernelGGL(hw_kv_kernel, dim3(n_ctx_hot, 2), dim3(256), 0, st, h->hw, hidden_hot_d, 1);
+    hipLaunchKernelGGL(hw_gate_table_kernel, dim3((unsigned)((long)N * T)), dim3(256),
+                       (size_t)(h->hw.D + 2 * h->hw.HW) * sizeof(float), st, h->hw, enc_feat_d, (long)N * T);
+    const size_t ep_stride = (size_t)h->max_utt * h->Tmax * d.J;
+    const dim3 ep_grid((unsigned)(((long)N * T + 7) / 8));
+    hipLaunchKernelGGL(ep_all_kernel, ep_grid, dim3(256), (size_t)8 * d.E * sizeof(float), st, h->dev, enc_cold_d, h->hw_ep2);
+    hipLaunchKernelGGL(ep_all_kernel, ep_grid, dim3(256), (size_t)8 * d.E * sizeof(float), st, h->dev, enc_hot_d, h->hw_ep2 + ep_stride);
+    hipLaunchKernelGGL(greedy_hw_init_kernel, dim3(N), dim3(128), 0, st, h->dev);
+    WR_CHECK_LAUNCH("greedy_search_hotword (setup)");
+    // every go-back re-decodes frames, at most once per 0 -> 1 flip of the gate: twice the plain loop's bound
+    const long max_micro = 2 * ((long)T * ((long)n_steps + 2) + 1);
+    for (long done = 0; done < max_micro; done += kStepsPerGraph) {
+        if (h->use_graph) {
+            if (h->hw_graph_key != N) {
+                if (h->hw_graph) { (void)hipGraphExecDestroy(h->hw_graph); h->hw_graph = nullptr; }
+                if (int rc = capture(st, kStepsPerGraph, [&] { hw_micro_step(h, N, st); }, &h->hw_graph)) return rc;
+                h->hw_graph_key = N;
+            }
+            hipError_t e = hipGraphLaunch(h->hw_graph, st);
+            if (e != hipSuccess) { set_error("greedy_search_hotword: hipGraphLaunch failed: %s", hipGetErrorString(e)); return WR_ELAUNCH; }
+        } else {
+            for (int i = 0; i < kStepsPerGraph; ++i) hw_micro_step(h, N, st);
+        }
+        (void)hipMemcpyAsync(h->h_active, s.active_count, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { set_error("greedy_search_hotword: stream error: %s", hipGetErrorString(e)); return WR_ELAUNCH; }
+        if (h->h_active[0] <= 0) break;
+    }
+    WR_CHECK_LAUNCH("greedy_search_hotword");
     scope.ok();
     return WR_OK;
 }

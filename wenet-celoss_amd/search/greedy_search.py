@@ -3,9 +3,12 @@
 for any number of independent streams at once, with the whole loop on the
 device (`wr_greedy_search`).
 
-The fork's hot-word variants (greedy_search.py:34-430: context gating and
-"go-back" re-decoding around ContextBias) are not accelerated in this round
-(SURVEY.md section 8f, item 3); with no hot words they reduce to this loop."""
+The fork's hot-word variants (greedy_search.py:34-430: context gating and "go-back"
+re-decoding around ContextBias) follow below: the default one (`basic_greedy_search_both`,
+loss_mode 'both') runs its whole loop on the device when the hot-word module has the
+reference ContextBias structure (wenet_celoss_amd/hotword.py); other modules and the
+'pred' variant keep a host-driven loop over the HIP step kernels.  With no hot words all
+of them reduce to the core loop."""
 from __future__ import annotations
 
 from typing import List
@@ -142,7 +145,17 @@ def basic_greedy_search_both(model, encoder_out, encoder_out_lens, context_list=
                              context_lengths=torch.IntTensor([0]), n_steps: int = 64,
                              context_filter_state: str = "off",
                              context_decoder_labels_padded=torch.IntTensor([0])):
-    """greedy_search.py:297-430 -> ([hyps], dist)"""
+    """greedy_search.py:297-430 -> ([hyps], dist).  With a hot-word module of the reference's structure the loop runs
+    on the device (hotword.py: gate table, fused predictor biasing, gate / go-back state machine in the update kernel,
+    hipGraph replay); WR_HOTWORD_HOST=1 forces the host-driven loop."""
+    import os
+    from ..hotword import device_capable, greedy_search_both_device
+    if device_capable(model.context_bias) and os.environ.get("WR_HOTWORD_HOST", "0") != "1":
+        hyps, traces = greedy_search_both_device(model, encoder_out, encoder_out_lens, context_list, context_lengths,
+                                                 n_steps=n_steps, filter_on=context_filter_state == "on")
+        lab = context_decoder_labels_padded
+        lab = lab.squeeze(0) if torch.is_tensor(lab) else lab
+        return [hyps[0]], edit_distance(lab.tolist() if torch.is_tensor(lab) else lab, traces[0])
     with torch.no_grad():
         h, dist, _ = _hotword_greedy(model, encoder_out, encoder_out_lens, context_list, context_lengths, n_steps,
                                      context_filter_state == "on", context_decoder_labels_padded, both=True)
