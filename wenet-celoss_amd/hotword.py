@@ -162,5 +162,7 @@ def greedy_search_both_device(model, encoder_out: torch.Tensor, encoder_out_lens
             pass
     hh = hidden.reshape(-1, hidden.shape[-1])
     hc = hidden_empty.reshape(-1, hidden_empty.shape[-1])
-    dec = cache.get_hw(model.predictor, model.joint, cb, lanes=N, tmax=T, max_hyp=T * n_steps, n_ctx=max(hh.shape[0], hc.shape[0]))
+    # a go-back lowers the per-frame emission counter by one (greedy_search.py:378), so a frame can carry more than n_steps
+    # tokens: room for one extra token per frame and rewind
+    dec = cache.get_hw(model.predictor, model.joint, cb, lanes=N, tmax=T, max_hyp=T * (n_steps + 2), n_ctx=max(hh.shape[0], hc.shape[0]))
     return dec.greedy_hotword(enc_hot, enc_cold, enc_feat, lens, hh, hc, n_steps=n_steps, blank=model.blank, filter_on=filter_on)
