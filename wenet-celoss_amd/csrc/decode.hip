@@ -861,15 +861,29 @@ __global__ __launch_bounds__(kHwThreads) void hw_bias_kernel(DevState *sp, HwDev
     for (int j = tid; j < D; j += kHwThreads) x[j] = S.outT[(size_t)j * d.NLp + n];
     __syncthreads();
     block_gemv_kmajor(hw.q_wt, D, hw.q_b, x, D, D, part, q);         // linear_q
-    // scores[h][c] = q_h . k_{c,h} / sqrt(d_k)   (attention.py:185)
+    // scores[h][c] = q_h . k_{c,h} / sqrt(d_k)   (attention.py:185): four threads per (head, entry) pair, each a
+    // quarter of the head's d_k elements with its loads in flight together, summed across the quad by DPP
     const int dk = D / hw.heads;
     const float sq = sqrtf((float)dk);
-    for (int idx = tid; idx < hw.heads * nctx; idx += kHwThreads) {
-        const int hh = idx / nctx, c = idx - hh * nctx;
-        const float *__restrict__ kr = Kb + (size_t)c * D + hh * dk;
-        float acc = 0.f;
-        for (int e = 0; e < dk; ++e) acc = fmaf(q[hh * dk + e], kr[e], acc);
-        p[idx] = acc / sq;
+    {
+        const int quarter = (dk + 3) / 4, sub = tid & 3;
+        for (int pr0 = 0; pr0 < hw.heads * nctx; pr0 += kHwThreads / 4) {
+            const int idx = pr0 + (tid >> 2);
+            const bool on = idx < hw.heads * nctx;
+            const int hh = on ? idx / nctx : 0, c = on ? idx - hh * nctx : 0;
+            const float *__restrict__ kr = Kb + (size_t)c * D + hh * dk;
+            const float *qh = q + hh * dk;
+            float acc = 0.f;
+#pragma unroll 16
+            for (int i = 0; i < quarter; ++i) {
+                const int e = sub * quarter + i;
+                const float kv = kr[e < dk ? e : dk - 1];
+                acc = fmaf(e < dk ? qh[e] : 0.f, kv, acc);
+            }
+            acc += __shfl_xor(acc, 1, kWave);
+            acc += __shfl_xor(acc, 2, kWave);
+            if (on && sub == 0) p[idx] = acc / sq;
+        }
     }
     __syncthreads();
     {   // softmax over the list, one wave per head (torch.softmax: exp(x - max) / sum)
@@ -885,11 +899,20 @@ __global__ __launch_bounds__(kHwThreads) void hw_bias_kernel(DevState *sp, HwDev
         }
     }
     __syncthreads();
-    for (int j = tid; j < D; j += kHwThreads) {                      // context = attn @ v
-        const int hh = j / dk;
-        float acc = 0.f;
-        for (int c = 0; c < nctx; ++c) acc = fmaf(p[hh * nctx + c], Vb[(size_t)c * D + j], acc);
-        ctx[j] = acc;
+    {   // context = attn @ v: the list split four ways over the thread block, partial sums through LDS
+        constexpr int SPL = 4;
+        const int per = kHwThreads / SPL;                            // 256 columns per pass
+        const int sgrp = tid / per, jj = tid - sgrp * per;
+        for (int j0 = 0; j0 < D; j0 += per) {
+            const int j = j0 + jj;
+            const int jc = j < D ? j : D - 1, hh = jc / dk;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int c = sgrp; c < nctx; c += SPL) acc = fmaf(p[hh * nctx + c], Vb[(size_t)c * D + jc], acc);
+            if (j < D) part[sgrp * D + j] = acc;
+        }
+        __syncthreads();
+        for (int j = tid; j < D; j += kHwThreads) ctx[j] = (part[j] + part[D + j]) + (part[2 * D + j] + part[3 * D + j]);
     }
     __syncthreads();
     block_gemv_kmajor(hw.o_wt, D, hw.o_b, ctx, D, D, part, o);       // linear_out
