@@ -37,6 +37,20 @@ from .search.greedy_search import basic_greedy_search, basic_greedy_search_both,
 from .search.prefix_beam_search import PrefixBeamSearch
 
 
+def check_limits(text: torch.Tensor, text_lengths: torch.Tensor, with_ctc: bool) -> None:
+    """Shape limits of the loss kernels (INTEGRATION.md "Shape limits"), checked on the padded label width before
+    anything is launched, with a message that names the longest utterance.  No device sync unless a limit is hit."""
+    width = int(text.shape[1])
+    limit = 255 if with_ctc else 511
+    if width <= limit:
+        return
+    i = int(text_lengths.argmax())
+    what = ("the CTC loss kernels take label sequences padded to at most 255" if with_ctc else
+            "the RNN-T loss kernels take at most 511 labels (U + 1 <= 512 lattice columns)")
+    raise RuntimeError(f"wenet_celoss_amd.Transducer: the label batch is padded to {width} (longest: utterance {i} with "
+                       f"{int(text_lengths[i])} labels); {what} -- lower filter_conf.token_max_length")
+
+
 class Transducer(nn.Module):
     """Transducer-ctc-attention hybrid Encoder-Predictor-Decoder model (transducer.py:20)."""
 
@@ -117,6 +131,7 @@ class Transducer(nn.Module):
         assert text_lengths.dim() == 1, text_lengths.shape
         assert (speech.shape[0] == speech_lengths.shape[0] == text.shape[0] == text_lengths.shape[0]), \
             (speech.shape, speech_lengths.shape, text.shape, text_lengths.shape)
+        check_limits(text, text_lengths, with_ctc=self.ctc_weight != 0.0 and self.ctc is not None)
         cb = self.context_bias
         bias_hidden = cb.forward_bias_hidden(context_list, context_lengths) if cb is not None else None
 
