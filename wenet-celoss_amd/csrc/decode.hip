@@ -89,6 +89,8 @@ struct DevState {
     float *ht;                    // [Jp][kMaxLook * NLp]  joiner activation, column f * NLp + n
     float *logits;                // [kMaxLook * NLp, V]   row f * NLp + n: lane n, frame t_n + f
     int32_t *row_tok;             // [kMaxLook * NLp]      argmax of each logits row (look-ahead greedy)
+    float4 *row_part;             // [NLp][Vp / 32]        per-block row statistics written by the ffn_out epilogue
+    int n_cb;                     // Vp / 32
     int32_t *active_count;        // lanes still decoding
     // greedy outputs / params
     int32_t *hyps;                // [NL, max_hyp]
@@ -134,11 +136,13 @@ struct GemmArgs {
     const float *ep_all;          // [n_utt, T, J]
     int H, J;
     int look, lane_stride;        // joiner activation: frames per lane and the column stride between frames (NLp)
+    float4 *row_part;             // kEpiRowStats: per (row, 32-column block) {max, sum exp(x - max), runner-up, first index of max}
+    int row_part_ld;              // blocks per row
     const int32_t *ep_gate;       // hot-word mode: per-lane selector of the encoder stream (ep_all + gate * ep_gate_stride)
     size_t ep_gate_stride;
 };
 
-enum GemmEpilogue { kEpiKMajor = 0, kEpiRowMajor = 1, kEpiLstmCell = 2, kEpiJointAct = 3 };
+enum GemmEpilogue { kEpiKMajor = 0, kEpiRowMajor = 1, kEpiLstmCell = 2, kEpiJointAct = 3, kEpiRowStats = 4 };
 
 // ----------------------------------------------------------------- setup --
 // src [R][C] row-major -> dst [C][Rp] (zero padded columns R..Rp-1 and rows C..Cp-1)
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(64 * kGemmWaves) void lane_gemm_kernel(GemmArgs g)
     float cell_c = 0.f;
     bool act_on[kItems];
     float act_ep[kMaxLook][kItems];
-    if (EPI == kEpiRowMajor) {
+    if (EPI == kEpiRowMajor || EPI == kEpiRowStats) {
         const int v = n0 + l31;                                          // the column of every item of this thread
         bias_v[0] = g.bias ? g.bias[v < g.N ? v : g.N - 1] : 0.f;
     } else if (EPI == kEpiKMajor || EPI == kEpiJointAct) {
@@ -359,6 +363,30 @@ __global__ __launch_bounds__(64 * kGemmWaves) void lane_gemm_kernel(GemmArgs g)
             const int m = i >> 10, ln = (i & 1023) >> 5, col = i & 31;
             const int n = lane0 + m * 32 + ln, v = n0 + col;
             if (n < g.n_lanes && v < g.N) g.C[(size_t)n * g.ldc + v] = total(m, ln, col) + bias_v[0];
+        }
+    } else if (EPI == kEpiRowStats) {
+        // the logits leave as above, and with them the statistics of this workgroup's 32 columns of every row: the
+        // update kernel then resolves log-softmax and argmax of a row from V / 32 records instead of V logits.  The 32
+        // columns of a row sit in the 32 lanes of a half-wave: butterflies inside the half.
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            const int i = tid + it * NT;
+            const int m = i >> 10, ln = (i & 1023) >> 5, col = i & 31;
+            const int n = lane0 + m * 32 + ln, v = n0 + col;
+            const bool in = v < g.N;
+            const float x = total(m, ln, col) + bias_v[0];
+            if (n < g.n_lanes && in) g.C[(size_t)n * g.ldc + v] = x;
+            const float xs = in ? x : -3.0e38f;
+            auto fmx = [](float a, float b) { return fmaxf(a, b); };
+            const float mx = half_allreduce_f(xs, fmx);
+            // first column holding the maximum
+            const int first = half_allreduce_i((xs == mx) ? col : 32, [](int a, int b) { return a < b ? a : b; });
+            const float second = half_allreduce_f((col == first) ? -3.0e38f : xs, fmx);     // the largest of the others
+            // the sum: every lane ends with the same value only if the additions pair up identically in both halves of
+            // each butterfly -- they do (a + b == b + a), so the record does not depend on the lane that stores it
+            const float se = half_allreduce_f(in ? expf(x - mx) : 0.f, [](float a, float b) { return a + b; });
+            if (col == 0 && n < g.n_lanes)
+                g.row_part[(size_t)n * g.row_part_ld + blockIdx.x] = make_float4(mx, se, second, __builtin_bit_cast(float, n0 + first));
         }
     } else if (EPI == kEpiKMajor) {
 #pragma unroll
@@ -453,16 +481,15 @@ __global__ void greedy_chunk_init_kernel(DevState *s, int ref_new_cache)
     }
 }
 
-// NV = logits held per thread (V <= 256 * NV): the row is read once, all loads in flight together.  The lane's
-// scalars are fetched up front and the state machine runs redundantly in every thread (thread 0 stores), so the
-// kernel has one memory round trip before the reductions and one after.
+// The lane's scalars and its row records are fetched up front and the state machine runs redundantly in every thread
+// (thread 0 stores), so the kernel has one memory round trip before the reductions and one after.
 // HW = true: the hot-word variant (greedy_search.py:297-430).  The gate decision of the NEXT predictor step is made
 // here, right after the emission that causes that step -- the gate is a function of the frame alone (see
 // hw_gate_table_kernel), so it does not have to wait for the predictor.  A "go-back" (:369-385) withdraws exactly
 // the emission this kernel has just decided on (the reference pops the last token, predictor output, cache and
 // input and steps the predictor again from the popped state), so it costs nothing to undo: the token is not
 // appended, the cache not committed, the next input not replaced.
-template <int NV, bool HW>
+template <bool HW>
 __global__ __launch_bounds__(256) void greedy_update_kernel(DevState *sp)
 {
     __shared__ float sv[4];
@@ -487,31 +514,50 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(DevState *sp)
         gate_t1 = S.gate_tab[(size_t)n * S.T + tn];
         last_gate = S.trace[(size_t)n * S.trace_cap + (tlen > 0 ? (tlen <= S.trace_cap ? tlen - 1 : S.trace_cap - 1) : 0)];
     }
-    const float *__restrict__ x = S.logits + (size_t)n * d.V;
-    // log_softmax as the reference evaluates it: (x - max) - log(sum(exp(x - max)))
-    float xv[NV];
+    // The row is resolved from the per-block records the ffn_out epilogue left (kEpiRowStats): {block max, sum of
+    // exp(x - block max), runner-up, first index of the block max} for every 32 columns -- V / 32 records instead of V
+    // logits.  log_softmax as the reference evaluates it, lp = (x - max) - log(sum(exp(x - max))), and its argmax with
+    // the first index on ties: lp is a monotone function of x, so the maximum of lp is (max - max) - ls and the
+    // winner is the first column whose lp equals it.  A block takes part if its maximum does; if its runner-up does too
+    // (two logits that lp cannot tell apart: they differ by less than half an ulp of ls), its 32 logits are re-read and
+    // scanned in order -- otherwise the recorded first index is the answer.
+    constexpr int PP = 2;                            // records per thread: V <= 16384 -> at most 512 blocks
+    const float4 *__restrict__ rp = S.row_part + (size_t)n * S.n_cb;
+    const int ncb = (d.V + 31) / 32;
+    float4 rec[PP];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int v = tid + i * 256;
-        xv[i] = x[v < d.V ? v : d.V - 1];
+    for (int i = 0; i < PP; ++i) {
+        const int bq = tid + i * 256;
+        rec[i] = rp[bq < ncb ? bq : ncb - 1];
     }
     float m = -3.0e38f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) m = fmaxf(m, (tid + i * 256 < d.V) ? xv[i] : -3.0e38f);
+    for (int i = 0; i < PP; ++i) m = fmaxf(m, (tid + i * 256 < ncb) ? rec[i].x : -3.0e38f);
     m = block_max(m, sv);
     if (!act) return;
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) sum += (tid + i * 256 < d.V) ? expf(xv[i] - m) : 0.f;
+    for (int i = 0; i < PP; ++i) sum += (tid + i * 256 < ncb) ? rec[i].y * expf(rec[i].x - m) : 0.f;
     sum = block_sum(sum, sv);
     const float ls = logf(sum);
-    float best = -3.0e38f;
+    const float top = (m - m) - ls;                 // log-probability of the maximum, exactly as the elementwise formula gives it
+    float best = 0.f;
     int bi = 0x7fffffff;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int v = tid + i * 256;
-        const float lp = (xv[i] - m) - ls;
-        if (v < d.V && lp > best) { best = lp; bi = v; }   // strided ascending scan keeps the lowest index per thread
+    for (int i = 0; i < PP; ++i) {
+        const int bq = tid + i * 256;
+        if (bq >= ncb) continue;
+        if (((rec[i].x - m) - ls) != top) continue;
+        int idx = __builtin_bit_cast(int, rec[i].w);
+        if (((rec[i].z - m) - ls) == top) {          // runner-up indistinguishable from the block maximum: scan the block
+            const float *__restrict__ x = S.logits + (size_t)n * d.V;
+            idx = 0x7fffffff;
+            for (int c = 31; c >= 0; --c) {
+                const int v = bq * 32 + c;
+                if (v < d.V && ((x[v] - m) - ls) == top) idx = v;
+            }
+        }
+        if (idx < bi) { best = 1.f; bi = idx; }
     }
     block_argmax(best, bi, sv, si);
     const int k = bi;
@@ -1406,6 +1452,8 @@ size_t carve(const wr_transducer_weights *w, int max_lanes, int max_utt, int Tma
     s.new_is_cache = c.take<int32_t>(d.NLp);
     s.logits = c.take<float>((size_t)kMaxLook * d.NLp * d.V);
     s.row_tok = c.take<int32_t>((size_t)kMaxLook * d.NLp);
+    s.n_cb = d.Vp / 32;
+    s.row_part = c.take<float4>((size_t)d.NLp * s.n_cb);
     s.active_count = c.take<int32_t>(64);
     s.topv = c.take<float>((size_t)d.NL * kMaxBeam); s.topi = c.take<int32_t>((size_t)d.NL * kMaxBeam);
     s.n_hyps = c.take<int32_t>(max_utt); s.frame = c.take<int32_t>(max_utt);
@@ -1482,7 +1530,7 @@ void launch_predictor(wr_decoder *h, int n_lanes, hipStream_t st)
     launch_gemm<kEpiKMajor>(g, up(d.P, 32), n_lanes, st);
 }
 
-void launch_predictor_and_joint(wr_decoder *h, int n_lanes, hipStream_t st, int look = 1)
+void launch_predictor_and_joint(wr_decoder *h, int n_lanes, hipStream_t st, int look = 1, bool row_stats = false)
 {
     const Dims &d = h->d;
     const DevState &s = h->host;
@@ -1501,7 +1549,12 @@ void launch_predictor_and_joint(wr_decoder *h, int n_lanes, hipStream_t st, int 
     const int rows = (look - 1) * d.NLp + n_lanes;
     g.A0 = s.ht; g.B0 = s.out_wt; g.K0 = d.Jp;
     g.lda = kMaxLook * d.NLp; g.ldb = d.Vp; g.bias = s.out_b; g.C = s.logits; g.ldc = d.V; g.N = d.V; g.n_lanes = rows;
-    launch_gemm<kEpiRowMajor>(g, d.Vp, rows, st);
+    if (row_stats) {                               // greedy, one frame per micro-step: the update kernel reads the records
+        g.row_part = s.row_part; g.row_part_ld = s.n_cb;
+        launch_gemm<kEpiRowStats>(g, d.Vp, rows, st);
+    } else {
+        launch_gemm<kEpiRowMajor>(g, d.Vp, rows, st);
+    }
 }
 
 }  // namespace
@@ -1637,12 +1690,10 @@ int upload_state(wr_decoder *h, hipStream_t st)
 
 void greedy_micro_step(wr_decoder *h, int n_lanes, hipStream_t st, int look)
 {
-    launch_predictor_and_joint(h, n_lanes, st, look);
+    launch_predictor_and_joint(h, n_lanes, st, look, look == 1);
     const int V = h->d.V;                           // <= 16384 (check_weights)
     if (look == 1) {
-        if (V <= 256 * 8) hipLaunchKernelGGL((greedy_update_kernel<8, false>), dim3(n_lanes), dim3(256), 0, st, h->dev);
-        else if (V <= 256 * 24) hipLaunchKernelGGL((greedy_update_kernel<24, false>), dim3(n_lanes), dim3(256), 0, st, h->dev);
-        else hipLaunchKernelGGL((greedy_update_kernel<64, false>), dim3(n_lanes), dim3(256), 0, st, h->dev);
+        hipLaunchKernelGGL((greedy_update_kernel<false>), dim3(n_lanes), dim3(256), 0, st, h->dev);
         return;
     }
     const dim3 grid(n_lanes, look);
@@ -1969,11 +2020,9 @@ void hw_micro_step(wr_decoder *h, int n_lanes, hipStream_t st)
     GemmArgs g{};
     g.A0 = s.ht; g.B0 = s.out_wt; g.K0 = d.Jp;
     g.lda = kMaxLook * d.NLp; g.ldb = d.Vp; g.bias = s.out_b; g.C = s.logits; g.ldc = d.V; g.N = d.V; g.n_lanes = n_lanes;
-    launch_gemm<kEpiRowMajor>(g, d.Vp, n_lanes, st);
-    const int V = d.V;
-    if (V <= 256 * 8) hipLaunchKernelGGL((greedy_update_kernel<8, true>), dim3(n_lanes), dim3(256), 0, st, h->dev);
-    else if (V <= 256 * 24) hipLaunchKernelGGL((greedy_update_kernel<24, true>), dim3(n_lanes), dim3(256), 0, st, h->dev);
-    else hipLaunchKernelGGL((greedy_update_kernel<64, true>), dim3(n_lanes), dim3(256), 0, st, h->dev);
+    g.row_part = s.row_part; g.row_part_ld = s.n_cb;
+    launch_gemm<kEpiRowStats>(g, d.Vp, n_lanes, st);
+    hipLaunchKernelGGL((greedy_update_kernel<true>), dim3(n_lanes), dim3(256), 0, st, h->dev);
 }
 
 }  // namespace

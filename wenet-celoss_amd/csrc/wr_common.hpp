@@ -158,6 +158,31 @@ __device__ __forceinline__ int wave_allmin_dpp(int v)
     const int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
     return min(min(r0, r1), min(r2, r3));
 }
+// All-reduce over each aligned group of 32 lanes (a half-wave): four DPP butterflies inside the rows of 16 and one
+// cross-row exchange (lane ^ 16).  OP is applied to (value, partner value).
+template <typename OP>
+__device__ __forceinline__ float half_allreduce_f(float v, OP op)
+{
+#define WR_DPP_F(x, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, false))
+    v = op(v, WR_DPP_F(v, 0xB1));                  // quad_perm:[1,0,3,2]
+    v = op(v, WR_DPP_F(v, 0x4E));                  // quad_perm:[2,3,0,1]
+    v = op(v, WR_DPP_F(v, 0x141));                 // row_half_mirror
+    v = op(v, WR_DPP_F(v, 0x140));                 // row_mirror
+#undef WR_DPP_F
+    return op(v, __shfl_xor(v, 16, kWave));
+}
+template <typename OP>
+__device__ __forceinline__ int half_allreduce_i(int v, OP op)
+{
+#define WR_DPP_I(x, ctrl) __builtin_amdgcn_update_dpp(0, x, ctrl, 0xf, 0xf, false)
+    v = op(v, WR_DPP_I(v, 0xB1));
+    v = op(v, WR_DPP_I(v, 0x4E));
+    v = op(v, WR_DPP_I(v, 0x141));
+    v = op(v, WR_DPP_I(v, 0x140));
+#undef WR_DPP_I
+    return op(v, __shfl_xor(v, 16, kWave));
+}
+
 // wave-wide argmax with "first index on ties"; result in every lane
 __device__ __forceinline__ void wave_argmax_dpp(float &val, int &idx)
 {
