@@ -554,3 +554,32 @@ def test_ctc_loss_takes_half_precision_logits_outside_autocast():
         loss.backward()
         assert xh.grad.dtype == dt and torch.isfinite(xh.grad).all()
         assert loss.item() == pytest.approx(ref.item(), rel=2e-2)
+
+
+def test_greedy_without_prejoin_linear_matches_oracle():
+    """prejoin_linear=False (joint.py:30-31: encoder, predictor and join widths equal): the step kernels run with
+    identity pre-join weights, which is exact in fp32; tokens equal the oracle's with the same identities."""
+    import wenet_celoss_amd as w
+    d = np.load(names("greedy_core_0.npz")[0])
+    pw, jw = sub(d, "pred_"), sub(d, "joint_")
+    V, D = pw["embed.weight"].shape
+    H, L = pw["rnn.weight_hh_l0"].shape[1], int(d["n_layers"])
+    P = pw["projection.weight"].shape[0]
+    pred = w.RNNPredictor(V, D, P, 0.1, H, L).to(DEV).eval()
+    pred.load_state_dict({k: torch.tensor(v) for k, v in pw.items()})
+    joint = w.TransducerJoint(V, P, P, P, prejoin_linear=False).to(DEV).eval()
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        joint.ffn_out.weight.copy_((torch.randint(-16, 17, joint.ffn_out.weight.shape, generator=g).float() / 8).to(DEV))
+        joint.ffn_out.bias.zero_()
+        joint.ffn_out.bias[0] += 3.0
+    model = types.SimpleNamespace(blank=0, predictor=pred, joint=joint)
+    T = int(d["T"])
+    enc = torch.tensor(d["enc"][:, :, :P], device=DEV).contiguous()
+    hyps = w.basic_greedy_search(model, enc, torch.tensor(T), n_steps=4)
+    jd = {"enc_ffn.weight": np.eye(P, dtype=np.float32), "enc_ffn.bias": np.zeros(P, np.float32),
+          "pred_ffn.weight": np.eye(P, dtype=np.float32), "pred_ffn.bias": np.zeros(P, np.float32),
+          "ffn_out.weight": joint.ffn_out.weight.detach().cpu().numpy(), "ffn_out.bias": joint.ffn_out.bias.detach().cpu().numpy()}
+    ref, margin = do.greedy_search(do.Predictor(pw, L), do.Joint(jd), enc[0].cpu().numpy(), T, n_steps=4, return_margin=True)
+    assert margin > 1e-4 and len(ref) > 3
+    assert hyps == [ref]

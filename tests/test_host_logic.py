@@ -201,6 +201,24 @@ def test_label_width_limits_are_reported_before_launch():
         check_limits(torch.zeros(2, 600, dtype=torch.long), torch.tensor([600, 3]), with_ctc=False)
 
 
+def test_joiner_and_predictor_variants_accepted_or_refused_loudly():
+    import wenet_celoss_amd as w
+    from wenet_celoss_amd.decoder import DeviceDecoder
+    j = w.TransducerJoint(10, 8, 8, 8, prejoin_linear=False)
+    assert j.enc_ffn is None and j.pred_ffn is None and j.post_ffn is None
+    j2 = w.TransducerJoint(10, 8, 8, 8, postjoin_linear=True)
+    assert set(dict(j2.named_parameters())) >= {"post_ffn.weight", "post_ffn.bias", "enc_ffn.weight", "ffn_out.weight"}
+    with pytest.raises(AssertionError):
+        w.TransducerJoint(10, 8, 6, 8, prejoin_linear=False)          # joint.py:30-31: widths must agree
+    with pytest.raises(NotImplementedError, match="tanh"):
+        w.TransducerJoint(10, 8, 8, 8, activation="relu")
+    p = w.RNNPredictor(10, 8, 8, 0.1, 8, 1)
+    with pytest.raises(NotImplementedError, match="postjoin_linear"):
+        DeviceDecoder(p, j2, 1, 1, 4)
+    e, pp = j2.pre_activation(torch.randn(2, 3, 8), torch.randn(2, 4, 8))
+    assert e.shape == (2, 3, 8) and pp.shape == (2, 4, 8)
+
+
 def test_transducer_constructor_contract():
     """Same keyword surface and weight-sum assertion as the reference (transducer.py:23-46)."""
     import wenet_celoss_amd as w

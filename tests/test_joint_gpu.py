@@ -361,3 +361,35 @@ def test_exact_dz_block_tiling_matches_cell_tiling(B, T, U1, J, V):
             assert float((res[0][0] - res[1][0]).abs().max()) <= 1e-5 * rms
     finally:
         lib.wr_tune_set(10, 0)
+
+
+@pytest.mark.parametrize("prejoin,postjoin", [(False, False), (True, True), (False, True)])
+def test_joiner_variants_match_the_reference_formula(prejoin, postjoin):
+    """joint.py:45-70 with prejoin_linear off and / or postjoin_linear on, evaluated literally in float64 (the
+    post-join Linear applied to the 4-D sum), against the module (which distributes that Linear over the two addends
+    and never forms the 4-D tensor): logits and every gradient."""
+    import wenet_celoss_amd as w
+    torch.manual_seed(5)
+    B, T, U1, D, V = 2, 9, 4, 24, 37
+    m = w.TransducerJoint(V, D, D, D, prejoin_linear=prejoin, postjoin_linear=postjoin).to(DEV)
+    enc = torch.randn(B, T, D, device=DEV, requires_grad=True)
+    pred = torch.randn(B, U1, D, device=DEV, requires_grad=True)
+    out = m(enc, pred)
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    prm = {k: v.detach().double().cpu().requires_grad_(True) for k, v in m.state_dict().items()}
+    e, p = enc.detach().double().cpu().requires_grad_(True), pred.detach().double().cpu().requires_grad_(True)
+    e2, p2 = e, p
+    if prejoin:
+        e2 = e @ prm["enc_ffn.weight"].T + prm["enc_ffn.bias"]
+        p2 = p @ prm["pred_ffn.weight"].T + prm["pred_ffn.bias"]
+    x = e2[:, :, None] + p2[:, None]
+    if postjoin:
+        x = x @ prm["post_ffn.weight"].T + prm["post_ffn.bias"]
+    ref = torch.tanh(x) @ prm["ffn_out.weight"].T + prm["ffn_out.bias"]
+    ref.backward(gout.double().cpu())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-5)
+    for name, got, want in [("enc", enc.grad, e.grad), ("pred", pred.grad, p.grad)] + \
+            [(k, dict(m.named_parameters())[k].grad, prm[k].grad) for k in prm]:
+        scale = float(want.abs().max())
+        assert float((got.double().cpu() - want).abs().max()) <= 1e-4 * scale + 1e-9, name

@@ -767,6 +767,7 @@ struct HwDev {
     const float *on_w, *on_b;         // predictor_bias_out_norm
     const float *he_w, *he_b, *hv_w, *hv_b, *ho_w, *ho_b, *hn_w, *hn_b, *hl_w, *hl_b;   // gate chain, row-major
     float *kbuf[2], *vbuf[2];         // [max_ctx][D]: K / V of the empty list (0) and of the hot-word list (1)
+    float *cold_c;                    // [D] one-entry empty list: combine(second half) of its constant bias feature + bias
     int32_t *gate_tab;                // [max_utt * Tmax]
 };
 
@@ -906,6 +907,14 @@ __global__ __launch_bounds__(kHwThreads) void hw_bias_kernel(DevState *sp, HwDev
     float *part = sm + 5 * D, *p = part + (kHwThreads / 64) * D;
     for (int j = tid; j < D; j += kHwThreads) x[j] = S.outT[(size_t)j * d.NLp + n];
     __syncthreads();
+    if (g == 0 && nctx == 1) {
+        // The empty list has ONE entry: softmax over one score is exactly 1, the context is exactly that entry's value
+        // row, so the bias feature -- and the second half of the combine Linear applied to it -- is the same vector
+        // for every step of the call (hw_cold_kernel computed it once).  Only the first half depends on the predictor.
+        block_gemv_kmajor(hw.c_wt, D, hw.cold_c, x, D, D, part, ctx);
+        block_layer_norm(ctx, D, hw.on_w, hw.on_b, sv, [&](int j, float v) { S.biasT[(size_t)j * d.NLp + n] = v; });
+        return;
+    }
     block_gemv_kmajor(hw.q_wt, D, hw.q_b, x, D, D, part, q);         // linear_q
     // scores[h][c] = q_h . k_{c,h} / sqrt(d_k)   (attention.py:185): four threads per (head, entry) pair, each a
     // quarter of the head's d_k elements with its loads in flight together, summed across the quad by DPP
@@ -967,6 +976,23 @@ __global__ __launch_bounds__(kHwThreads) void hw_bias_kernel(DevState *sp, HwDev
     block_gemv_kmajor(hw.c_wt, D, hw.c_b, x, D, D, part, q);
     block_gemv_kmajor(hw.c_wt + (size_t)D * D, D, q, pb, D, D, part, ctx);   // "bias" = the first segment's sums
     block_layer_norm(ctx, D, hw.on_w, hw.on_b, sv, [&](int j, float v) { S.biasT[(size_t)j * d.NLp + n] = v; });
+}
+
+// One-entry empty list (the reference's `context_list_empty`, greedy_search.py:328-333): its attention output does not
+// depend on the query, so   cold_c = predictor_bias_combine[:, D:] . predictor_bias_bias_norm(linear_out(v_0)) + bias
+// is computed once per call.
+__global__ __launch_bounds__(kHwThreads) void hw_cold_kernel(HwDev hw)
+{
+    extern __shared__ float sm[];                   // v[D] o[D] pb[D] | part[16][D]
+    __shared__ float sv[kHwThreads / 64];
+    const int D = hw.D, tid = threadIdx.x;
+    float *v = sm, *o = sm + D, *pb = sm + 2 * D, *part = sm + 3 * D;
+    for (int j = tid; j < D; j += kHwThreads) v[j] = hw.vbuf[0][j];
+    __syncthreads();
+    block_gemv_kmajor(hw.o_wt, D, hw.o_b, v, D, D, part, o);
+    block_layer_norm(o, D, hw.bn_w, hw.bn_b, sv, [&](int j, float val) { pb[j] = val; });
+    block_gemv_kmajor(hw.c_wt + (size_t)D * D, D, hw.c_b, pb, D, D, part, o);
+    for (int j = tid; j < D; j += kHwThreads) hw.cold_c[j] = o[j];
 }
 
 __global__ void greedy_hw_init_kernel(DevState *s)
@@ -1960,7 +1986,7 @@ extern "C" int wr_predictor_step(wr_decoder *h, const int32_t *tokens_d, const f
 namespace {
 
 struct HwCarve {
-    size_t q_wt, o_wt, c_wt, kbuf[2], vbuf[2], gate_tab, ep2, state, biasT, total;
+    size_t q_wt, o_wt, c_wt, kbuf[2], vbuf[2], cold_c, gate_tab, ep2, state, biasT, total;
 };
 
 HwCarve hw_carve(const wr_decoder *h, int D, int max_ctx)
@@ -1973,6 +1999,7 @@ HwCarve hw_carve(const wr_decoder *h, int D, int max_ctx)
     c.o_wt = take((size_t)D * D * sizeof(float));
     c.c_wt = take((size_t)2 * D * D * sizeof(float));
     for (int i = 0; i < 2; ++i) { c.kbuf[i] = take((size_t)max_ctx * D * sizeof(float)); c.vbuf[i] = take((size_t)max_ctx * D * sizeof(float)); }
+    c.cold_c = take((size_t)D * sizeof(float));
     c.gate_tab = take((size_t)h->max_utt * h->Tmax * sizeof(int32_t));
     c.ep2 = take((size_t)2 * h->max_utt * h->Tmax * d.J * sizeof(float));
     c.state = take((size_t)4 * d.NLp * sizeof(int32_t));
@@ -2061,6 +2088,7 @@ extern "C" int wr_decoder_attach_hotword(wr_decoder *h, const wr_hotword_weights
         v.kbuf[i] = reinterpret_cast<float *>(ws + c.kbuf[i]);
         v.vbuf[i] = reinterpret_cast<float *>(ws + c.vbuf[i]);
     }
+    v.cold_c = reinterpret_cast<float *>(ws + c.cold_c);
     v.gate_tab = reinterpret_cast<int32_t *>(ws + c.gate_tab);
     h->hw_ep2 = reinterpret_cast<float *>(ws + c.ep2);
     h->hw_state = reinterpret_cast<int32_t *>(ws + c.state);
@@ -2106,6 +2134,8 @@ extern "C" int wr_greedy_search_hotword(wr_decoder *h, const float *enc_hot_d, c
     // loop-invariant work: list projections, the gate of every frame, enc_ffn of both encoder streams
     hipLaunchKernelGGL(hw_kv_kernel, dim3(n_ctx_cold, 2), dim3(256), 0, st, h->hw, hidden_cold_d, 0);
     hipLaunchKernelGGL(hw_kv_kernel, dim3(n_ctx_hot, 2), dim3(256), 0, st, h->hw, hidden_hot_d, 1);
+    if (n_ctx_cold == 1)
+        hipLaunchKernelGGL(hw_cold_kernel, dim3(1), dim3(kHwThreads), (size_t)(3 + kHwThreads / 64) * h->hw.D * sizeof(float), st, h->hw);
     hipLaunchKernelGGL(hw_gate_table_kernel, dim3((unsigned)((long)N * T)), dim3(256),
                        (size_t)(h->hw.D + 2 * h->hw.HW) * sizeof(float), st, h->hw, enc_feat_d, (long)N * T);
     const size_t ep_stride = (size_t)h->max_utt * h->Tmax * d.J;

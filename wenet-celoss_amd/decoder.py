@@ -29,9 +29,20 @@ class DeviceDecoder:
         if not isinstance(rnn, torch.nn.LSTM):
             raise NotImplementedError("wenet_celoss_amd decoding implements the LSTM RNNPredictor "
                                       f"(the shipped configuration); got {type(rnn).__name__}")
-        if joint.enc_ffn is None or joint.pred_ffn is None:
-            raise NotImplementedError("wenet_celoss_amd decoding needs prejoin_linear=True (the shipped configuration)")
+        if getattr(joint, "post_ffn", None) is not None:
+            raise NotImplementedError("wenet_celoss_amd decoding does not take postjoin_linear=True (the step kernels fuse "
+                                      "pred_ffn with the activation; the shipped configuration has no post-join Linear)")
         dev = joint.ffn_out.weight.device
+        if joint.enc_ffn is None or joint.pred_ffn is None:
+            # prejoin_linear=False (joint.py:30-31 then requires enc == pred == join width): the step kernels multiply by
+            # identity weights -- x * 1 + 0 * others is exact in fp32, so the joiner sees enc / pred unchanged
+            J = joint.ffn_out.weight.shape[1]
+            eye, zero = torch.eye(J, device=dev), torch.zeros(J, device=dev)
+            enc_w = pred_w = eye
+            enc_b = pred_b = zero
+        else:
+            enc_w, enc_b = joint.enc_ffn.weight, joint.enc_ffn.bias
+            pred_w, pred_b = joint.pred_ffn.weight, joint.pred_ffn.bias
         if dev.type != "cuda":
             raise RuntimeError("wenet_celoss_amd decoding: modules must live on a HIP device (this package has no CPU path)")
         self.device = dev
@@ -44,7 +55,7 @@ class DeviceDecoder:
 
         w = _lib.TransducerWeights()
         w.vocab_size = joint.ffn_out.weight.shape[0]
-        w.enc_dim = joint.enc_ffn.weight.shape[1]
+        w.enc_dim = enc_w.shape[1]
         w.pred_dim = predictor.projection.weight.shape[0]
         w.embed_dim = predictor.embed.weight.shape[1]
         w.hidden = rnn.hidden_size
@@ -59,8 +70,8 @@ class DeviceDecoder:
             w.b_ih[l] = hold(getattr(rnn, f"bias_ih_l{l}"))
             w.b_hh[l] = hold(getattr(rnn, f"bias_hh_l{l}"))
         w.proj_w, w.proj_b = hold(predictor.projection.weight), hold(predictor.projection.bias)
-        w.enc_ffn_w, w.enc_ffn_b = hold(joint.enc_ffn.weight), hold(joint.enc_ffn.bias)
-        w.pred_ffn_w, w.pred_ffn_b = hold(joint.pred_ffn.weight), hold(joint.pred_ffn.bias)
+        w.enc_ffn_w, w.enc_ffn_b = hold(enc_w), hold(enc_b)
+        w.pred_ffn_w, w.pred_ffn_b = hold(pred_w), hold(pred_b)
         w.out_w, w.out_b = hold(joint.ffn_out.weight), hold(joint.ffn_out.bias)
         self._w = w
         self.dims = dict(V=w.vocab_size, E=w.enc_dim, P=w.pred_dim, D=w.embed_dim, H=w.hidden, L=w.n_layers, J=w.join_dim)

@@ -18,10 +18,10 @@ under autocast the logits come out in the autocast dtype.  In both modes the act
 and the weight gradient ``dW = dY^T H`` use the same split (``wr_joint_bwd_dz_split``, ``wr_joint_bwd_dw_split``,
 when V is a multiple of 4; otherwise the exact kernels); the bias gradient is summed in fp32.
 
-Supported configuration: the reference's shipped one (``joint_mode='add'``,
-``activation='tanh'``, ``postjoin_linear=False``,
-conf/encoder_bias_conformer_rnnt_*.yaml:21-26).  Anything else raises -- there
-is no silent fallback.
+Supported configurations: ``joint_mode='add'`` with ``activation='tanh'`` (the kernels fuse tanh and its
+derivative), ``prejoin_linear`` on (shipped, conf/encoder_bias_conformer_rnnt_*.yaml:21-26) or off,
+``postjoin_linear`` off (shipped) or on (training forward; distributed over the two addends, see
+``pre_activation``).  Other activations raise -- there is no silent fallback.
 """
 from __future__ import annotations
 
@@ -183,10 +183,9 @@ class TransducerJoint(nn.Module):
                  activation: str = "tanh", precision: Optional[str] = None):
         assert joint_mode in ["add"]
         super().__init__()
-        if activation != "tanh" or postjoin_linear:
-            raise NotImplementedError("wenet_celoss_amd.TransducerJoint implements the shipped configuration "
-                                      "(activation='tanh', postjoin_linear=False); got "
-                                      f"activation={activation!r}, postjoin_linear={postjoin_linear}")
+        if activation != "tanh":
+            raise NotImplementedError("wenet_celoss_amd.TransducerJoint implements activation='tanh' (the shipped "
+                                      f"configuration; the kernels fuse tanh and its derivative); got {activation!r}")
         self.precision = precision                 # None: WR_JOINT_PRECISION or exact fp32
         self.prejoin_linear = prejoin_linear
         self.postjoin_linear = postjoin_linear
@@ -199,7 +198,23 @@ class TransducerJoint(nn.Module):
             self.enc_ffn = nn.Linear(enc_output_size, join_dim)
             self.pred_ffn = nn.Linear(pred_output_size, join_dim)
         self.post_ffn: Optional[nn.Linear] = None
+        if self.postjoin_linear:
+            self.post_ffn = nn.Linear(enc_output_size, join_dim)          # joint.py:39-41 (applied to a join_dim tensor)
         self.ffn_out = nn.Linear(join_dim, voca_size)
+
+    def pre_activation(self, enc_out: torch.Tensor, pred_out: torch.Tensor):
+        """The two addends whose broadcast sum enters the activation: (B, T, J), (B, U, J).
+        prejoin_linear (joint.py:55-58): enc_ffn / pred_ffn.  postjoin_linear (:66-67) applies a Linear to the 4-D sum
+        enc[:, :, None] + pred[:, None]; a Linear distributes over the sum, post(e + p) = (W e + b) + W p, so it is
+        applied to the two small addends instead of the (B, T, U, J) tensor (same value up to fp32 rounding of one
+        addition per element; the 4-D tensor is never formed)."""
+        if self.prejoin_linear and self.enc_ffn is not None and self.pred_ffn is not None:
+            enc_out = self.enc_ffn(enc_out)
+            pred_out = self.pred_ffn(pred_out)
+        if self.postjoin_linear and self.post_ffn is not None:
+            enc_out = self.post_ffn(enc_out)
+            pred_out = torch.nn.functional.linear(pred_out, self.post_ffn.weight)
+        return enc_out, pred_out
 
     def _export_forward(self, enc_out: torch.Tensor, pred_out: torch.Tensor) -> torch.Tensor:
         """TorchScript-export body of the joiner for the step export `forward_joint_step` (transducer.py:619-622):
@@ -210,8 +225,10 @@ class TransducerJoint(nn.Module):
         if self.enc_ffn is not None and self.pred_ffn is not None:
             enc = self.enc_ffn(enc_out)
             pred = self.pred_ffn(pred_out)
-        out = torch.tanh(enc.unsqueeze(2) + pred.unsqueeze(1))
-        return self.ffn_out(out)
+        out = enc.unsqueeze(2) + pred.unsqueeze(1)
+        if self.post_ffn is not None:
+            out = self.post_ffn(out)
+        return self.ffn_out(torch.tanh(out))
 
     @torch.jit.unused      # backed by a ctypes autograd Function: opaque to TorchScript (train.py:203-205 smoke export)
     def forward(self, enc_out: torch.Tensor, pred_out: torch.Tensor,
@@ -219,8 +236,6 @@ class TransducerJoint(nn.Module):
                 target_lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
         """enc_out (B, T, E), pred_out (B, U, P) -> (B, T, U, V).  The optional lengths are an
         extension (skip cells the loss never reads); the reference call passes none."""
-        if self.prejoin_linear and self.enc_ffn is not None and self.pred_ffn is not None:
-            enc_out = self.enc_ffn(enc_out)
-            pred_out = self.pred_ffn(pred_out)
+        enc_out, pred_out = self.pre_activation(enc_out, pred_out)
         return joint_logits(enc_out, pred_out, self.ffn_out.weight, self.ffn_out.bias, logit_lengths, target_lengths,
                             self.precision)

@@ -105,7 +105,8 @@ class Transducer(nn.Module):
         encoder_out_lens = encoder_out_lens.to(torch.int32)
         if self._can_fuse_loss():
             jt = self.joint
-            loss = joint_rnnt_loss(jt.enc_ffn(encoder_out), jt.pred_ffn(predictor_out), jt.ffn_out.weight, jt.ffn_out.bias,
+            ep, pp = jt.pre_activation(encoder_out, predictor_out)
+            loss = joint_rnnt_loss(ep, pp, jt.ffn_out.weight, jt.ffn_out.bias,
                                    rnnt_text, encoder_out_lens, rnnt_text_lengths, blank=self.blank, reduction="mean",
                                    precision=jt.precision)
             return None, loss
@@ -119,7 +120,7 @@ class Transducer(nn.Module):
 
     def _can_fuse_loss(self) -> bool:
         jt = self.joint
-        return (self.fused_loss and isinstance(jt, TransducerJoint) and jt.enc_ffn is not None and jt.pred_ffn is not None
+        return (self.fused_loss and isinstance(jt, TransducerJoint)
                 and _resolve_precision(jt.precision) != "bf16")        # the AMP single-term mode keeps 16-bit logits
 
     @torch.jit.unused      # wenet/bin/train.py:203-205 scripts the model as an export smoke test; the HIP-backed forward
