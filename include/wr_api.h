@@ -54,7 +54,7 @@ const char *wr_last_error(void);
  * stores, 4: row-lse loads), key 3 / key 4: 16-byte vectors in flight per lane in the gradient / row-lse pass (4 or 8),
  * key 5: retired (the superseded joiner forward variants were removed), key 6: decoder GEMM lane
  * tile (0: by occupancy, 1: 32 lanes, 2: 64 lanes), key 7: column parts of the split joiner forward (0: automatic),
- * key 8: split dZ tiling (0: 128 cells, 1: 64 cells), key 9 / key 10: exact dW / dZ tiling (0: 256 x 256 blocks,
+ * key 8: retired (the 64-cell split dZ tiling was removed), key 9 / key 10: exact dW / dZ tiling (0: 256 x 256 blocks,
  * 1: the first tilings of joint.hip).  Keys 6-10 pick between kernels that compute the same sums; the two dZ tilings
  * are bit-identical, the dW tilings differ in the order of fp32 additions. */
 int wr_tune_set(int key, int value);

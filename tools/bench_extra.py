@@ -77,16 +77,14 @@ def bench_joint(args):
     wsz = lib.wr_joint_dz_split_workspace_bytes(J, V)
     wz = torch.empty(wsz, dtype=torch.uint8, device=dev)
     dz_ref = dz.clone()
-    for terms, tile in ((3, 0), (3, 1), (1, 0)):
-        lib.wr_tune_set(8, tile)                       # 0: 128-cell tiling (default), 1: 64-cell tiling
+    for terms in (3, 1):
         gs = lambda: _lib.check(lib.wr_joint_bwd_dz_split(P(out), P(ep), P(pp), P(w), None, None, B, T, U1, J, V, terms,
                                                            P(dz), P(h), P(wz), wsz, st))
         ms = timeit(gs, args.steps)
         err = float((dz[:1] - dz_ref[:1]).abs().max())
-        print(json.dumps({"what": "joint_bwd_dz_split", "terms": terms, "tile64": tile, "shape": [B, T, U1, J, V], "ms": round(ms, 3),
+        print(json.dumps({"what": "joint_bwd_dz_split", "terms": terms, "shape": [B, T, U1, J, V], "ms": round(ms, 3),
                           "TFLOPs_fp32_equiv": round(flops / ms / 1e9, 2), "max_abs_err_vs_fp32": err,
                           "dz_rms": float(dz_ref[:1].pow(2).mean().sqrt())}), flush=True)
-    lib.wr_tune_set(8, 0)
     g()
     wsb2 = lib.wr_joint_dw_workspace_bytes(J, V)
     ws2 = torch.empty(wsb2, dtype=torch.uint8, device=dev)

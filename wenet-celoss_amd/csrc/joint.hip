@@ -5,21 +5,24 @@
 //     ep = enc_ffn(enc)  [B, T,  J]      pp = pred_ffn(pred)  [B, U1, J]
 // (those are plain library GEMMs on tiny tensors and stay with rocBLAS).
 //
-// Forward  joint_fwd_kernel      out[m, v] = sum_k tanh(ep[bt(m),k] + pp[bu(m),k]) * W[v,k] + bias[v]
+// Forward  joint_fwd_direct_kernel   out[m, v] = sum_k tanh(ep[bt(m),k] + pp[bu(m),k]) * W[v,k] + bias[v]
 //   M = B*T*U1 lattice cells (4.83 M at the BASELINE shape), K = J = 512, N = V.
-//   One workgroup owns 64 consecutive cells and ALL V columns: the activation tile
+//   One workgroup (8 waves) owns 64 consecutive cells and ALL V columns: the activation tile
 //   H = tanh(ep + pp) (64 x J) is computed ONCE into LDS (k-major, +1 padded) and
 //   never exists in HBM (the reference materialises it: 9.9 GB + its autograd copy);
-//   W^T is streamed from L2 / Infinity Cache in 8-deep k-slices, double buffered.
-//   Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32, bit-identical to an fmaf chain),
-//   4 waves x (64 rows x 64 cols) per 256-column chunk.  MFMA-bound:
-//   2*M*J*V flop = 24.74 TFLOP forward at the BASELINE shape vs 157.3 TFLOP/s.
+//   each wave streams the W^T fragments of its own 32 columns straight from L2 into a register
+//   ping-pong (no LDS, no barrier in the k-loop).  Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32).
+//   MFMA-bound: 2*M*J*V flop = 24.74 TFLOP forward at the BASELINE shape vs 157.3 TFLOP/s.
+//   With LSE = true the epilogue also writes the RNN-T loss's row statistics (joint_lse.hpp).
 //
-// Backward joint_bwd_dz_kernel   dZ[m,k] = (sum_v dY[m,v] * W[v,k]) * (1 - H[m,k]^2)
-//   same tiling transposed: one workgroup owns 64 cells and all J columns, streams
-//   dY (the RNN-T gradient) once in 16-deep v-slices; H is recomputed, optionally
-//   written out for the weight-gradient GEMM.  d ep = sum_u dZ, d pp = sum_t dZ and
-//   dW = dY^T H are left to library reductions/GEMMs on the host side.
+// Backward (general shapes; the shipped shapes take the 256 x 256 block tilings of joint_split.hip:
+//   joint_bwd_dz_block_kernel, joint_bwd_dw_block_kernel)
+//   joint_bwd_dz_kernel   dZ[m,k] = (sum_v dY[m,v] * W[v,k]) * (1 - H[m,k]^2): one workgroup owns 64 cells
+//     and all J columns, streams dY (the RNN-T gradient) once in 16-deep v-slices; H is recomputed,
+//     optionally written out for the weight gradient.  Any V (odd vocabularies, unaligned rows).
+//   joint_bwd_dw_kernel   dW = dY^T H, db = sum dY: 128-row slabs of the vocabulary x all J columns, operands
+//     straight into registers, partial slabs summed by a deterministic second kernel.  Any V.
+//   d ep = sum_u dZ and d pp = sum_t dZ are library reductions on the host side.
 #include "wr_common.hpp"
 #include "joint_lse.hpp"
 

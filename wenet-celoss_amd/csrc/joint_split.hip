@@ -329,12 +329,12 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
 
 // ------------------------------------------------------------- backward, dZ --
 // dZ[m, j] = (sum_v dY[m, v] * W[v, j]) * (1 - H[m, j]^2),  H = tanh(ep + pp) recomputed (exact tanhf).
-// One workgroup (4 waves) owns 64 cells and all J columns: a wave holds 2 row tiles x 4 column tiles of fp32
-// accumulators (128 registers).  The reduction runs over the vocabulary in double steps of 32: lane half h reads
-// 16 consecutive floats dY[row][32 d + 16 h ...] (64 bytes; a row's two halves make one 128-byte line), splits
-// them into bf16 hi / lo in registers and feeds two MFMAs (elements 0-7, then 8-15); W is re-laid once per call
-// into fragments that follow the same k permutation (k = 32 d + 16 h + 8 t + e), hi and lo images, and streamed
-// from L2 / Infinity Cache.  Three rotating register sets (dY + W of one double step each), two in flight.
+// The reduction runs over the vocabulary in double steps of 32: lane half h reads 16 consecutive floats
+// dY[row][32 d + 16 h ...] (64 bytes; a row's two halves make one 128-byte line), splits them into bf16 hi / lo in
+// registers and feeds two MFMAs (elements 0-7, then 8-15); W is re-laid once per call into fragments that follow the
+// same k permutation (k = 32 d + 16 h + 8 t + e), hi and lo images.  Kernel: joint_bwd_dz_split128_kernel below
+// (128 cells per workgroup, a wave owns 32 of them and all J columns, the W fragments of a step staged once per
+// workgroup in LDS; the first, 64-cell tiling of round 1 was 6-15 % slower and has been removed).
 constexpr int kZWaves = 4;
 constexpr int kZCT = 4;          // column tiles per wave: 4 waves x 4 x 32 = 512 = the largest join_dim
 
@@ -371,162 +371,6 @@ __device__ __forceinline__ void split8(const f32x4 &a, const f32x4 &b, bf16x8 &h
     split_pair(b[2], b[3], h3, l3);
     hi = __builtin_bit_cast(bf16x8, (u32x4){h0, h1, h2, h3});
     if (want_lo) lo = __builtin_bit_cast(bf16x8, (u32x4){l0, l1, l2, l3});
-}
-
-template <int TERMS>
-__global__ __launch_bounds__(64 * kZWaves) void joint_bwd_dz_split_kernel(
-    const float *__restrict__ gout /* [M, V] */, const float *__restrict__ ep, const float *__restrict__ pp,
-    const u32x4 *__restrict__ wh, const u32x4 *__restrict__ wl, const int32_t *__restrict__ llens,
-    const int32_t *__restrict__ tlens, int B, int T, int U1, int J, int V, int D, int n_jt,
-    float *__restrict__ dz /* [M, J] */, float *__restrict__ hout /* [M, J] or null */)
-{
-    __shared__ long row_e[kSM], row_p[kSM];                 // offsets of the rows' ep / pp vectors
-    __shared__ int row_ok[kSM];
-    const long M = (long)B * T * U1;
-    const long m0 = (long)blockIdx.x * kSM;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int half = lane >> 5, l31 = lane & 31;
-
-    int valid = 0;
-    if (tid < kSM) {
-        const long m = m0 + tid < M ? m0 + tid : M - 1;
-        const long bt = m / U1;
-        const int u = (int)(m - bt * U1);
-        const long b = bt / T;
-        valid = m0 + tid < M;
-        if (valid && llens != nullptr && tlens != nullptr) {
-            const int t = (int)(bt - b * T);
-            valid = (t < llens[b]) && (u <= tlens[b]);
-        }
-        row_e[tid] = bt * J;
-        row_p[tid] = (b * U1 + u) * J;
-        row_ok[tid] = valid;
-    }
-    const bool any = __syncthreads_or(valid);               // also publishes the row tables
-    if (!any) {                                             // wholly padded tile: zeros, no arithmetic
-        for (int i = tid; i < kSM * J; i += 64 * kZWaves) {
-            const long m = m0 + i / J;
-            if (m < M) {
-                dz[(size_t)m * J + i % J] = 0.f;
-                if (hout) hout[(size_t)m * J + i % J] = 0.f;
-            }
-        }
-        return;
-    }
-
-    f32x16 acc[2][kZCT];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int c = 0; c < kZCT; ++c) acc[r][c] = (f32x16){0};
-
-    // this lane's dY rows (clamped to the tensor) and W fragments (column tiles past join_dim reload the last one)
-    const float *__restrict__ arow[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const long m = m0 + 32 * r + l31 < M ? m0 + 32 * r + l31 : M - 1;
-        arow[r] = gout + (size_t)m * V + 16 * half;
-    }
-    int jt_w[kZCT];
-#pragma unroll
-    for (int c = 0; c < kZCT; ++c) jt_w[c] = wave * kZCT + c < n_jt ? wave * kZCT + c : n_jt - 1;
-    const u32x4 *__restrict__ whl = wh + lane;
-    const u32x4 *__restrict__ wll = wl + lane;
-    const int Dfull = V / 32;                               // double steps that lie wholly inside a row (V >= 32)
-
-    struct Set { f32x4 a[2][4]; u32x4 bh[kZCT][2], bl[kZCT][2]; };
-    auto load_b = [&](int dd, Set &z) {
-#pragma unroll
-        for (int c = 0; c < kZCT; ++c)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const size_t f = (((size_t)jt_w[c] * D + dd) * 2 + t) * 64;
-                z.bh[c][t] = whl[f];
-                if (TERMS == 3) z.bl[c][t] = wll[f];
-            }
-    };
-    auto load_set = [&](int d, Set &z) {                    // prefetches past the end reload the last full step
-        const int dd = d < Dfull ? d : Dfull - 1;
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) z.a[r][i] = *reinterpret_cast<const f32x4 *>(arow[r] + 32 * dd + 4 * i);
-        load_b(dd, z);
-    };
-    auto mfma_set = [&](Set &z) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            bf16x8 ah[2], al[2];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) split8(z.a[r][2 * t], z.a[r][2 * t + 1], ah[r], al[r], TERMS == 3);
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int c = 0; c < kZCT; ++c) {
-                    const bf16x8 bhv = __builtin_bit_cast(bf16x8, z.bh[c][t]);
-                    if (TERMS == 3) {
-                        const bf16x8 blv = __builtin_bit_cast(bf16x8, z.bl[c][t]);
-                        acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[r], bhv, acc[r][c], 0, 0, 0);
-                        acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[r], blv, acc[r][c], 0, 0, 0);
-                    }
-                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[r], bhv, acc[r][c], 0, 0, 0);
-                }
-        }
-    };
-    Set s0, s1, s2;
-    load_set(0, s0);
-    load_set(1, s1);
-    for (int d = 0; d < Dfull; d += 3) {
-        load_set(d + 2, s2);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_set(s0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (d + 1 >= Dfull) break;
-        load_set(d + 3, s0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_set(s1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (d + 2 >= Dfull) break;
-        load_set(d + 4, s1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_set(s2);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (Dfull < D) {                                        // the row's tail (V % 32 values): guarded scalar reads
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int v = 32 * Dfull + 16 * half + 4 * i + e;
-                    s0.a[r][i][e] = v < V ? arow[r][32 * Dfull + 4 * i + e] : 0.f;
-                }
-        load_b(Dfull, s0);
-        mfma_set(s0);
-    }
-
-    // epilogue: dZ = dH * (1 - H^2), H recomputed per element; padded cells give zeros
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int row = 32 * r + (q & 3) + 8 * (q >> 2) + 4 * half;
-            const long m = m0 + row;
-            if (m >= M) continue;
-            const bool ok = row_ok[row] != 0;
-            const float *__restrict__ e = ep + row_e[row];
-            const float *__restrict__ p = pp + row_p[row];
-#pragma unroll
-            for (int c = 0; c < kZCT; ++c) {
-                const int k = (wave * kZCT + c) * 32 + l31;
-                if (k >= J) continue;
-                const float h = tanhf(e[k] + p[k]);
-                dz[(size_t)m * J + k] = ok ? acc[r][c][q] * (1.f - h * h) : 0.f;
-                if (hout) hout[(size_t)m * J + k] = ok ? h : 0.f;
-            }
-        }
-    }
 }
 
 // dZ, second tiling: the W fragments of a step are needed by every row tile, so here the waves split the ROWS (a
@@ -1408,7 +1252,7 @@ extern "C" int wr_joint_bwd_dz_split(const float *gout_d, const float *ep_d, con
     WR_CHECK_LAUNCH("split_w_dz_kernel");
     const long M = (long)B * T * U1;
     const dim3 grid((unsigned)((M + kSM - 1) / kSM));
-    if (tune_get(kTuneDzTile) != 1) {                       // default: 128-cell tiling, W fragments staged in LDS
+    {                                                       // 128-cell tiling, W fragments staged in LDS
         const size_t lds = (size_t)kZStages * 2 * 16 * 64 * 16 + (size_t)kZM2 * (2 * sizeof(long) + sizeof(int));
         const dim3 grid2((unsigned)((M + kZM2 - 1) / kZM2));
 #define WR_LAUNCH_DZ2(TERMS)                                                                                           \
@@ -1422,17 +1266,7 @@ extern "C" int wr_joint_bwd_dz_split(const float *gout_d, const float *ep_d, con
         if (terms == 3) WR_LAUNCH_DZ2(3); else WR_LAUNCH_DZ2(1);
 #undef WR_LAUNCH_DZ2
         WR_CHECK_LAUNCH("joint_bwd_dz_split128_kernel");
-        return WR_OK;
     }
-    if (terms == 3)
-        hipLaunchKernelGGL(joint_bwd_dz_split_kernel<3>, grid, dim3(64 * kZWaves), 0, st, gout_d, ep_d, pp_d,
-                           reinterpret_cast<const u32x4 *>(wh), reinterpret_cast<const u32x4 *>(wl), logit_lengths_d,
-                           target_lengths_d, B, T, U1, J, V, D, n_jt, dz_d, h_d);
-    else
-        hipLaunchKernelGGL(joint_bwd_dz_split_kernel<1>, grid, dim3(64 * kZWaves), 0, st, gout_d, ep_d, pp_d,
-                           reinterpret_cast<const u32x4 *>(wh), reinterpret_cast<const u32x4 *>(wl), logit_lengths_d,
-                           target_lengths_d, B, T, U1, J, V, D, n_jt, dz_d, h_d);
-    WR_CHECK_LAUNCH("joint_bwd_dz_split_kernel");
     return WR_OK;
 }
 
