@@ -152,3 +152,54 @@ def test_fused_argument_checks():
         w_.joint_rnnt_loss(ep, pp, w, b, y, tl, ul, precision="bf16")
     with pytest.raises(RuntimeError, match="HIP device"):
         w_.joint_rnnt_loss(ep.cpu(), pp.cpu(), w.cpu(), b.cpu(), y.cpu(), tl.cpu(), ul.cpu())
+
+
+def test_full_baseline_shape_loss_block():
+    """The loss block of Transducer.forward at the BASELINE shape (B=32, T=1000, U=150, V=5000, join_dim 512, ragged
+    lengths): the fused node against the two separate ops -- costs to 1e-6, every gradient to 1e-5 of its largest entry --
+    and 64 sampled logit rows of the separate ops' output against a float64 evaluation of joint.py:60-69 (their
+    log-sum-exp against the fused node's through the costs).  One logits-sized tensor (96.6 GB) lives at a time."""
+    import gc
+    import wenet_celoss_amd as w_
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150 * 2 ** 30:
+        pytest.skip("needs 150 GB of free HBM")
+    B, T, U, J, V = 32, 1000, 150, 512, 5000
+    g = torch.Generator().manual_seed(17)
+    ep = (torch.randn(B, T, J, generator=g) * 0.7).to(DEV)
+    pp = (torch.randn(B, U + 1, J, generator=g) * 0.7).to(DEV)
+    w = (torch.randn(V, J, generator=g) * 0.06).to(DEV)
+    b = (torch.randn(V, generator=g) * 0.5).to(DEV)
+    y = torch.randint(1, V, (B, U), generator=g, dtype=torch.int32).to(DEV)
+    tl = torch.randint(T // 2, T + 1, (B,), generator=g); tl[0] = T
+    ul = torch.randint(U // 3, U + 1, (B,), generator=g); ul[-1] = U
+    tl, ul = tl.to(torch.int32).to(DEV), ul.to(torch.int32).to(DEV)
+    gc_w = torch.linspace(0.5, 1.5, B, device=DEV)
+
+    def run(fused):
+        leaves = [t.clone().requires_grad_(True) for t in (ep, pp, w, b)]
+        if fused:
+            costs = w_.joint_rnnt_loss(*leaves, y, tl, ul, blank=0, reduction="none")
+        else:
+            logits = w_.joint_logits(*leaves, tl, ul)
+            costs = w_.rnnt_loss(logits, y, tl, ul, blank=0, reduction="none", inplace_grad=True)
+            del logits
+        (costs * gc_w).sum().backward()
+        out = (costs.detach().clone(), [t.grad.clone() for t in leaves])
+        del costs, leaves
+        gc.collect(); torch.cuda.empty_cache()
+        return out
+    c1, g1 = run(True)
+    c0, g0 = run(False)
+    assert torch.isfinite(c1).all()
+    torch.testing.assert_close(c1, c0, rtol=1e-6, atol=1e-3)
+    for name, a, r in zip(("ep", "pp", "w", "b"), g1, g0):
+        assert float((a - r).abs().max()) <= 1e-5 * float(r.abs().max()) + 1e-12, name
+    # sampled rows of the logits against float64
+    logits = w_.joint_logits(ep, pp, w, b, tl, ul)
+    rs = np.random.default_rng(3)
+    wd, bd = w.double().cpu(), b.double().cpu()
+    for _ in range(64):
+        bi = int(rs.integers(B)); t = int(rs.integers(int(tl[bi]))); u = int(rs.integers(int(ul[bi]) + 1))
+        ref = torch.tanh(ep[bi, t].double().cpu() + pp[bi, u].double().cpu()) @ wd.T + bd
+        np.testing.assert_allclose(logits[bi, t, u].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)

@@ -142,6 +142,8 @@ def test_reference_init_model_unedited_builds_our_transducer():
         assert type(m.encoder).__module__ == "wenet.transformer.encoder"
         assert type(m.context_bias).__module__ == "wenet.transformer.context_bias"
         assert type(m.ctc) is w.CTC and type(m.joint) is w.TransducerJoint
+        from wenet_celoss_amd.hotword import device_capable
+        assert device_capable(m.context_bias)      # the reference's own ContextBias takes the device hot-word path
         keys = set(m.state_dict())
         for k in ("joint.ffn_out.weight", "ctc.ctc_lo.bias", "predictor.rnn.weight_hh_l1", "encoder.after_norm.weight"):
             assert k in keys, k
