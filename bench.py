@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: let the N ranks share the visible devices (rank %% devices) and use the gloo "
                          "backend for the barrier -- exercises the N>1 code path on a 1-GPU box; the line is marked")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0,
+                    help="self-launch only: seconds after which ranks that are still running are stopped (exit code 3)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="utterances timed on the CPU (-1: auto, 0: skip)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time budget for the baseline")
     return ap.parse_args()
@@ -88,8 +90,12 @@ def self_launch(args) -> int:
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     failed = None
     pending = set(range(n))
+    deadline = time.monotonic() + args.launch_timeout
     while pending and failed is None:
         time.sleep(0.2)
+        if time.monotonic() > deadline:
+            failed = (min(pending), "timeout")
+            break
         for r in sorted(pending):
             rc = procs[r].poll()
             if rc is not None:
@@ -101,6 +107,9 @@ def self_launch(args) -> int:
             procs[r].kill()                       # exact PIDs of our own children
         for p in procs:
             p.wait()
+        if failed[1] == "timeout":
+            print(f"bench.py: ranks {sorted(pending)} still running after {args.launch_timeout:.0f} s; stopped", file=sys.stderr)
+            return 3
         print(f"bench.py: rank {failed[0]} exited with code {failed[1]}", file=sys.stderr)
         return 1
     out = procs[0].stdout.read()

@@ -219,6 +219,22 @@ def test_joiner_and_predictor_variants_accepted_or_refused_loudly():
     assert e.shape == (2, 3, 8) and pp.shape == (2, 4, 8)
 
 
+def test_bench_self_launch_names_the_missing_devices():
+    """`python bench.py --gpus N` without a launcher environment starts its own ranks; with fewer than N devices
+    visible it must stop before touching a GPU, naming what is missing (here: no GPU at all)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two devices visible")
+    assert r.returncode == 2 and "needs 2 HIP devices" in r.stderr and "missing: " in r.stderr and r.stdout == ""
+    # a launcher environment that disagrees with --gpus is refused as well
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="4", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+
+
 def test_transducer_constructor_contract():
     """Same keyword surface and weight-sum assertion as the reference (transducer.py:23-46)."""
     import wenet_celoss_amd as w
