@@ -208,9 +208,15 @@ class Transducer(nn.Module):
         hyps_pad_blank = add_blank(hyps_pad, self.blank, self.ignore_id)
         xs_in_lens = encoder_mask.squeeze(1).sum(1).int()
         predictor_out = self.predictor(hyps_pad_blank)
-        joint_out = self.joint(encoder_out, predictor_out)
         rnnt_text = hyps_pad.to(torch.int64)
         rnnt_text = torch.where(rnnt_text == self.ignore_id, 0, rnnt_text).to(torch.int32)
+        if self._can_fuse_loss():                   # same node as the training loss block: no pass 1 over the logits
+            ep, pp = self.joint.pre_activation(encoder_out, predictor_out)
+            loss_td = joint_rnnt_loss(ep, pp, self.joint.ffn_out.weight, self.joint.ffn_out.bias, rnnt_text,
+                                      xs_in_lens, hyps_lens.int(), blank=self.blank, reduction="none",
+                                      precision=self.joint.precision)
+            return loss_td * -1
+        joint_out = self.joint(encoder_out, predictor_out)
         loss_td = rnnt_loss(joint_out, rnnt_text.contiguous(), xs_in_lens.contiguous(), hyps_lens.int().contiguous(),
                             blank=self.blank, reduction="none")
         return loss_td * -1
