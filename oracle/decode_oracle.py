@@ -240,11 +240,11 @@ class ContextBiasNP:
 
 
 def greedy_search_both(pred: Predictor, joint: Joint, cb: ContextBiasNP, hidden, hidden_empty, enc_hot, enc_hot_feat,
-                       enc_cold, T, labels, blank=0, n_steps=64, filter_on=False):
+                       enc_cold, T, labels, blank=0, n_steps=64, filter_on=False, return_go_backs=False):
     """/root/reference/wenet/transducer/search/greedy_search.py:297-430 (`basic_greedy_search_both`) for one
     utterance, from the loop-invariant tensors on: hidden (Nc, D) / hidden_empty (1, D) = forward_bias_hidden of the
     hot-word list / of the empty list (:327-333), enc_hot / enc_hot_feat / enc_cold (T, D) = forward_encoder_bias
-    (:335-336).  Returns (hyps, dist, gate trace, number of joiner decisions)."""
+    (:335-336).  Returns (hyps, dist, gate trace, number of joiner decisions[, number of go-backs])."""
     cache = pred.init_state(1)
     new_cache = cache
     tok = np.array([blank])
@@ -253,7 +253,7 @@ def greedy_search_both(pred: Predictor, joint: Joint, cb: ContextBiasNP, hidden,
     prev_nblk, per_frame = True, 0
     go_back, go_back_end, last_t = False, -1, 0
     steps, caches, inputs = [], [], []
-    out, decisions = None, 0
+    out, decisions, n_back = None, 0, 0
     while t < T:
         if prev_nblk:
             raw, new_cache = pred.forward_step(tok, padding, cache)
@@ -268,6 +268,7 @@ def greedy_search_both(pred: Predictor, joint: Joint, cb: ContextBiasNP, hidden,
                     else:
                         if result and result[-1] == 0:
                             go_back_end, t, go_back = t, last_t, True
+                            n_back += 1
                             result.pop(); hyps.pop(); inputs.pop()
                             per_frame -= 1
                             steps.pop(); caches.pop()
@@ -297,7 +298,8 @@ def greedy_search_both(pred: Predictor, joint: Joint, cb: ContextBiasNP, hidden,
                 prev_nblk = False
             t += 1
             per_frame = 0
-    return hyps, edit_distance(list(labels), result), result, decisions
+    res = (hyps, edit_distance(list(labels), result), result, decisions)
+    return res + (n_back,) if return_go_backs else res
 
 
 def edit_distance(a, b):

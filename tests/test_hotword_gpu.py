@@ -144,6 +144,64 @@ def test_shipped_shape_against_the_numpy_oracle():
     assert compared >= 3
 
 
+@pytest.mark.parametrize("n_steps", [1, 2, 3, 64])
+def test_random_models_against_the_numpy_oracle(n_steps):
+    """Many small random models (V = 48, D = 16) with a gate that flips often: go-backs at the emission cap, right at
+    frame 0, several in a row.  Tokens, gate trace and edit distance equal the numpy restatement (pinned to the
+    reference by the fixtures) whenever every joiner decision and every gate was clear."""
+    from context_bias_mirror import ContextBiasMirror
+    from oracle import decode_oracle as do
+    import wenet_celoss_amd as w
+    from wenet_celoss_amd.hotword import greedy_search_both_device
+    V, D, J, H, L, HW, T = 48, 16, 32, 16, 2, 8, 36
+    compared = go_backs = 0
+    for seed in range(12):
+        torch.manual_seed(1000 * n_steps + seed)
+        pred = w.RNNPredictor(V, D, D, 0.1, H, L).eval()
+        joint = w.TransducerJoint(V, D, D, J).eval()
+        cb = ContextBiasMirror(V, D, layers=1, heads=2, hw_dim=HW, hw_heads=2).eval()
+        with torch.no_grad():
+            for prm in list(pred.parameters()) + list(joint.parameters()):
+                prm.mul_(3.0)
+            joint.ffn_out.bias[0] += 2.5
+            cb.hw_output_layer_enc.weight.mul_(6.0)
+            cb.hw_output_layer.weight.mul_(4.0)
+        enc = torch.randn(1, T, D)
+        ctx = torch.randint(1, V, (4, 3)); ctx[0, 0] = 0
+        ctx_len = torch.tensor([1, 3, 2, 3], dtype=torch.int32)
+        for r in range(4):
+            ctx[r, ctx_len[r]:] = -1
+        with torch.no_grad():
+            hidden = cb.forward_bias_hidden(ctx, ctx_len)
+            hidden_empty = cb.forward_bias_hidden(torch.zeros((1, 1), dtype=torch.int), ctx_len[0].unsqueeze(0))
+            enc_hot, feat = cb.forward_encoder_bias(hidden, enc)
+            enc_cold, _ = cb.forward_encoder_bias(hidden_empty, enc.clone())
+            gl = cb.forward_hw_pred_both(feat.transpose(0, 1), torch.zeros(T, 1, D))[:, 0, :]
+            dlt = (gl[:, 0] - gl[:, 1]).sort().values
+            cb.hw_output_layer.bias[1] += float((dlt[T // 2 - 1] + dlt[T // 2]) / 2)
+            gl = cb.forward_hw_pred_both(feat.transpose(0, 1), torch.zeros(T, 1, D))[:, 0, :]
+        labels = [0, 1, 1, 0, 1]
+        mj = MarginTracker(do.Joint({k: v.detach().numpy() for k, v in joint.state_dict().items()}))
+        ref = do.greedy_search_both(do.Predictor({k: v.detach().numpy() for k, v in pred.state_dict().items()}, L), mj,
+                                    do.ContextBiasNP({k: v.detach().numpy() for k, v in cb.state_dict().items()}, 2, 2),
+                                    hidden[0].numpy(), hidden_empty[0].numpy(), enc_hot[0].numpy(), feat[0].numpy(),
+                                    enc_cold[0].numpy(), T, labels, n_steps=n_steps, filter_on=True, return_go_backs=True)
+        if float((gl[:, 0] - gl[:, 1]).abs().min()) < 1e-3 or mj.min_margin < 1e-3:
+            continue
+        m = w.Transducer(V, 0, torch.nn.Identity(), pred.to(DEV), joint.to(DEV), context_bias=cb.to(DEV), ctc_weight=0.0,
+                         transducer_weight=1.0, loss_mode="both")
+        out = w.basic_greedy_search_both(m, enc.to(DEV), torch.tensor(T), ctx, ctx_len, n_steps=n_steps,
+                                         context_filter_state="on", context_decoder_labels_padded=torch.tensor([labels]))
+        _, traces = greedy_search_both_device(m, enc.to(DEV), torch.tensor(T), ctx, ctx_len, n_steps=n_steps, filter_on=True)
+        assert out[0] == [ref[0]], (seed, n_steps)
+        assert traces[0] == ref[2], (seed, n_steps)
+        assert out[1] == ref[1]
+        compared += 1
+        go_backs += ref[4]
+    assert compared >= 6, compared
+    assert go_backs > 0 or n_steps == 64           # with 64 tokens per frame these models rarely cross a gate flip
+
+
 class MarginTracker:
     """Joiner wrapper for the numpy oracle: smallest top-1 / top-2 logit gap over all decisions."""
 
