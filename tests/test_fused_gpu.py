@@ -62,6 +62,19 @@ def test_fused_equals_unfused_and_oracle(case, precision):
         np.testing.assert_allclose(costs.detach().cpu().numpy(), oc, rtol=2e-5)
 
 
+def test_fused_inplace_and_separate_gradient_buffers_agree(monkeypatch):
+    import wenet_celoss_amd as w_
+    args = make(3, 70, 11, 32, 257, True)
+    res = []
+    for thr in ("0", str(1 << 40)):                          # always in place / never
+        monkeypatch.setenv("WR_FUSED_INPLACE_BYTES", thr)
+        leaves = [t.clone().requires_grad_(True) for t in args[:4]]
+        w_.joint_rnnt_loss(*leaves, *args[4:], blank=0, reduction="sum").backward()
+        res.append([t.grad.clone() for t in leaves])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 def test_fused_workspace_matches_pass1():
     """The lattice the sweeps build from the epilogue's statistics equals the one built from rnnt_lse_kernel's."""
     import wenet_celoss_amd as w_

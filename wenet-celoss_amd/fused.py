@@ -6,14 +6,15 @@ pass 1 read, gradient pass read + write, joiner backward read).  A joiner forwar
 its 64 lattice cells, so it produces the loss's row statistics (denom, skip / emit log-probabilities) in its
 epilogue (`wr_joint_fwd_lse`); the loss then only runs its lattice sweeps (`wr_rnnt_loss_fwd_from_lse`) -- pass 1,
 one full read of the logits (16.6 ms of the 50 ms loss step at B=32, T=1000, U=150, V=5000), is gone.  And because
-the logits are internal to the node, the gradient pass writes over them: the peak footprint is one logits-sized
-tensor instead of two.
+the logits are internal to the node, the gradient pass can write over them (done above 16 GiB of logits, where the
+footprint matters: one logits-sized tensor instead of two).
 
 Results: costs and every gradient agree with the unfused path to fp32 rounding of the row log-sum-exp (the
 statistics are merged in a different order); tests/test_fused_gpu.py states the tolerance (1e-6 relative on costs).
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -70,12 +71,17 @@ class _JointRnntFn(torch.autograd.Function):
         B, T, U1, V = logits.shape
         dev = logits.device
         gc = grad_costs.to(torch.float32).contiguous()
-        with torch.cuda.device(dev):      # the gradient w.r.t. the logits overwrites them: nothing else holds the tensor
+        # Nothing else holds the logits, so the gradient may overwrite them (one logits-sized tensor instead of two).
+        # Rewriting a line microseconds after reading it costs the gradient pass ~11 % (5.2 against 5.85 TB/s, DESIGN.md
+        # section 4), so this is done only where the footprint matters: above WR_FUSED_INPLACE_BYTES (default 16 GiB).
+        inplace = logits.numel() * logits.element_size() > int(os.environ.get("WR_FUSED_INPLACE_BYTES", str(16 << 30)))
+        grads = logits if inplace else torch.empty_like(logits)
+        with torch.cuda.device(dev):
             rc = lib.wr_rnnt_loss_bwd(_lib.ptr(logits), _lib.WR_F32, _lib.ptr(targets), _lib.ptr(llens), _lib.ptr(tlens),
-                                      B, T, U1, V, ctx.blank, float(ctx.clamp), _lib.ptr(gc), _lib.ptr(logits),
+                                      B, T, U1, V, ctx.blank, float(ctx.clamp), _lib.ptr(gc), _lib.ptr(grads),
                                       _lib.ptr(rws), rws.numel(), _lib.current_stream(dev))
         _lib.check(rc, "wr_rnnt_loss_bwd")
-        d_ep, d_pp, d_w, d_b = joint_backward(logits, ep, pp, w, llens, tlens, ctx.terms, ctx.needs_input_grad[2],
+        d_ep, d_pp, d_w, d_b = joint_backward(grads, ep, pp, w, llens, tlens, ctx.terms, ctx.needs_input_grad[2],
                                               ctx.needs_input_grad[3], gout_zero_in_padding=True)
         return d_ep, d_pp, d_w, d_b, None, None, None, None, None, None
 
