@@ -583,3 +583,38 @@ def test_greedy_without_prejoin_linear_matches_oracle():
     ref, margin = do.greedy_search(do.Predictor(pw, L), do.Joint(jd), enc[0].cpu().numpy(), T, n_steps=4, return_margin=True)
     assert margin > 1e-4 and len(ref) > 3
     assert hyps == [ref]
+
+
+@pytest.mark.parametrize("where", ["same_block", "other_block", "with_blank"])
+def test_greedy_exact_ties_go_to_the_first_index(where):
+    """Two vocabulary entries with identical joiner rows tie exactly on every step; log_softmax + argmax give the lower
+    index (torch.argmax, numpy argmax).  The device resolves rows from per-block records: the pair shares a 32-column
+    block (runner-up equals the block maximum: the block is re-read and scanned), sits in two blocks, or involves blank.
+    The duplicated entry is the fixture's most frequent token, so the tie is at the top of many decisions."""
+    import wenet_celoss_amd as w
+    d = np.load(names("greedy_core_6.npz")[0])
+    pred, joint, _ = build_modules(d)
+    toks, counts = np.unique(d["hyp"], return_counts=True)
+    hot = int(toks[counts.argmax()])                      # wins the argmax most often
+    if where == "same_block":
+        a, b = hot, hot + 1 if hot % 32 != 31 else hot - 1
+    elif where == "other_block":
+        a, b = hot, (hot + 32) % 64 or 1
+    else:
+        a, b = 0, hot                                     # the token gets blank's row: blank (index 0) wins their ties
+    lo, hi = min(a, b), max(a, b)
+    with torch.no_grad():
+        src = a if where == "with_blank" else hot
+        dst = b if src == a else a
+        joint.ffn_out.weight[dst] = joint.ffn_out.weight[src]
+        joint.ffn_out.bias[dst] = joint.ffn_out.bias[src]
+    model = types.SimpleNamespace(blank=0, predictor=pred, joint=joint)
+    T, n_steps = int(d["T"]), int(d["n_steps"])
+    enc = torch.tensor(d["enc"], device=DEV)
+    hyps = w.basic_greedy_search(model, enc, torch.tensor(T), n_steps=n_steps)
+    jw = {k: v.detach().cpu().numpy() for k, v in joint.state_dict().items()}
+    ref = do.greedy_search(do.Predictor(sub(d, "pred_"), int(d["n_layers"])), do.Joint(jw), d["enc"][0], T, n_steps=n_steps)
+    assert hyps == [ref]
+    assert hi not in ref                                  # the higher index of a tied pair never wins
+    if where != "with_blank":
+        assert lo in ref                                  # ... and the tie was at the top: the lower index was emitted
