@@ -129,7 +129,7 @@ int wr_rnnt_export_lattice(const void *workspace_d, size_t workspace_bytes,
  * per utterance (infeasible alignment -> +inf, a value, not an error);
  * reduction ('sum' then /B in the reference, ctc.py:61-63) is the caller's and
  * is folded into grad_nll.  grads = grad_nll[b] * d nll_b / d logits, zero for
- * t >= input_lengths[b]; grads_d may alias logits_d.  Limits: Smax <= 255,
+ * t >= input_lengths[b]; grads_d may alias logits_d.  Limits: Smax <= 511,
  * V <= 16384.
  * ---------------------------------------------------------------------- */
 size_t wr_ctc_workspace_bytes(int B, int Tmax, int Smax);

@@ -49,8 +49,8 @@ def test_bad_arguments_are_rejected_without_launch(lib):
     assert rc == -1 and b"null" in lib.wr_last_error()
     rc = lib.wr_rnnt_loss_fwd(null, 0, null, null, null, 2, 4, 3, 8, 9, null, null, 0, null)
     assert rc == -1 and b"blank" in lib.wr_last_error()
-    rc = lib.wr_rnnt_loss_fwd(null, 0, null, null, null, 2, 4, 600, 8, 0, null, null, 0, null)
-    assert rc == -2 and b"512" in lib.wr_last_error()
+    rc = lib.wr_rnnt_loss_fwd(null, 0, null, null, null, 2, 4, 1100, 8, 0, null, null, 0, null)
+    assert rc == -2 and b"1024" in lib.wr_last_error()
     rc = lib.wr_rnnt_loss_bwd(null, 0, null, null, null, 0, 4, 3, 8, 0, -1.0, null, null, null, 0, null)
     assert rc == -1
 
@@ -80,8 +80,8 @@ def test_every_entry_point_rejects_bad_arguments_before_launch(lib):
     from wenet_celoss_amd import _lib
     null = ctypes.c_void_p(None)
     # CTC: label sequences longer than the sweep supports; vocabulary wider than the gradient kernel's LDS row
-    assert lib.wr_ctc_loss_fwd(null, 0, null, null, null, 2, 10, 300, 50, 0, null, null, 0, null) == -2
-    assert b"255" in lib.wr_last_error()
+    assert lib.wr_ctc_loss_fwd(null, 0, null, null, null, 2, 10, 600, 50, 0, null, null, 0, null) == -2
+    assert b"511" in lib.wr_last_error()
     assert lib.wr_ctc_loss_fwd(null, 0, null, null, null, 2, 10, 5, 20000, 0, null, null, 0, null) == -2
     assert lib.wr_ctc_loss_bwd(null, 0, null, null, null, 2, 10, 5, 50, 0, null, null, null, 0, null) == -1
     assert lib.wr_ctc_workspace_bytes(2, 10, 5) > 0 and lib.wr_ctc_workspace_bytes(0, 10, 5) == 0

@@ -50,7 +50,9 @@ def make(rng, B, T, S, V, repeat=False, full=False):
     (2, 90, 40, 64, True),      # 81 states, KS=2
     (2, 200, 80, 50, False),    # KS=3
     (2, 330, 150, 40, True),    # 301 states, KS=5: the BASELINE label length
-    (1, 520, 255, 30, False),   # KS=8: supported maximum
+    (1, 520, 255, 30, False),   # KS=8: round 1's maximum
+    (2, 1100, 400, 25, True),   # 801 states, 13 waves
+    (1, 1030, 511, 12, False),  # 1023 states: the supported maximum (16 waves)
     (5, 77, 12, 1000, True),
 ])
 def test_parity_vs_oracle(B, T, S, V, repeat):

@@ -191,14 +191,14 @@ def test_label_width_limits_are_reported_before_launch():
     """The loss kernels' label-width limits are checked in Transducer.forward on the padded batch, naming the longest
     utterance -- on the CPU, before any kernel (or the missing GPU) is touched."""
     from wenet_celoss_amd.transducer import check_limits
-    text = torch.zeros(3, 300, dtype=torch.long)
-    lens = torch.tensor([10, 300, 40])
-    check_limits(text[:, :255], lens.clamp(max=255), with_ctc=True)
+    text = torch.zeros(3, 600, dtype=torch.long)
+    lens = torch.tensor([10, 600, 40])
+    check_limits(text[:, :511], lens.clamp(max=511), with_ctc=True)
     check_limits(text, lens, with_ctc=False)
-    with pytest.raises(RuntimeError, match=r"utterance 1 with 300 labels.*255"):
+    with pytest.raises(RuntimeError, match=r"utterance 1 with 600 labels.*511"):
         check_limits(text, lens, with_ctc=True)
-    with pytest.raises(RuntimeError, match=r"511 labels"):
-        check_limits(torch.zeros(2, 600, dtype=torch.long), torch.tensor([600, 3]), with_ctc=False)
+    with pytest.raises(RuntimeError, match=r"1023 labels"):
+        check_limits(torch.zeros(2, 1100, dtype=torch.long), torch.tensor([1100, 3]), with_ctc=False)
 
 
 def test_joiner_and_predictor_variants_accepted_or_refused_loudly():

@@ -70,7 +70,9 @@ def test_public_known_answer():
     (2, 40, 150, 36),      # U1 = 151 -> K = 3 (the BASELINE shape's width)
     (2, 12, 200, 20),      # K = 4
     (1, 9, 300, 12),       # K = 5
-    (1, 6, 511, 8),        # K = 8, the supported maximum
+    (1, 6, 511, 8),        # 8 waves: round 1's maximum
+    (2, 9, 700, 12),       # 701 columns, 11 waves
+    (1, 5, 1023, 6),       # 1024 columns: the supported maximum (16 waves)
     (5, 130, 30, 64),      # more steps than the prefetch ring several times over
 ])
 def test_parity_ragged(B, T, U, V):

@@ -26,6 +26,8 @@
 namespace wr {
 namespace {
 
+constexpr int kCtcMaxStates = 1024;     // one lane per state of the extended label sequence: Smax <= 511
+
 struct CtcWs {
     int KS;           // extended-label states per lane
     int SP;           // 2*Smax+1
@@ -45,7 +47,7 @@ inline CtcWs ctc_ws_layout(int B, int Tmax, int Smax)
     w.alpha_off = off; off = align_up(off + frames * w.SP * sizeof(double), 256);
     w.beta_off = off;  off = align_up(off + frames * w.SP * sizeof(double), 256);
     w.nll_off = off;   off = align_up(off + (size_t)B * sizeof(double), 256);
-    w.dump_off = off;  off = align_up(off + (size_t)B * 2 * 512 * sizeof(double), 256);
+    w.dump_off = off;  off = align_up(off + (size_t)B * 2 * kCtcMaxStates * sizeof(double), 256);
     w.total = off;
     return w;
 }
@@ -128,7 +130,7 @@ __device__ __forceinline__ double lse3_d(double a, double b, double c)
 // one LDS write, one s_barrier.  Log-prob rows are prefetched PF frames ahead with unconditional (clamped) loads;
 // idle lanes store to a sink so the loop body is straight-line.
 template <int PF>
-__global__ __launch_bounds__(512) void ctc_sweep_kernel(
+__global__ __launch_bounds__(kCtcMaxStates) void ctc_sweep_kernel(
     const float *__restrict__ lp_blank, const float *__restrict__ lp_label,
     const int32_t *__restrict__ targets, const int32_t *__restrict__ ilens,
     const int32_t *__restrict__ tlens, int Tmax, int Smax, int SP,
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(512) void ctc_sweep_kernel(
     float *__restrict__ nll_out, double *__restrict__ dump)
 {
     constexpr double NEG = (double)kNegInf;
-    __shared__ double prev[2][512 + 4];            // states shifted by 2; two NEG guard cells on each side
+    __shared__ double prev[2][kCtcMaxStates + 4];  // states shifted by 2; two NEG guard cells on each side
     const int b = blockIdx.x;
     const bool backward = blockIdx.y != 0;
     const int s = threadIdx.x;                     // state index
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(512) void ctc_sweep_kernel(
     const float *__restrict__ lpb = lp_blank + (size_t)b * Tmax;
     const float *__restrict__ lpl = lp_label + (size_t)b * Tmax * Smax;
     double *__restrict__ out = (backward ? beta : alpha) + (size_t)b * Tmax * SP;
-    double *__restrict__ sink = dump + ((size_t)b * 2 + (backward ? 1 : 0)) * 512 + s;
+    double *__restrict__ sink = dump + ((size_t)b * 2 + (backward ? 1 : 0)) * kCtcMaxStates + s;
 
     if (T == 0) {
         // no frames: feasible only for the empty target (ATen: nll = 0 if S == 0 else inf)
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(512) void ctc_sweep_kernel(
         const float ll = lpl[(size_t)tc * Smax + li];
         return is_label ? ll : lb;
     };
-    for (int i = threadIdx.x; i < 2 * (512 + 4); i += blockDim.x) (&prev[0][0])[i] = NEG;
+    for (int i = threadIdx.x; i < 2 * (kCtcMaxStates + 4); i += blockDim.x) (&prev[0][0])[i] = NEG;
     __syncthreads();
 
     float ring[PF];
@@ -297,12 +299,12 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
 // One workgroup per utterance, one lane per state, fp32 like the reference; ties prefer the first candidate
 // [s, s-1, s-2] (torch.argmax).  Quirk kept: for s = 0 the reference reads log_alpha[t-1, s-1] with s-1 = -1,
 // i.e. the LAST state (Python negative index) -- reproduced by wrapping.
-__global__ __launch_bounds__(512) void ctc_viterbi_kernel(
+__global__ __launch_bounds__(kCtcMaxStates) void ctc_viterbi_kernel(
     const float *__restrict__ lp_blank, const float *__restrict__ lp_label, const int32_t *__restrict__ targets,
     const int32_t *__restrict__ ilens, const int32_t *__restrict__ tlens, int Tmax, int Smax, int SP, int blank,
     int16_t *__restrict__ backptr /* [B][Tmax][SP] */, int32_t *__restrict__ align /* [B][Tmax] */)
 {
-    __shared__ float prev[2][512];
+    __shared__ float prev[2][kCtcMaxStates];
     __shared__ int s_state;
     const int b = blockIdx.x, s = threadIdx.x;
     int T = ilens[b], S = tlens[b];
@@ -360,8 +362,8 @@ int ctc_check(int B, int Tmax, int Smax, int V, int blank)
     WR_REQUIRE(B > 0 && Tmax > 0 && Smax >= 0 && V > 0, WR_EINVAL,
                "ctc: B, Tmax, V must be positive and Smax >= 0 (got %d,%d,%d,%d)", B, Tmax, Smax, V);
     WR_REQUIRE(blank >= 0 && blank < V, WR_EINVAL, "ctc: blank %d out of range [0,%d)", blank, V);
-    WR_REQUIRE((2 * Smax + 1 + kWave - 1) / kWave <= 8, WR_EUNSUPPORTED,
-               "ctc: Smax=%d exceeds the sweep kernel's limit of 255 labels", Smax);
+    WR_REQUIRE(2 * Smax + 1 <= kCtcMaxStates, WR_EUNSUPPORTED,
+               "ctc: Smax=%d exceeds the sweep kernel's limit of %d labels", Smax, (kCtcMaxStates - 1) / 2);
     WR_REQUIRE((size_t)V * sizeof(float) <= 64 * 1024, WR_EUNSUPPORTED,
                "ctc: V=%d does not fit the gradient kernel's LDS row (max 16384)", V);
     return WR_OK;

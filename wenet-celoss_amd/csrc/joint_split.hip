@@ -1213,7 +1213,7 @@ extern "C" int wr_joint_fwd_split_lse(const float *ep_d, const float *pp_d, cons
     WR_REQUIRE(logit_lengths_d && target_lengths_d, WR_EINVAL, "joint_fwd_split_lse: both length arrays are required");
     WR_REQUIRE(targets_d || U1 == 1, WR_EINVAL, "joint_fwd_split_lse: targets is null");
     WR_REQUIRE(blank >= 0 && blank < V, WR_EINVAL, "joint_fwd_split_lse: blank %d out of range [0,%d)", blank, V);
-    WR_REQUIRE(rnnt_cols_per_lane(U1) <= 8, WR_EUNSUPPORTED, "joint_fwd_split_lse: U1=%d exceeds the loss's limit of 512", U1);
+    WR_REQUIRE(U1 <= kRnntMaxCols, WR_EUNSUPPORTED, "joint_fwd_split_lse: U1=%d exceeds the loss's limit of %d", U1, kRnntMaxCols);
     const RnntWs w = rnnt_ws_layout(B, T, U1);
     WR_REQUIRE(rnnt_workspace_bytes >= w.total, WR_EWORKSPACE, "joint_fwd_split_lse: RNN-T workspace %zu < required %zu",
                rnnt_workspace_bytes, w.total);

@@ -204,15 +204,15 @@ __device__ __forceinline__ double lane_rotate_down_d(double v)
 // straight-line: loads are unconditional (clamped rows, values masked afterwards) and idle lanes store
 // to a sink, so PF rows of log-probs stay in flight under counted s_waitcnt.
 template <int PF>
-__global__ __launch_bounds__(512) void rnnt_sweep_kernel(
+__global__ __launch_bounds__(kRnntMaxCols) void rnnt_sweep_kernel(
     const float2 *__restrict__ lp_skew, const int32_t *__restrict__ llens,
     const int32_t *__restrict__ tlens, int Tmax, int U1max, int S,
     double *__restrict__ alpha_skew, double *__restrict__ beta_skew,
     double *__restrict__ ll_out, double *__restrict__ cost_ws, float *__restrict__ costs_out,
-    double *__restrict__ dump /* [2*B*512] scratch that absorbs the stores of idle lanes */)
+    double *__restrict__ dump /* [2*B*kRnntMaxCols] scratch that absorbs the stores of idle lanes */)
 {
     constexpr double NEG = (double)kNegInf;
-    __shared__ double xch[2][8];
+    __shared__ double xch[2][kRnntMaxCols / kWave];
     const int b = blockIdx.x;
     const bool backward = blockIdx.y != 0;
     const int u = threadIdx.x;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(512) void rnnt_sweep_kernel(
     const int col = in_row ? u : U1max - 1;
     const float2 *__restrict__ lp = lp_skew + (size_t)b * S * U1max + col;
     double *__restrict__ out = (backward ? beta_skew : alpha_skew) + (size_t)b * S * U1max + col;
-    double *__restrict__ sink = dump + ((size_t)b * 2 + (backward ? 1 : 0)) * 512 + u;
+    double *__restrict__ sink = dump + ((size_t)b * 2 + (backward ? 1 : 0)) * kRnntMaxCols + u;
 
     auto load_row = [&](int s) -> float2 {
         const int sc = s < 0 ? 0 : (s >= nsteps ? nsteps - 1 : s);
@@ -465,8 +465,8 @@ int check_shape(int B, int Tmax, int U1max, int V, int blank)
     WR_REQUIRE(B > 0 && Tmax > 0 && U1max > 0 && V > 0, WR_EINVAL,
                "rnnt: B, Tmax, U1max, V must be positive (got %d,%d,%d,%d)", B, Tmax, U1max, V);
     WR_REQUIRE(blank >= 0 && blank < V, WR_EINVAL, "rnnt: blank %d out of range [0,%d)", blank, V);
-    WR_REQUIRE(rnnt_cols_per_lane(U1max) <= 8, WR_EUNSUPPORTED,
-               "rnnt: U1max=%d exceeds the sweep kernel's limit of 512 label columns", U1max);
+    WR_REQUIRE(U1max <= kRnntMaxCols, WR_EUNSUPPORTED,
+               "rnnt: U1max=%d exceeds the sweep kernel's limit of %d label columns", U1max, kRnntMaxCols);
     WR_REQUIRE((long)B * Tmax * U1max < (1L << 31), WR_EUNSUPPORTED, "rnnt: more than 2^31 lattice cells");
     return WR_OK;
 }

@@ -54,6 +54,8 @@ int joint_bwd_dw_block(const float *gout_d, const float *h_d, const int32_t *lle
                        int U1, int J, int V, int max_parts, float *dw_d, float *db_d, float *part_dw, hipStream_t st);
 
 // ---- RNN-T loss workspace (rnnt_loss.hip; the joiner's fused row-statistics epilogue writes into it too) ----
+constexpr int kRnntMaxCols = 1024;      // lattice columns U+1: one lane per column in the sweep (16 waves)
+
 struct RnntWs {
     int K;            // label columns per lane in the sweep (lane l owns u = l, l+64, ...)
     int S;            // number of anti-diagonals per utterance
@@ -75,7 +77,7 @@ inline RnntWs rnnt_ws_layout(int B, int Tmax, int U1max)
     w.denom_off = off; off = align_up(off + (size_t)B * Tmax * U1max * sizeof(float), 256);
     w.ll_off = off;    off = align_up(off + (size_t)B * sizeof(double), 256);
     w.cost_off = off;  off = align_up(off + (size_t)B * sizeof(double), 256);
-    w.dump_off = off;  off = align_up(off + (size_t)B * 2 * 512 * sizeof(double), 256);
+    w.dump_off = off;  off = align_up(off + (size_t)B * 2 * kRnntMaxCols * sizeof(double), 256);
     w.flag_off = off;  off = align_up(off + 64, 256);   // "row statistics need the stand-alone pass" (joint_lse.hpp)
     w.total = off;
     return w;

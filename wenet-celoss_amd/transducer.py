@@ -41,12 +41,12 @@ def check_limits(text: torch.Tensor, text_lengths: torch.Tensor, with_ctc: bool)
     """Shape limits of the loss kernels (INTEGRATION.md "Shape limits"), checked on the padded label width before
     anything is launched, with a message that names the longest utterance.  No device sync unless a limit is hit."""
     width = int(text.shape[1])
-    limit = 255 if with_ctc else 511
+    limit = 511 if with_ctc else 1023
     if width <= limit:
         return
     i = int(text_lengths.argmax())
-    what = ("the CTC loss kernels take label sequences padded to at most 255" if with_ctc else
-            "the RNN-T loss kernels take at most 511 labels (U + 1 <= 512 lattice columns)")
+    what = ("the CTC loss kernels take label sequences padded to at most 511" if with_ctc else
+            "the RNN-T loss kernels take at most 1023 labels (U + 1 <= 1024 lattice columns)")
     raise RuntimeError(f"wenet_celoss_amd.Transducer: the label batch is padded to {width} (longest: utterance {i} with "
                        f"{int(text_lengths[i])} labels); {what} -- lower filter_conf.token_max_length")
 
