@@ -75,6 +75,30 @@ def test_fused_inplace_and_separate_gradient_buffers_agree(monkeypatch):
         assert torch.equal(a, b)
 
 
+def test_bucketing_by_label_length_keeps_costs_and_gradients():
+    """`buckets`: the batch cut into groups by label length, each its own joiner + loss call padded to its own maxima
+    (fused.plan_buckets).  Utterances are independent, so per-utterance costs are bit-identical and come back in the
+    caller's order; gradients agree to summation order."""
+    import wenet_celoss_amd as w_
+    from wenet_celoss_amd.fused import plan_buckets
+    B, T, U, J, V = 9, 60, 40, 32, 300
+    ep, pp, w, b, y, tl, ul = make(B, T, U, J, V, False, seed=21)
+    tl = torch.tensor([60, 33, 58, 41, 60, 25, 47, 52, 39], dtype=torch.int32, device=DEV)
+    ul = torch.tensor([40, 3, 17, 38, 9, 22, 40, 5, 30], dtype=torch.int32, device=DEV)
+    groups = plan_buckets(tl.tolist(), ul.tolist())
+    assert groups is not None and len(groups) >= 2 and sorted(i for g in groups for i in g) == list(range(B))
+    res = []
+    gc_w = torch.linspace(0.5, 1.5, B, device=DEV)
+    for nb in (1, 4):
+        leaves = [t.clone().requires_grad_(True) for t in (ep, pp, w, b)]
+        costs = w_.joint_rnnt_loss(*leaves, y, tl, ul, blank=0, reduction="none", buckets=nb)
+        (costs * gc_w).sum().backward()
+        res.append((costs.detach(), [t.grad for t in leaves]))
+    assert torch.equal(res[0][0], res[1][0])
+    for name, a, r in zip(("ep", "pp", "w", "b"), res[1][1], res[0][1]):
+        assert float((a - r).abs().max()) <= 1e-5 * float(r.abs().max()) + 1e-9, name
+
+
 def test_fused_workspace_matches_pass1():
     """The lattice the sweeps build from the epilogue's statistics equals the one built from rnnt_lse_kernel's."""
     import wenet_celoss_amd as w_

@@ -235,6 +235,30 @@ def test_bench_self_launch_names_the_missing_devices():
     assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
 
 
+def test_plan_buckets_properties():
+    """fused.plan_buckets: a partition of the batch in ascending label length that saves at least the stated share of
+    lattice cells, or None (uniform batches, tiny batches, savings below the bar)."""
+    import random
+    from wenet_celoss_amd.fused import plan_buckets
+    assert plan_buckets([1000] * 32, [150] * 32) is None            # BASELINE config: nothing to gain
+    assert plan_buckets([10], [5]) is None and plan_buckets([0, 0], [0, 0]) is None
+    rnd = random.Random(4)
+    for _ in range(20):
+        n = rnd.randint(2, 40)
+        t = [rnd.randint(50, 400) for _ in range(n)]
+        u = [rnd.randint(0, 120) for _ in range(n)]
+        g = plan_buckets(t, u, max_buckets=4, min_gain=0.08)
+        whole = n * max(t) * (max(u) + 1)
+        if g is None:
+            continue
+        assert 2 <= len(g) <= 4 and sorted(i for x in g for i in x) == list(range(n))
+        cells = sum(len(x) * max(t[i] for i in x) * (max(u[i] for i in x) + 1) for x in g)
+        assert cells <= 0.92 * whole
+        tops = [max(u[i] for i in x) for x in g]
+        assert tops == sorted(tops)                                  # groups in ascending label length
+        assert all(max(u[i] for i in g[k]) <= min(u[i] for i in g[k + 1]) for k in range(len(g) - 1))
+
+
 def test_transducer_constructor_contract():
     """Same keyword surface and weight-sum assertion as the reference (transducer.py:23-46)."""
     import wenet_celoss_amd as w

@@ -350,6 +350,11 @@ def bench_step(args):
     pred = torch.randn(B, U + 1, P, device=dev, requires_grad=True)
     y = torch.randint(1, V, (B, U), dtype=torch.int32, device=dev)
     ll = torch.full((B,), T, dtype=torch.int32, device=dev); tl = torch.full((B,), U, dtype=torch.int32, device=dev)
+    if args.ragged:                                    # utterances sorted by frames (processor.py:704), label counts spread
+        gcpu = torch.Generator().manual_seed(5)
+        ll = torch.sort(torch.randint(int(0.8 * T), T + 1, (B,), generator=gcpu), descending=True).values.to(torch.int32).to(dev)
+        tl = torch.randint(U // 3, U + 1, (B,), generator=gcpu).to(torch.int32).to(dev)
+        ll[0], tl[-1] = T, U
     base = None
     precs = ("fp32", "fp32-fused", "bf16x3", "bf16x3-fused", "bf16-autocast")
     if args.only:
@@ -369,15 +374,17 @@ def bench_step(args):
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
                 if fused:
                     loss = w.joint_rnnt_loss(joint.enc_ffn(enc), joint.pred_ffn(pred), joint.ffn_out.weight,
-                                             joint.ffn_out.bias, y, ll, tl, blank=0, reduction="mean", precision=jprec)
+                                             joint.ffn_out.bias, y, ll, tl, blank=0, reduction="mean", precision=jprec,
+                                             buckets=args.buckets)
                 else:
-                    logits = joint(enc, pred)
+                    logits = joint(enc, pred, ll, tl) if args.ragged else joint(enc, pred)
                     loss = w.rnnt_loss(logits, y, ll, tl, blank=0, reduction="mean", inplace_grad=True)
             loss.backward()
             return loss
         loss = step()
         ms = timeit(step, args.steps)
         rec = {"what": "joint+rnnt_loss fwd+bwd (autograd)", "precision": prec, "shape": [B, T, U + 1, J, V],
+               "ragged": bool(args.ragged), "buckets": args.buckets if fused else None,
                "ms": round(ms, 2), "utt_per_s": round(B / ms * 1e3, 1), "loss": float(loss)}
         if base is None:
             base = (float(loss), enc.grad.clone(), joint.ffn_out.weight.grad.clone())
@@ -403,6 +410,8 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--dw", action="store_true")
     ap.add_argument("--fwd-only", action="store_true", help="joint: stop after the exact forward sweep")
+    ap.add_argument("--ragged", action="store_true", help="step: frames in [0.8 T, T] sorted, labels in [U/3, U]")
+    ap.add_argument("--buckets", type=int, default=4, help="step: label-length groups of the fused node (1 = off)")
     ap.add_argument("--only", default="", help="step: comma-separated subset of the configurations")
     ap.add_argument("--streams", type=int, default=64, help="greedy: independent streams decoded together")
     ap.add_argument("--tile", type=int, default=0, help="lane-GEMM tile policy of the decoders (wr_tune_set key 6)")

@@ -86,14 +86,63 @@ class _JointRnntFn(torch.autograd.Function):
         return d_ep, d_pp, d_w, d_b, None, None, None, None, None, None
 
 
+def plan_buckets(t_lens, u_lens, max_buckets: int = 4, min_gain: float = 0.08):
+    """Group utterances by label length so that each group is padded to its own maxima.
+
+    The joiner kernels skip 64- / 256-cell tiles that lie wholly in padding, which removes the frames beyond an
+    utterance's length (runs of U+1 cells) but not the label positions beyond its label count (short runs inside every
+    frame): their cost is B * T * (Umax + 1) whatever the individual label counts are.  Sorting the batch by label count
+    and cutting it into a few groups, each a joiner + loss call of its own padded to ITS longest label sequence (and
+    frame count), removes most of that padding; per-utterance costs and gradients do not change (utterances are
+    independent; the weight gradient is the sum over the groups).
+
+    Returns a list of index lists (ascending label length), or None when one call is best: dynamic programming over the
+    sorted order with cost sum_g n_g * maxT_g * (maxU_g + 1), at most `max_buckets` groups, and the split must save at
+    least `min_gain` of the cells."""
+    n = len(t_lens)
+    order = sorted(range(n), key=lambda i: (u_lens[i], t_lens[i]))
+    whole = n * max(t_lens) * (max(u_lens) + 1)
+    if n < 2 or whole == 0:
+        return None
+    us = [u_lens[i] for i in order]
+    ts = [t_lens[i] for i in order]
+
+    def cost(a, b):                      # group of sorted positions [a, b)
+        return (b - a) * max(ts[a:b]) * (us[b - 1] + 1)
+    INF = float("inf")
+    best = [[INF] * (n + 1) for _ in range(max_buckets + 1)]
+    cut = [[0] * (n + 1) for _ in range(max_buckets + 1)]
+    best[0][0] = 0
+    for g in range(1, max_buckets + 1):
+        for b in range(1, n + 1):
+            for a in range(g - 1, b):
+                if best[g - 1][a] == INF:
+                    continue
+                c = best[g - 1][a] + cost(a, b)
+                if c < best[g][b]:
+                    best[g][b], cut[g][b] = c, a
+    g_best = min(range(1, max_buckets + 1), key=lambda g: best[g][n])
+    if g_best == 1 or best[g_best][n] > (1.0 - min_gain) * whole:
+        return None
+    groups, b = [], n
+    for g in range(g_best, 0, -1):
+        a = cut[g][b]
+        groups.append(order[a:b])
+        b = a
+    return groups[::-1]
+
+
 def joint_rnnt_loss(ep: torch.Tensor, pp: torch.Tensor, w_out: torch.Tensor, b_out: torch.Tensor,
                     targets: torch.Tensor, logit_lengths: torch.Tensor, target_lengths: torch.Tensor, blank: int = 0,
-                    clamp: float = -1.0, reduction: str = "mean", precision: Optional[str] = None) -> torch.Tensor:
+                    clamp: float = -1.0, reduction: str = "mean", precision: Optional[str] = None,
+                    buckets: Optional[int] = None) -> torch.Tensor:
     """rnnt_loss(ffn_out(tanh(ep[:, :, None] + pp[:, None])), targets, logit_lengths, target_lengths) without the
     logits ever leaving the node.  ep (B, T, J) = enc_ffn(encoder_out), pp (B, U+1, J) = pred_ffn(predictor_out);
     targets (B, U) int32 with padding already mapped to a valid class; lengths (B,) int32; requires
     max(logit_lengths) == T and max(target_lengths) + 1 == U+1 like torchaudio's rnnt_loss.
-    ``precision``: "fp32" (exact MFMA, default) or "bf16x3" (split precision, joint.py); reduction as rnnt_loss."""
+    ``precision``: "fp32" (exact MFMA, default) or "bf16x3" (split precision, joint.py); reduction as rnnt_loss.
+    ``buckets``: at most this many groups by label length, each padded to its own maxima (`plan_buckets`; default from
+    WR_FUSED_BUCKETS, 4; 1 = one call for the whole batch).  Costs come back in the caller's utterance order."""
     if reduction not in ("none", "mean", "sum"):
         raise ValueError("reduction should be one of 'none', 'mean', or 'sum'")
     precision = _resolve_precision(precision)
@@ -119,7 +168,23 @@ def joint_rnnt_loss(ep: torch.Tensor, pp: torch.Tensor, w_out: torch.Tensor, b_o
         raise RuntimeError("output length mismatch")
     if int(lens.min()) < 0:
         raise RuntimeError("lengths must be non-negative")
-    costs = _JointRnntFn.apply(ep, pp, w_out, b_out, tg, ll, tl, int(blank), float(clamp), _PRECISIONS[precision])
+    if buckets is None:
+        buckets = int(os.environ.get("WR_FUSED_BUCKETS", "4"))
+    groups = plan_buckets(lens[0].tolist(), lens[1].tolist(), max_buckets=buckets) if buckets > 1 else None
+    terms = _PRECISIONS[precision]
+    if groups is None:
+        costs = _JointRnntFn.apply(ep, pp, w_out, b_out, tg, ll, tl, int(blank), float(clamp), terms)
+    else:
+        costs = torch.empty(B, dtype=torch.float32, device=dev)
+        parts, index = [], []
+        for g in groups:
+            idx = torch.tensor(g, device=dev)
+            tg_max, ug_max = int(lens[0][g].max()), int(lens[1][g].max())
+            parts.append(_JointRnntFn.apply(ep[idx, :tg_max], pp[idx, :ug_max + 1], w_out, b_out,
+                                            tg[idx, :ug_max].contiguous(), ll[idx].contiguous(), tl[idx].contiguous(),
+                                            int(blank), float(clamp), terms))
+            index.append(idx)
+        costs = torch.cat(parts)[torch.argsort(torch.cat(index))]      # back to the caller's order (differentiable)
     if reduction == "mean":
         return costs.mean()
     if reduction == "sum":
