@@ -86,7 +86,7 @@ def test_bucketing_by_label_length_keeps_costs_and_gradients():
     tl = torch.tensor([60, 33, 58, 41, 60, 25, 47, 52, 39], dtype=torch.int32, device=DEV)
     ul = torch.tensor([40, 3, 17, 38, 9, 22, 40, 5, 30], dtype=torch.int32, device=DEV)
     groups = plan_buckets(tl.tolist(), ul.tolist())
-    assert groups is not None and len(groups) >= 2 and sorted(i for g in groups for i in g) == list(range(B))
+    assert 9 * 60 * 41 >= 20000 and groups is not None and len(groups) >= 2 and sorted(i for g in groups for i in g) == list(range(B))
     res = []
     gc_w = torch.linspace(0.5, 1.5, B, device=DEV)
     for nb in (1, 4):

@@ -242,12 +242,14 @@ def test_plan_buckets_properties():
     from wenet_celoss_amd.fused import plan_buckets
     assert plan_buckets([1000] * 32, [150] * 32) is None            # BASELINE config: nothing to gain
     assert plan_buckets([10], [5]) is None and plan_buckets([0, 0], [0, 0]) is None
+    assert plan_buckets([30, 30, 30], [2, 9, 20]) is None           # a rescoring n-best: too small to split
+    assert plan_buckets([30, 30, 30], [2, 9, 20], min_cells=0) is not None
     rnd = random.Random(4)
     for _ in range(20):
         n = rnd.randint(2, 40)
         t = [rnd.randint(50, 400) for _ in range(n)]
         u = [rnd.randint(0, 120) for _ in range(n)]
-        g = plan_buckets(t, u, max_buckets=4, min_gain=0.08)
+        g = plan_buckets(t, u, max_buckets=4, min_gain=0.08, min_cells=0)
         whole = n * max(t) * (max(u) + 1)
         if g is None:
             continue

@@ -86,7 +86,7 @@ class _JointRnntFn(torch.autograd.Function):
         return d_ep, d_pp, d_w, d_b, None, None, None, None, None, None
 
 
-def plan_buckets(t_lens, u_lens, max_buckets: int = 4, min_gain: float = 0.08):
+def plan_buckets(t_lens, u_lens, max_buckets: int = 4, min_gain: float = 0.08, min_cells: int = 20000):
     """Group utterances by label length so that each group is padded to its own maxima.
 
     The joiner kernels skip 64- / 256-cell tiles that lie wholly in padding, which removes the frames beyond an
@@ -98,11 +98,12 @@ def plan_buckets(t_lens, u_lens, max_buckets: int = 4, min_gain: float = 0.08):
 
     Returns a list of index lists (ascending label length), or None when one call is best: dynamic programming over the
     sorted order with cost sum_g n_g * maxT_g * (maxU_g + 1), at most `max_buckets` groups, and the split must save at
-    least `min_gain` of the cells."""
+    least `min_gain` of the cells; batches of fewer than `min_cells` lattice cells (a couple of milliseconds of joiner
+    work, e.g. the n-best list of a rescoring call) are not worth the extra launches."""
     n = len(t_lens)
     order = sorted(range(n), key=lambda i: (u_lens[i], t_lens[i]))
     whole = n * max(t_lens) * (max(u_lens) + 1)
-    if n < 2 or whole == 0:
+    if n < 2 or whole < max(min_cells, 1):
         return None
     us = [u_lens[i] for i in order]
     ts = [t_lens[i] for i in order]
