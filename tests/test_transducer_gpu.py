@@ -364,3 +364,36 @@ def test_two_rank_ddp_training_step_on_the_product_path(tmp_path):
         want = e0[n] / 2                                  # join() divides by the initial world size
         assert float((got[0]["extra"][n] - want).abs().max()) <= 1e-5 * float(want.abs().max()) + 1e-9, n
     assert "extra" not in got[1]
+
+
+def test_amp_two_op_path_buckets_ragged_batches(monkeypatch):
+    """The --use_amp configuration (joiner precision "bf16" under autocast: 16-bit logits, two ops) cuts a ragged batch
+    into label-length groups as the fused node does; loss and gradients equal the one-call path to summation order."""
+    import wenet_celoss_amd as w
+    torch.manual_seed(3)
+    V, E, P, J, H = 40, 12, 10, 16, 14
+    m = w.Transducer(V, 0, TinyEncoder(8, E), w.RNNPredictor(V, P, P, 0.0, H, 2, dropout=0.0),
+                     w.TransducerJoint(V, E, P, J, precision="bf16"), ctc=None, ctc_weight=0.0, transducer_weight=1.0,
+                     hw_weight=0.0).to(DEV)
+    B, Tin, U = 10, 70, 36
+    g = torch.Generator().manual_seed(8)
+    speech = torch.randn(B, Tin, 8, generator=g).to(DEV)
+    slen = torch.tensor([70, 70, 68, 66, 66, 64, 60, 60, 58, 56], dtype=torch.int32, device=DEV)
+    tlen = torch.tensor([36, 4, 30, 9, 36, 12, 3, 25, 7, 33], dtype=torch.int32, device=DEV)
+    text = torch.randint(1, V, (B, U), generator=g)
+    for i in range(B):
+        text[i, int(tlen[i]):] = -1
+    text = text.to(DEV)
+    res = {}
+    for nb in ("1", "4"):
+        monkeypatch.setenv("WR_FUSED_BUCKETS", nb)
+        m.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = m(speech, slen, text, tlen)
+        out["loss"].float().backward()
+        res[nb] = (out["loss_rnnt"].item(), {n: p.grad.clone() for n, p in m.named_parameters()})
+    # per-utterance costs come back in bfloat16 in both; the one-call path also takes their mean in bfloat16 (ulp = 2 at
+    # this magnitude), the grouped path in float32
+    assert res["4"][0] == pytest.approx(res["1"][0], rel=1e-2)
+    for n, gr in res["1"][1].items():
+        assert float((res["4"][1][n].float() - gr.float()).abs().max()) <= 2e-2 * float(gr.float().abs().max()) + 1e-7, n

@@ -30,7 +30,7 @@ from torch.nn.utils.rnn import pad_sequence
 
 from .common import IGNORE_ID, LabelSmoothingLoss, add_blank, add_sos_eos, end_blank, reverse_pad_list
 from .decoder import DecoderCache
-from .fused import joint_rnnt_loss
+from .fused import joint_rnnt_loss, plan_buckets
 from .joint import TransducerJoint, _resolve_precision
 from .rnnt_loss import rnnt_loss
 from .search.greedy_search import basic_greedy_search, basic_greedy_search_both, basic_greedy_search_hw
@@ -110,6 +110,23 @@ class Transducer(nn.Module):
                                    rnnt_text, encoder_out_lens, rnnt_text_lengths, blank=self.blank, reduction="mean",
                                    precision=jt.precision)
             return None, loss
+        if self.fused_loss and isinstance(self.joint, TransducerJoint):
+            # the AMP single-term joiner keeps 16-bit logits (two ops), but a ragged batch is still cut into
+            # label-length groups, each padded to its own maxima (fused.plan_buckets): same costs, fewer padded cells
+            lens = torch.stack([encoder_out_lens, rnnt_text_lengths]).cpu()
+            groups = plan_buckets(lens[0].tolist(), lens[1].tolist(), max_buckets=int(os.environ.get("WR_FUSED_BUCKETS", "4")))
+            if groups is not None:
+                dev = encoder_out.device
+                parts, index = [], []
+                for g in groups:
+                    idx = torch.tensor(g, device=dev)
+                    tg, ug = int(lens[0][g].max()), int(lens[1][g].max())
+                    ll, tl = encoder_out_lens[idx].contiguous(), rnnt_text_lengths[idx].contiguous()
+                    logits = self.joint(encoder_out[idx, :tg], predictor_out[idx, :ug + 1], ll, tl)
+                    parts.append(rnnt_loss(logits, rnnt_text[idx, :ug].contiguous(), ll, tl, blank=self.blank, reduction="none",
+                                           inplace_grad=True))
+                    index.append(idx)
+                return None, torch.cat(parts).float().mean()
         if skip_padding:
             joint_out = self.joint(encoder_out, predictor_out, encoder_out_lens, rnnt_text_lengths)
         else:
