@@ -21,6 +21,9 @@ for modules that are absent from the image -- `typeguard`, used only for
                                       exports, :541-606)             -> greedy_stream_*.npz
                                       (module-level imports of `torchaudio` and `k2.rnnt_loss` are satisfied by empty
                                       in-process stubs; the two methods touch neither)
+  wenet/transducer/transducer.py      Transducer.forward / beam_search / transducer_attention_rescoring / greedy_search
+                                      through the reference's own class (torchaudio.functional.rnnt_loss stubbed with
+                                      this repo's float64 oracle)    -> transducer_wrappers.npz
   wenet/transformer/context_bias.py   ContextBias (the real module) driven by
   wenet/transducer/search/greedy_search.py  basic_greedy_search_both -> greedy_both_real_*.npz
 torchaudio.functional.rnnt_loss cannot be imported (torchaudio is absent), so no
@@ -618,6 +621,101 @@ def gen_greedy_both_real():
              **{"cb_" + k: v for k, v in sd(cb).items()})
 
 
+def gen_transducer_wrappers():
+    """The reference's own `Transducer` class (wenet/transducer/transducer.py:20-629), instantiated around stand-in
+    encoder / attention-decoder modules (tests/test_transducer_gpu.py: TinyEncoder, TinyAttnDecoder) and the reference's
+    own RNNPredictor, TransducerJoint, CTC and ContextBias, and driven through `forward` (:79-270), `beam_search`
+    (:332-377), `transducer_attention_rescoring` (:379-513, both beam_search_type branches, with and without the
+    right-to-left decoder) and `greedy_search` (:515-598).  The module imports torchaudio (:4), which the image lacks: an
+    in-process stub provides `torchaudio.functional.rnnt_loss` from THIS repo's float64 oracle (oracle/rnnt_oracle.c),
+    so the RNN-T numbers inside these fixtures are the oracle's (that leg stays "parity unpinned"); everything around
+    them -- label preparation, the loss dictionary and its weights, hot-word loss, n-best padding, score combination,
+    arg-max -- is the reference's own code."""
+    root = os.path.dirname(os.path.dirname(HERE))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import oracle
+    from test_transducer_gpu import TinyAttnDecoder, TinyEncoder
+
+    def rnnt_loss(logits, targets, logit_lengths, target_lengths, blank=-1, clamp=-1, reduction="mean"):
+        c, _ = oracle.rnnt_loss_f64(logits.detach().float().numpy(), targets.numpy().astype(np.int32),
+                                    logit_lengths.numpy().astype(np.int32), target_lengths.numpy().astype(np.int32),
+                                    blank=blank if blank >= 0 else logits.shape[-1] + blank)
+        c = torch.tensor(c, dtype=torch.float32)
+        return c.mean() if reduction == "mean" else c.sum() if reduction == "sum" else c
+    ta = sys.modules.setdefault("torchaudio", types.ModuleType("torchaudio"))
+    ta.functional = types.ModuleType("torchaudio.functional")
+    ta.functional.rnnt_loss = rnnt_loss
+    sys.modules["torchaudio.functional"] = ta.functional
+    from wenet.transducer.transducer import Transducer
+    from wenet.transducer.joint import TransducerJoint
+    from wenet.transducer.predictor import RNNPredictor
+    from wenet.transformer.context_bias import ContextBias
+    from wenet.transformer.ctc import CTC
+    V, D, J, H, HW = 23, 12, 16, 14, 8
+    torch.manual_seed(41)
+    enc = TinyEncoder(8, D)
+    pred = RNNPredictor(V, D, D, 0.0, H, 2, dropout=0.0)
+    joint = TransducerJoint(V, D, D, J)
+    ctc = CTC(V, D)
+    dec = TinyAttnDecoder(V, D)
+    cb = ContextBias(input_size=D, output_size=D, vocab_size=V, embedding_size=D, num_layers=1, attention_heads=2,
+                     bias_encoder_type="linear", context_extractor="BLSTM", unified_hw_odim=HW, unified_hw_heads=2)
+    m = Transducer(V, 0, enc, pred, joint, attention_decoder=dec, ctc=ctc, context_bias=cb, ctc_weight=0.1,
+                   transducer_weight=0.75, attention_weight=0.15, reverse_weight=0.3, lsm_weight=0.1, hw_weight=0.4,
+                   loss_mode="both").eval()
+    with torch.no_grad():
+        m.joint.ffn_out.weight *= 5
+        m.joint.ffn_out.bias[0] += 1.5
+        m.ctc.ctc_lo.weight *= 5
+        m.ctc.ctc_lo.bias[0] += 1.0
+    g = torch.Generator().manual_seed(42)
+    out = {}
+    # ---- forward (the loss dictionary)
+    B, Tin, U = 3, 13, 4
+    speech = torch.randn(B, Tin, 8, generator=g)
+    slen = torch.tensor([13, 9, 11], dtype=torch.int32)
+    text = torch.tensor([[3, 5, 2, 9], [4, 4, -1, -1], [7, 1, 6, -1]])
+    tlen = torch.tensor([4, 2, 3], dtype=torch.int32)
+    ctx = torch.tensor([[0, -1, -1], [3, 5, -1], [7, 1, 6]])
+    ctx_len = torch.tensor([1, 2, 3], dtype=torch.int32)
+    hw_label = torch.tensor([[1, 1, 0, 0], [0, 0, -1, -1], [1, 1, 1, -1]])
+    with torch.no_grad():
+        res = m(speech, slen, text, tlen, ctx, ctx_len, hw_label)
+    out.update(fwd_speech=speech.numpy(), fwd_slen=slen.numpy(), fwd_text=text.numpy(), fwd_tlen=tlen.numpy(),
+               fwd_ctx=ctx.numpy(), fwd_ctx_len=ctx_len.numpy(), fwd_hw_label=hw_label.numpy(),
+               **{"fwd_" + k: np.array(float(v)) for k, v in res.items()})
+    print("  forward dict:", {k: round(float(v), 5) for k, v in res.items()})
+    # ---- decode wrappers (batch 1)
+    Td = 26
+    sp1 = torch.randn(1, Td, 8, generator=g)
+    sl1 = torch.tensor([Td], dtype=torch.int32)
+    out.update(dec_speech=sp1.numpy())
+    with torch.no_grad():
+        hyp, score = m.beam_search(sp1, sl1, beam_size=4, ctc_weight=0.3, transducer_weight=0.7)
+        out.update(beam_hyp=np.array(hyp, np.int64), beam_score=np.array(float(score)))
+        print("  beam_search:", hyp, float(score))
+        k = 0
+        for typ in ("transducer", "ctc"):
+            for rw in (0.0, 0.3):
+                h, s = m.transducer_attention_rescoring(sp1, sl1, 4, reverse_weight=rw, ctc_weight=0.2, attn_weight=0.3,
+                                                        transducer_weight=0.5, search_ctc_weight=0.3,
+                                                        search_transducer_weight=0.7, beam_search_type=typ)
+                out[f"resc_{k}_type"] = np.array(typ); out[f"resc_{k}_rw"] = np.array(rw)
+                out[f"resc_{k}_hyp"] = np.array(list(h), np.int64); out[f"resc_{k}_score"] = np.array(float(s))
+                print(f"  rescoring {typ} rw={rw}:", list(h), float(s))
+                k += 1
+        out["n_resc"] = np.array(k)
+        labels = torch.randint(0, 2, (1, 8), generator=g)
+        with contextlib.redirect_stdout(io.StringIO()):
+            gh, gd = m.greedy_search(sp1, sl1, n_steps=4, context_list=ctx, context_lengths=ctx_len,
+                                     context_filter_state="on", context_decoder_labels_padded=labels)
+        out.update(greedy_hyp=np.array(gh[0], np.int64), greedy_dist=np.array(float(gd)), greedy_labels=labels.numpy())
+        print("  greedy_search:", gh, gd)
+    save("transducer_wrappers", **out, **{"m_" + k: v for k, v in sd(m).items()}, heads=np.array(2), hw_dim=np.array(HW),
+         hw_heads=np.array(2))
+
+
 def gen_common():
     from wenet.utils.common import add_blank, log_add
     ys = torch.tensor([[1, 2, 3, 4, 5], [4, 5, 6, -1, -1], [7, 8, 9, -1, -1]])
@@ -651,3 +749,4 @@ if __name__ == "__main__":
     gen_greedy_fork()
     gen_greedy_stream()
     gen_greedy_both_real()
+    gen_transducer_wrappers()

@@ -397,3 +397,49 @@ def test_amp_two_op_path_buckets_ragged_batches(monkeypatch):
     assert res["4"][0] == pytest.approx(res["1"][0], rel=1e-2)
     for n, gr in res["1"][1].items():
         assert float((res["4"][1][n].float() - gr.float()).abs().max()) <= 2e-2 * float(gr.float().abs().max()) + 1e-7, n
+
+
+def test_wrappers_match_the_reference_class():
+    """tests/golden/transducer_wrappers.npz was produced by the reference's OWN `Transducer` class
+    (wenet/transducer/transducer.py) around the stand-in encoder / attention decoder of this file and the reference's
+    predictor, joiner, CTC and ContextBias (make_golden.py::gen_transducer_wrappers; its torchaudio.functional.rnnt_loss
+    was stubbed with the float64 oracle).  Same weights here: the loss dictionary of `forward` (all five entries),
+    `beam_search`, `transducer_attention_rescoring` (both search types, with / without the right-to-left decoder) and
+    `greedy_search` with the hot-word module reproduce what the reference class returned."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from conftest import GOLDEN
+    from context_bias_mirror import ContextBiasMirror
+    import wenet_celoss_amd as w
+    d = np.load(os.path.join(GOLDEN, "transducer_wrappers.npz"))
+    sd = {k[2:]: torch.tensor(d[k]) for k in d.files if k.startswith("m_")}
+    V, D = sd["predictor.embed.weight"].shape
+    J, H = sd["joint.enc_ffn.weight"].shape[0], sd["predictor.rnn.weight_hh_l0"].shape[1]
+    cb = ContextBiasMirror(V, D, layers=1, heads=int(d["heads"]), hw_dim=int(d["hw_dim"]), hw_heads=int(d["hw_heads"]))
+    m = w.Transducer(V, 0, TinyEncoder(8, D), w.RNNPredictor(V, D, D, 0.0, H, 2, dropout=0.0), w.TransducerJoint(V, D, D, J),
+                     attention_decoder=TinyAttnDecoder(V, D), ctc=w.CTC(V, D), context_bias=cb, ctc_weight=0.1,
+                     transducer_weight=0.75, attention_weight=0.15, reverse_weight=0.3, lsm_weight=0.1, hw_weight=0.4,
+                     loss_mode="both")
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not missing, missing                 # (the reference ContextBias has layers the decode / loss path never uses)
+    m = m.to(DEV).eval()
+    T = lambda k, dt=None: torch.tensor(d[k]).to(DEV) if dt is None else torch.tensor(d[k]).to(dt).to(DEV)
+    with torch.no_grad():
+        out = m(T("fwd_speech"), T("fwd_slen"), T("fwd_text"), T("fwd_tlen"), torch.tensor(d["fwd_ctx"]),
+                torch.tensor(d["fwd_ctx_len"]), T("fwd_hw_label"))
+    for k in ("loss", "loss_att", "loss_ctc", "loss_rnnt", "hw_loss"):
+        assert out[k].item() == pytest.approx(float(d["fwd_" + k]), rel=2e-5), k
+    sp, sl = T("dec_speech"), torch.tensor([d["dec_speech"].shape[1]], dtype=torch.int32, device=DEV)
+    with torch.no_grad():
+        hyp, score = m.beam_search(sp, sl, beam_size=4, ctc_weight=0.3, transducer_weight=0.7)
+        assert list(hyp) == d["beam_hyp"].tolist() and float(score) == pytest.approx(float(d["beam_score"]), rel=1e-5)
+        for k in range(int(d["n_resc"])):
+            h, s = m.transducer_attention_rescoring(sp, sl, 4, reverse_weight=float(d[f"resc_{k}_rw"]), ctc_weight=0.2,
+                                                    attn_weight=0.3, transducer_weight=0.5, search_ctc_weight=0.3,
+                                                    search_transducer_weight=0.7, beam_search_type=str(d[f"resc_{k}_type"]))
+            assert list(h) == d[f"resc_{k}_hyp"].tolist(), k
+            assert float(s) == pytest.approx(float(d[f"resc_{k}_score"]), rel=1e-4), k
+        gh, gd = m.greedy_search(sp, sl, n_steps=4, context_list=torch.tensor(d["fwd_ctx"]),
+                                 context_lengths=torch.tensor(d["fwd_ctx_len"]), context_filter_state="on",
+                                 context_decoder_labels_padded=torch.tensor(d["greedy_labels"]))
+    assert gh == [d["greedy_hyp"].tolist()] and gd == float(d["greedy_dist"])
