@@ -637,11 +637,21 @@ def gen_transducer_wrappers():
     import oracle
     from test_transducer_gpu import TinyAttnDecoder, TinyEncoder
 
+    class OracleRnnt(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, logits, targets, logit_lengths, target_lengths, blank):
+            c, gr = oracle.rnnt_loss_f64(logits.detach().float().numpy(), targets.numpy().astype(np.int32),
+                                         logit_lengths.numpy().astype(np.int32), target_lengths.numpy().astype(np.int32),
+                                         blank=blank)
+            ctx.save_for_backward(torch.tensor(gr, dtype=torch.float32))
+            return torch.tensor(c, dtype=torch.float32)
+
+        @staticmethod
+        def backward(ctx, g):
+            return ctx.saved_tensors[0] * g[:, None, None, None], None, None, None, None
+
     def rnnt_loss(logits, targets, logit_lengths, target_lengths, blank=-1, clamp=-1, reduction="mean"):
-        c, _ = oracle.rnnt_loss_f64(logits.detach().float().numpy(), targets.numpy().astype(np.int32),
-                                    logit_lengths.numpy().astype(np.int32), target_lengths.numpy().astype(np.int32),
-                                    blank=blank if blank >= 0 else logits.shape[-1] + blank)
-        c = torch.tensor(c, dtype=torch.float32)
+        c = OracleRnnt.apply(logits, targets, logit_lengths, target_lengths, blank if blank >= 0 else logits.shape[-1] + blank)
         return c.mean() if reduction == "mean" else c.sum() if reduction == "sum" else c
     ta = sys.modules.setdefault("torchaudio", types.ModuleType("torchaudio"))
     ta.functional = types.ModuleType("torchaudio.functional")
@@ -680,8 +690,10 @@ def gen_transducer_wrappers():
     ctx = torch.tensor([[0, -1, -1], [3, 5, -1], [7, 1, 6]])
     ctx_len = torch.tensor([1, 2, 3], dtype=torch.int32)
     hw_label = torch.tensor([[1, 1, 0, 0], [0, 0, -1, -1], [1, 1, 1, -1]])
-    with torch.no_grad():
-        res = m(speech, slen, text, tlen, ctx, ctx_len, hw_label)
+    res = m(speech, slen, text, tlen, ctx, ctx_len, hw_label)
+    res["loss"].backward()                 # the reference's own autograd graph (RNN-T gradient from the oracle stub)
+    out.update({"grad_" + k: p.grad.numpy().copy() for k, p in m.named_parameters() if p.grad is not None})
+    res = {k: v.detach() for k, v in res.items()}
     out.update(fwd_speech=speech.numpy(), fwd_slen=slen.numpy(), fwd_text=text.numpy(), fwd_tlen=tlen.numpy(),
                fwd_ctx=ctx.numpy(), fwd_ctx_len=ctx_len.numpy(), fwd_hw_label=hw_label.numpy(),
                **{"fwd_" + k: np.array(float(v)) for k, v in res.items()})

@@ -422,13 +422,28 @@ def test_wrappers_match_the_reference_class():
                      loss_mode="both")
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert not missing, missing                 # (the reference ContextBias has layers the decode / loss path never uses)
-    m = m.to(DEV).eval()
+    m = m.to(DEV).train()          # MIOpen's LSTM backward needs training mode; every dropout in this model is 0
     T = lambda k, dt=None: torch.tensor(d[k]).to(DEV) if dt is None else torch.tensor(d[k]).to(dt).to(DEV)
-    with torch.no_grad():
-        out = m(T("fwd_speech"), T("fwd_slen"), T("fwd_text"), T("fwd_tlen"), torch.tensor(d["fwd_ctx"]),
-                torch.tensor(d["fwd_ctx_len"]), T("fwd_hw_label"))
+    out = m(T("fwd_speech"), T("fwd_slen"), T("fwd_text"), T("fwd_tlen"), torch.tensor(d["fwd_ctx"]),
+            torch.tensor(d["fwd_ctx_len"]), T("fwd_hw_label"))
     for k in ("loss", "loss_att", "loss_ctc", "loss_rnnt", "hw_loss"):
         assert out[k].item() == pytest.approx(float(d["fwd_" + k]), rel=2e-5), k
+    # ... and loss.backward() through the reference class's autograd graph gave these parameter gradients
+    out["loss"].backward()
+    checked = 0
+    top = max(float(np.abs(d[k]).max()) for k in d.files if k.startswith("grad_"))
+    for n, p in m.named_parameters():
+        if "grad_" + n not in d.files:
+            continue
+        ref = torch.tensor(d["grad_" + n])
+        assert p.grad is not None, n
+        # 1e-4 of the tensor's largest entry; biases in front of a LayerNorm have a zero gradient up to rounding noise,
+        # hence the floor at 1e-6 of the model's largest gradient entry
+        assert float((p.grad.cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-6 * top, n
+        checked += 1
+    assert checked >= 40
+    m.zero_grad()
+    m.eval()
     sp, sl = T("dec_speech"), torch.tensor([d["dec_speech"].shape[1]], dtype=torch.int32, device=DEV)
     with torch.no_grad():
         hyp, score = m.beam_search(sp, sl, beam_size=4, ctc_weight=0.3, transducer_weight=0.7)
