@@ -36,6 +36,9 @@ extern "C" {
 #define WR_API_VERSION 1
 
 enum wr_dtype { WR_F32 = 0, WR_F16 = 1, WR_BF16 = 2 };
+/* joiner activation (TransducerJoint(activation=...), wenet/transducer/joint.py:25 -> wenet/utils/common.py:228-242);
+ * "tanh" is the shipped configuration, "swish" is torch.nn.SiLU, "gelu" the erf form (torch.nn.GELU default) */
+enum wr_activation { WR_ACT_TANH = 0, WR_ACT_RELU = 1, WR_ACT_HARDTANH = 2, WR_ACT_SELU = 3, WR_ACT_SWISH = 4, WR_ACT_GELU = 5 };
 
 enum wr_status {
     WR_OK = 0,
@@ -154,7 +157,8 @@ int wr_ctc_loss_bwd(const void *logits_d, int dtype,
  * Replaces TransducerJoint.forward, wenet/transducer/joint.py:45-70, from the
  * point where the two pre-join projections exist:
  *   ep = enc_ffn(enc) [B, T, J],  pp = pred_ffn(pred) [B, U1, J]   (joint.py:55-58)
- *   out[b,t,u,:] = ffn_out(tanh(ep[b,t,:] + pp[b,u,:]))             (joint.py:60-69)
+ *   out[b,t,u,:] = ffn_out(act(ep[b,t,:] + pp[b,u,:]))              (joint.py:60-69)
+ * `activation` is a wr_activation code (tanh in the shipped configuration; the text below writes tanh for it).
  * w_out [V, J] and b_out [V] are ffn_out.weight / .bias in nn.Linear layout.
  * fp32 throughout (exact-fp32 MFMA).  J a multiple of 4, at most 512.
  * The activation tensor tanh(ep+pp) [B,T,U1,J] is never written to HBM in the
@@ -171,7 +175,7 @@ size_t wr_joint_workspace_bytes(int J, int V);
 
 int wr_joint_fwd(const float *ep_d, const float *pp_d, const float *w_out_d, const float *b_out_d,
                  const int32_t *logit_lengths_d /* nullable */, const int32_t *target_lengths_d /* nullable */,
-                 int B, int T, int U1, int J, int V,
+                 int B, int T, int U1, int J, int V, int activation,
                  float *out_d /* [B,T,U1,V] */,
                  void *workspace_d, size_t workspace_bytes, void *stream);
 
@@ -182,7 +186,7 @@ int wr_joint_fwd(const float *ep_d, const float *pp_d, const float *w_out_d, con
  * arrays are required; targets [B, U1-1] as for wr_rnnt_loss_fwd. */
 int wr_joint_fwd_lse(const float *ep_d, const float *pp_d, const float *w_out_d, const float *b_out_d,
                      const int32_t *logit_lengths_d, const int32_t *target_lengths_d, const int32_t *targets_d,
-                     int B, int T, int U1, int J, int V, int blank,
+                     int B, int T, int U1, int J, int V, int activation, int blank,
                      float *out_d /* [B,T,U1,V] */,
                      void *workspace_d, size_t workspace_bytes,
                      void *rnnt_workspace_d, size_t rnnt_workspace_bytes, void *stream);
@@ -190,7 +194,7 @@ int wr_joint_fwd_lse(const float *ep_d, const float *pp_d, const float *w_out_d,
 int wr_joint_bwd_dz(const float *gout_d /* [B,T,U1,V] */, const float *ep_d, const float *pp_d,
                     const float *w_out_d,
                     const int32_t *logit_lengths_d /* nullable */, const int32_t *target_lengths_d /* nullable */,
-                    int B, int T, int U1, int J, int V,
+                    int B, int T, int U1, int J, int V, int activation,
                     float *dz_d /* [B,T,U1,J] */, float *h_d /* [B,T,U1,J] or NULL */, void *stream);
 
 /* Split-precision joiner on the bf16 matrix cores (opt-in; the exact-fp32 entry points above stay the default).
@@ -204,14 +208,14 @@ size_t wr_joint_split_workspace_bytes(int J, int V);
 
 int wr_joint_fwd_split(const float *ep_d, const float *pp_d, const float *w_out_d, const float *b_out_d,
                        const int32_t *logit_lengths_d /* nullable */, const int32_t *target_lengths_d /* nullable */,
-                       int B, int T, int U1, int J, int V, int terms,
+                       int B, int T, int U1, int J, int V, int activation, int terms,
                        void *out_d /* [B,T,U1,V] */, int out_dtype,
                        void *workspace_d, size_t workspace_bytes, void *stream);
 
 /* wr_joint_fwd_split with the RNN-T loss's row statistics fused into the epilogue (see wr_joint_fwd_lse); fp32 logits. */
 int wr_joint_fwd_split_lse(const float *ep_d, const float *pp_d, const float *w_out_d, const float *b_out_d,
                            const int32_t *logit_lengths_d, const int32_t *target_lengths_d, const int32_t *targets_d,
-                           int B, int T, int U1, int J, int V, int blank, int terms,
+                           int B, int T, int U1, int J, int V, int activation, int blank, int terms,
                            float *out_d /* [B,T,U1,V] */,
                            void *workspace_d, size_t workspace_bytes,
                            void *rnnt_workspace_d, size_t rnnt_workspace_bytes, void *stream);
@@ -224,7 +228,7 @@ size_t wr_joint_dz_split_workspace_bytes(int J, int V);
 int wr_joint_bwd_dz_split(const float *gout_d /* [B,T,U1,V] */, const float *ep_d, const float *pp_d,
                           const float *w_out_d,
                           const int32_t *logit_lengths_d /* nullable */, const int32_t *target_lengths_d /* nullable */,
-                          int B, int T, int U1, int J, int V, int terms,
+                          int B, int T, int U1, int J, int V, int activation, int terms,
                           float *dz_d /* [B,T,U1,J] */, float *h_d /* [B,T,U1,J] or NULL */,
                           void *workspace_d, size_t workspace_bytes, void *stream);
 
@@ -281,7 +285,7 @@ typedef struct wr_transducer_weights {
     int32_t hidden;       /* H: LSTM hidden size */
     int32_t n_layers;     /* L */
     int32_t join_dim;     /* J */
-    int32_t reserved;
+    int32_t activation;   /* wr_activation of the joiner (0 = tanh) */
     const float *embed;                        /* predictor.embed.weight       [V, D] */
     const float *w_ih[WR_MAX_LSTM_LAYERS];     /* predictor.rnn.weight_ih_l{k} [4H, D or H], gate order i,f,g,o */
     const float *w_hh[WR_MAX_LSTM_LAYERS];     /* predictor.rnn.weight_hh_l{k} [4H, H] */

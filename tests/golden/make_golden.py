@@ -12,7 +12,8 @@ Reference entry points exercised (all importable here with two in-process stubs
 for modules that are absent from the image -- `typeguard`, used only for
 `assert check_argument_types()`, and `turtle`, an accidental import):
   wenet/transformer/ctc.py            CTC.forward / log_softmax      -> ctc_ref_*.npz
-  wenet/transducer/joint.py           TransducerJoint.forward        -> joint_ref_*.npz
+  wenet/transducer/joint.py           TransducerJoint.forward        -> joint_ref_*.npz, joint_var_*.npz (other activations,
+                                      prejoin_linear off, postjoin_linear on)
   wenet/transducer/predictor.py       RNNPredictor.forward_step ...  -> predictor_step_*.npz
   wenet/transducer/search/greedy_search copy.py  basic_greedy_search -> greedy_core_*.npz
   wenet/transducer/search/prefix_beam_search.py  PrefixBeamSearch    -> prefix_beam_*.npz
@@ -125,6 +126,31 @@ def gen_joint():
         out.backward(gout)
         save(f"joint_ref_{i}", enc=enc.detach().numpy(), pred=pred.detach().numpy(), out=out.detach().numpy(),
              gout=gout.numpy(), grad_enc=enc.grad.numpy(), grad_pred=pred.grad.numpy(),
+             **{"w_" + k: v for k, v in sd(joint).items()},
+             **{"g_" + k: p.grad.numpy() for k, p in joint.named_parameters()})
+
+
+def gen_joint_variants():
+    """Non-shipped constructor options of the reference joiner (joint.py:16-43): every activation of get_activation,
+    prejoin_linear off, postjoin_linear on."""
+    from wenet.transducer.joint import TransducerJoint
+    cases = [dict(activation=a) for a in ("relu", "hardtanh", "selu", "swish", "gelu")]
+    cases += [dict(activation="swish", prejoin_linear=False), dict(activation="gelu", postjoin_linear=True),
+              dict(activation="tanh", prejoin_linear=False, postjoin_linear=True)]
+    for i, kw in enumerate(cases):
+        torch.manual_seed(40 + i)
+        B, T, U1, J, V = 2, 9, 5, 24, 70
+        E = P = J if not kw.get("prejoin_linear", True) or kw.get("postjoin_linear", False) else 16
+        joint = TransducerJoint(V, E, P, J, **kw)
+        enc = (torch.randn(B, T, E) * 1.5).requires_grad_(True)      # spread over the kinks of relu / hardtanh
+        pred = (torch.randn(B, U1, P) * 1.5).requires_grad_(True)
+        out = joint(enc, pred)
+        gout = torch.randn_like(out)
+        out.backward(gout)
+        save(f"joint_var_{i}", enc=enc.detach().numpy(), pred=pred.detach().numpy(), out=out.detach().numpy(),
+             gout=gout.numpy(), grad_enc=enc.grad.numpy(), grad_pred=pred.grad.numpy(),
+             activation=np.array(kw["activation"]), prejoin=np.array(kw.get("prejoin_linear", True)),
+             postjoin=np.array(kw.get("postjoin_linear", False)),
              **{"w_" + k: v for k, v in sd(joint).items()},
              **{"g_" + k: p.grad.numpy() for k, p in joint.named_parameters()})
 
@@ -749,10 +775,16 @@ def gen_rnnt_kat():
 if __name__ == "__main__":
     install_stubs()
     torch.set_num_threads(1)
+    only = os.environ.get("GOLDEN_ONLY")          # e.g. GOLDEN_ONLY=gen_joint_variants,gen_predictor: just these
+    if only:
+        for name in only.split(","):
+            globals()[name]()
+        sys.exit(0)
     gen_common()
     gen_rnnt_kat()
     gen_ctc()
     gen_joint()
+    gen_joint_variants()
     gen_predictor()
     gen_greedy()
     gen_beam()

@@ -86,10 +86,12 @@ def test_every_entry_point_rejects_bad_arguments_before_launch(lib):
     assert lib.wr_ctc_loss_bwd(null, 0, null, null, null, 2, 10, 5, 50, 0, null, null, null, 0, null) == -1
     assert lib.wr_ctc_workspace_bytes(2, 10, 5) > 0 and lib.wr_ctc_workspace_bytes(0, 10, 5) == 0
     # joiner: join_dim limits, missing pointers, half-specified lengths
-    assert lib.wr_joint_fwd(null, null, null, null, null, null, 1, 2, 2, 516, 10, null, null, 0, null) == -2
+    assert lib.wr_joint_fwd(null, null, null, null, null, null, 1, 2, 2, 516, 10, 0, null, null, 0, null) == -2
     assert b"join_dim" in lib.wr_last_error()
-    assert lib.wr_joint_fwd(null, null, null, null, null, null, 1, 2, 2, 512, 10, null, null, 0, null) == -1
-    assert lib.wr_joint_bwd_dz(null, null, null, null, null, null, 1, 2, 2, 512, 10, null, null, null) == -1
+    assert lib.wr_joint_fwd(null, null, null, null, null, null, 1, 2, 2, 512, 10, 0, null, null, 0, null) == -1
+    assert lib.wr_joint_fwd(null, null, null, null, null, null, 1, 2, 2, 512, 10, 6, null, null, 0, null) == -1
+    assert b"activation" in lib.wr_last_error()
+    assert lib.wr_joint_bwd_dz(null, null, null, null, null, null, 1, 2, 2, 512, 10, 0, null, null, null) == -1
     assert lib.wr_joint_bwd_dw(null, null, null, null, 1, 2, 2, 512, 10, null, null, null, 0, null) == -1
     assert lib.wr_joint_workspace_bytes(512, 5000) >= 512 * 5120 * 4
     assert lib.wr_joint_dw_workspace_bytes(512, 5000) >= 5000 * 512 * 4

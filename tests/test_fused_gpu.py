@@ -116,7 +116,7 @@ def test_fused_workspace_matches_pass1():
     costs = torch.empty(B, device=DEV)
     st = _lib.current_stream(torch.device(DEV))
     P = _lib.ptr
-    _lib.check(lib.wr_joint_fwd_lse(P(ep), P(pp), P(w), P(b), P(tl), P(ul), P(y), B, T, U1, J, V, 0, P(logits), P(jws), jwsb,
+    _lib.check(lib.wr_joint_fwd_lse(P(ep), P(pp), P(w), P(b), P(tl), P(ul), P(y), B, T, U1, J, V, 0, 0, P(logits), P(jws), jwsb,
                                     P(rws), rwsb, st), "fwd_lse")
     _lib.check(lib.wr_rnnt_loss_fwd_from_lse(P(logits), P(y), P(tl), P(ul), B, T, U1, V, 0, P(costs), P(rws), rwsb, st),
                "from_lse")

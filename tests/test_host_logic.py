@@ -210,8 +210,10 @@ def test_joiner_and_predictor_variants_accepted_or_refused_loudly():
     assert set(dict(j2.named_parameters())) >= {"post_ffn.weight", "post_ffn.bias", "enc_ffn.weight", "ffn_out.weight"}
     with pytest.raises(AssertionError):
         w.TransducerJoint(10, 8, 6, 8, prejoin_linear=False)          # joint.py:30-31: widths must agree
-    with pytest.raises(NotImplementedError, match="tanh"):
-        w.TransducerJoint(10, 8, 8, 8, activation="relu")
+    for act in ("tanh", "relu", "hardtanh", "selu", "swish", "gelu"):            # get_activation's table, common.py:233-240
+        assert w.TransducerJoint(10, 8, 8, 8, activation=act).act_code == w._lib.ACTIVATIONS[act]
+    with pytest.raises(KeyError):
+        w.TransducerJoint(10, 8, 8, 8, activation="sigmoid")
     p = w.RNNPredictor(10, 8, 8, 0.1, 8, 1)
     with pytest.raises(NotImplementedError, match="postjoin_linear"):
         DeviceDecoder(p, j2, 1, 1, 4)

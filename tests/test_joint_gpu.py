@@ -105,10 +105,67 @@ def test_lengths_skip_padding_and_feed_rnnt_loss():
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "joint_var_*.npz"))))
+def test_constructor_variants_match_reference_fixture(path, precision):
+    """Every activation of get_activation, prejoin_linear off, postjoin_linear on: outputs and all gradients of the
+    reference's TransducerJoint (joint.py:16-70) built with the same options.  Exact kernels at the 1e-4 bar; the split
+    kernels relative to each tensor's scale (their operand rounding is 2^-17)."""
+    import wenet_celoss_amd as w
+    d = np.load(path)
+    sd = {k[2:]: d[k] for k in d.files if k.startswith("w_")}
+    V, J = sd["ffn_out.weight"].shape
+    E, P = d["enc"].shape[-1], d["pred"].shape[-1]
+    m = w.TransducerJoint(V, E, P, J, prejoin_linear=bool(d["prejoin"]), postjoin_linear=bool(d["postjoin"]),
+                          activation=str(d["activation"]), precision=precision).to(DEV)
+    m.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
+    enc = torch.tensor(d["enc"], device=DEV, requires_grad=True)
+    pred = torch.tensor(d["pred"], device=DEV, requires_grad=True)
+    out = m(enc, pred)
+    rel = 1e-4 if precision == "fp32" else 2e-4
+
+    def close(got, ref, name):
+        ref = np.asarray(ref)
+        np.testing.assert_allclose(got.detach().cpu().numpy(), ref, rtol=rel, atol=rel * max(1.0, float(np.abs(ref).max())),
+                                   err_msg=name)
+    close(out, d["out"], "out")
+    out.backward(torch.tensor(d["gout"], device=DEV))
+    close(enc.grad, d["grad_enc"], "enc")
+    close(pred.grad, d["grad_pred"], "pred")
+    for name, p in m.named_parameters():
+        close(p.grad, d["g_" + name], name)
+
+
+@pytest.mark.parametrize("activation", ["relu", "hardtanh", "selu", "swish", "gelu"])
+def test_activation_through_the_fused_loss_node(activation):
+    """joint_rnnt_loss with a non-tanh activation: same costs and gradients as joiner module + rnnt_loss."""
+    import wenet_celoss_amd as w
+    torch.manual_seed(11)
+    B, T, U, J, V = 3, 21, 6, 64, 96
+    m = w.TransducerJoint(V, 16, 16, J, activation=activation).to(DEV)
+    enc = torch.randn(B, T, 16, device=DEV); pred = torch.randn(B, U + 1, 16, device=DEV)
+    y = torch.randint(1, V, (B, U), dtype=torch.int32, device=DEV)
+    ll = torch.tensor([T, 9, 15], dtype=torch.int32, device=DEV); tl = torch.tensor([U, 2, 4], dtype=torch.int32, device=DEV)
+    res = []
+    for fused in (False, True):
+        m.zero_grad()
+        e = enc.clone().requires_grad_(True); p = pred.clone().requires_grad_(True)
+        if fused:
+            ep, pp = m.pre_activation(e, p)
+            loss = w.joint_rnnt_loss(ep, pp, m.ffn_out.weight, m.ffn_out.bias, y, ll, tl, activation=activation)
+        else:
+            loss = w.rnnt_loss(m(e, p, ll, tl), y, ll, tl, blank=0, reduction="mean")
+        loss.backward()
+        res.append((loss.item(), e.grad.clone(), p.grad.clone(), m.ffn_out.weight.grad.clone(), m.enc_ffn.weight.grad.clone()))
+    assert res[0][0] == pytest.approx(res[1][0], rel=1e-5)
+    for a, b in zip(res[0][1:], res[1][1:]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * float(a.abs().max()))
+
+
 def test_unsupported_configuration_raises():
     import wenet_celoss_amd as w
-    with pytest.raises(NotImplementedError):
-        w.TransducerJoint(10, 8, 8, 8, activation="relu")
+    with pytest.raises(KeyError):                    # get_activation's dictionary lookup (common.py:242)
+        w.TransducerJoint(10, 8, 8, 8, activation="sigmoid")
     m = w.TransducerJoint(10, 8, 8, 516).to(DEV)
     with pytest.raises(RuntimeError, match="join_dim"):
         m(torch.zeros(1, 2, 8, device=DEV), torch.zeros(1, 2, 8, device=DEV))
@@ -176,14 +233,14 @@ def test_split_dz_matches_exact_kernel(terms, tol, B, T, U1, J, V):
     for lens in ((None, None), (ll, tl)):
         dz0 = torch.empty(B, T, U1, J, device=DEV); h0 = torch.empty_like(dz0)
         dz1 = torch.full_like(dz0, float("nan")); h1 = torch.full_like(dz0, float("nan"))
-        _lib.check(lib.wr_joint_bwd_dz(P(gout), P(ep), P(pp), P(w), P(lens[0]), P(lens[1]), B, T, U1, J, V, P(dz0), P(h0), st))
-        _lib.check(lib.wr_joint_bwd_dz_split(P(gout), P(ep), P(pp), P(w), P(lens[0]), P(lens[1]), B, T, U1, J, V, terms,
+        _lib.check(lib.wr_joint_bwd_dz(P(gout), P(ep), P(pp), P(w), P(lens[0]), P(lens[1]), B, T, U1, J, V, 0, P(dz0), P(h0), st))
+        _lib.check(lib.wr_joint_bwd_dz_split(P(gout), P(ep), P(pp), P(w), P(lens[0]), P(lens[1]), B, T, U1, J, V, 0, terms,
                                              P(dz1), P(h1), P(ws), wsb, st))
         assert torch.equal(h0, h1)
         assert torch.equal(dz0 == 0, dz1 == 0) or lens[0] is None
         rms = float(dz0.pow(2).mean().sqrt())
         assert float((dz0 - dz1).abs().max()) <= tol * rms
-    assert lib.wr_joint_bwd_dz_split(P(gout), P(ep), P(pp), P(w), None, None, B, T, U1, J, 30, terms, P(dz1), None,
+    assert lib.wr_joint_bwd_dz_split(P(gout), P(ep), P(pp), P(w), None, None, B, T, U1, J, 30, 0, terms, P(dz1), None,
                                      P(ws), wsb, st) != 0           # V not a multiple of 4
 
 
@@ -223,7 +280,7 @@ def test_split_forward_amp_dtype_and_errors():
         w.joint_logits(enc, pred, m.ffn_out.weight, m.ffn_out.bias, precision="fp8")
     from wenet_celoss_amd import _lib
     lib = _lib.load()
-    assert lib.wr_joint_fwd_split(None, None, None, None, None, None, 1, 1, 1, 64, 10, 2, None, 0, None, 0, None) != 0
+    assert lib.wr_joint_fwd_split(None, None, None, None, None, None, 1, 1, 1, 64, 10, 0, 2, None, 0, None, 0, None) != 0
     assert b"terms" in lib.wr_last_error()
 
 
@@ -353,7 +410,7 @@ def test_exact_dz_block_tiling_matches_cell_tiling(B, T, U1, J, V):
             for knob in (0, 1):
                 lib.wr_tune_set(10, knob)
                 dz = torch.full((B, T, U1, J), float("nan"), device=DEV); h = torch.full_like(dz, float("nan"))
-                _lib.check(lib.wr_joint_bwd_dz(P(gout), P(ep), P(pp), P(w), P(lens[0]), P(lens[1]), B, T, U1, J, V, P(dz), P(h), st))
+                _lib.check(lib.wr_joint_bwd_dz(P(gout), P(ep), P(pp), P(w), P(lens[0]), P(lens[1]), B, T, U1, J, V, 0, P(dz), P(h), st))
                 res.append((dz, h))
             assert torch.equal(res[0][1], res[1][1])
             assert torch.equal(res[0][0] == 0, res[1][0] == 0) or lens[0] is None

@@ -34,7 +34,7 @@ def bench_joint(args):
     ws_bytes = lib.wr_joint_workspace_bytes(J, V)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     st = _lib.current_stream(dev); P = _lib.ptr
-    f = lambda: _lib.check(lib.wr_joint_fwd(P(ep), P(pp), P(w), P(b), None, None, B, T, U1, J, V, P(out), P(ws), ws_bytes, st))
+    f = lambda: _lib.check(lib.wr_joint_fwd(P(ep), P(pp), P(w), P(b), None, None, B, T, U1, J, V, 0, P(out), P(ws), ws_bytes, st))
     flops = 2.0 * B * T * U1 * J * V
     ms = timeit(f, args.steps)
     print(json.dumps({"what": "joint_fwd", "shape": [B, T, U1, J, V], "ms": round(ms, 3),
@@ -50,7 +50,7 @@ def bench_joint(args):
                                     (1, torch.float32, 0, 1), (1, torch.float32, 0, 2), (1, torch.bfloat16, 2, 1), (1, torch.bfloat16, 2, 2)):
         lib.wr_tune_set(7, parts)
         out_s = torch.empty(B, T, U1, V, dtype=odt, device=dev)
-        fs = lambda: _lib.check(lib.wr_joint_fwd_split(P(ep), P(pp), P(w), P(b), None, None, B, T, U1, J, V, terms,
+        fs = lambda: _lib.check(lib.wr_joint_fwd_split(P(ep), P(pp), P(w), P(b), None, None, B, T, U1, J, V, 0, terms,
                                                        P(out_s), code, P(ws_s), wsb_s, st))
         ms = timeit(fs, args.steps)
         err = float((out_s[:1].float() - out[:1]).abs().max())
@@ -61,7 +61,7 @@ def bench_joint(args):
         del out_s
     lib.wr_tune_set(7, 0)
     dz = torch.empty(B, T, U1, J, device=dev); h = torch.empty_like(dz)
-    g = lambda: _lib.check(lib.wr_joint_bwd_dz(P(out), P(ep), P(pp), P(w), None, None, B, T, U1, J, V, P(dz), P(h), st))
+    g = lambda: _lib.check(lib.wr_joint_bwd_dz(P(out), P(ep), P(pp), P(w), None, None, B, T, U1, J, V, 0, P(dz), P(h), st))
     dz_blocks = None
     for blocks in (1, 0):                              # knob 10: 0 = 256 x 256 block tiling (default), 1 = 64-cell tiling
         lib.wr_tune_set(10, 0 if blocks else 1)
@@ -78,7 +78,7 @@ def bench_joint(args):
     wz = torch.empty(wsz, dtype=torch.uint8, device=dev)
     dz_ref = dz.clone()
     for terms in (3, 1):
-        gs = lambda: _lib.check(lib.wr_joint_bwd_dz_split(P(out), P(ep), P(pp), P(w), None, None, B, T, U1, J, V, terms,
+        gs = lambda: _lib.check(lib.wr_joint_bwd_dz_split(P(out), P(ep), P(pp), P(w), None, None, B, T, U1, J, V, 0, terms,
                                                            P(dz), P(h), P(wz), wsz, st))
         ms = timeit(gs, args.steps)
         err = float((dz[:1] - dz_ref[:1]).abs().max())

@@ -22,6 +22,8 @@ LIB_PATH = os.path.join(_PKG, LIB_NAME)
 _HASH_PATH = LIB_PATH + ".srchash"
 
 WR_F32, WR_F16, WR_BF16 = 0, 1, 2
+# wr_activation codes (include/wr_api.h), keyed by the names of wenet/utils/common.py:228-242 get_activation
+ACTIVATIONS = {"tanh": 0, "relu": 1, "hardtanh": 2, "selu": 3, "swish": 4, "gelu": 5}
 
 _lock = threading.Lock()
 _lib = None
@@ -106,15 +108,15 @@ SIGNATURES = {
     "wr_ctc_loss_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "wr_ctc_loss_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "wr_joint_workspace_bytes": (_sz, [_i, _i]),
-    "wr_joint_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
-    "wr_joint_fwd_lse": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _sz, _vp]),
-    "wr_joint_fwd_split_lse": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "wr_joint_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "wr_joint_fwd_lse": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "wr_joint_fwd_split_lse": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _sz, _vp]),
     "wr_rnnt_loss_fwd_from_lse": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
-    "wr_joint_bwd_dz": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "wr_joint_bwd_dz": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "wr_joint_split_workspace_bytes": (_sz, [_i, _i]),
-    "wr_joint_fwd_split": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
+    "wr_joint_fwd_split": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
     "wr_joint_dz_split_workspace_bytes": (_sz, [_i, _i]),
-    "wr_joint_bwd_dz_split": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "wr_joint_bwd_dz_split": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "wr_joint_dw_split_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "wr_joint_bwd_dw_split": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "wr_joint_dw_workspace_bytes": (_sz, [_i, _i]),
@@ -144,7 +146,7 @@ class TransducerWeights(ctypes.Structure):
     _MAXL = 4
     _fields_ = [("vocab_size", ctypes.c_int32), ("enc_dim", ctypes.c_int32), ("pred_dim", ctypes.c_int32),
                 ("embed_dim", ctypes.c_int32), ("hidden", ctypes.c_int32), ("n_layers", ctypes.c_int32),
-                ("join_dim", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("join_dim", ctypes.c_int32), ("activation", ctypes.c_int32),
                 ("embed", ctypes.c_void_p),
                 ("w_ih", ctypes.c_void_p * 4), ("w_hh", ctypes.c_void_p * 4),
                 ("b_ih", ctypes.c_void_p * 4), ("b_hh", ctypes.c_void_p * 4),

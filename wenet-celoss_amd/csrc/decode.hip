@@ -62,6 +62,7 @@ struct Dims {
     int Dp, Hp, Pp, Jp;           // K dimensions padded to a multiple of 8 (zero rows)
     int G4p, Vp;                  // N dimensions: 4H padded to 32, V padded to 256
     int NL, NLp;                  // lanes, lanes padded to 32
+    int act;                      // joiner activation (wr_activation)
 };
 
 // Device-resident decoder state; all pointers are carved from the caller's workspace.
@@ -135,6 +136,7 @@ struct GemmArgs {
     float *new_cT, *new_hT;       // this layer's new state
     const float *ep_all;          // [n_utt, T, J]
     int H, J;
+    int act;                      // joiner activation (wr_activation)
     int look, lane_stride;        // joiner activation: frames per lane and the column stride between frames (NLp)
     float4 *row_part;             // kEpiRowStats: per (row, 32-column block) {max, sum exp(x - max), runner-up, first index of max}
     int row_part_ld;              // blocks per row
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(64 * kGemmWaves) void lane_gemm_kernel(GemmArgs g)
             const float pp = total(m, ln, col) + bias_v[it];
 #pragma unroll
             for (int f = 0; f < kMaxLook; ++f)
-                if (f < g.look) g.C[(size_t)v * g.ldc + f * g.lane_stride + n] = act_on[it] ? tanhf(act_ep[f][it] + pp) : 0.f;
+                if (f < g.look) g.C[(size_t)v * g.ldc + f * g.lane_stride + n] = act_on[it] ? act_value(g.act, act_ep[f][it] + pp) : 0.f;
         }
     }
 }
@@ -1443,6 +1445,7 @@ size_t carve(const wr_transducer_weights *w, int max_lanes, int max_utt, int Tma
     Dims d;
     d.V = w->vocab_size; d.E = w->enc_dim; d.P = w->pred_dim; d.D = w->embed_dim; d.H = w->hidden; d.L = w->n_layers;
     d.J = w->join_dim;
+    d.act = w->activation;
     auto up = [](int x, int m) { return (x + m - 1) / m * m; };
     d.Dp = up(d.D, 16); d.Hp = up(d.H, 16); d.Pp = up(d.P, 16); d.Jp = up(d.J, 16);   // K: 8 waves x k-pairs
     d.G4p = 4 * d.Hp;                                      // 32-column tiles = i,f,g,o of 8 hidden units
@@ -1504,6 +1507,8 @@ int check_weights(const wr_transducer_weights *w)
                WR_EINVAL, "decoder: non-positive dimension");
     WR_REQUIRE(w->n_layers >= 1 && w->n_layers <= kMaxLayers, WR_EUNSUPPORTED, "decoder: n_layers=%d (max %d)", w->n_layers,
                kMaxLayers);
+    WR_REQUIRE(w->activation >= WR_ACT_TANH && w->activation <= WR_ACT_GELU, WR_EINVAL,
+               "decoder: activation code %d is not a wr_activation", w->activation);
     WR_REQUIRE(w->join_dim <= 1024 && w->pred_dim <= 1024 && w->hidden <= 1024 && w->embed_dim <= 1024 && w->enc_dim <= 1024,
                WR_EUNSUPPORTED, "decoder: a layer dimension exceeds 1024");
     WR_REQUIRE(w->vocab_size * sizeof(float) <= 64 * 1024, WR_EUNSUPPORTED, "decoder: vocab_size=%d exceeds 16384",
@@ -1567,7 +1572,7 @@ void launch_predictor_and_joint(wr_decoder *h, int n_lanes, hipStream_t st, int 
         g.A0 = s.outT; g.B0 = s.predffn_wt; g.K0 = d.Pp;
         g.lda = d.NLp; g.ldb = up(d.J, 32); g.bias = s.predffn_b; g.C = s.ht; g.ldc = kMaxLook * d.NLp; g.N = d.J; g.n_lanes = n_lanes;
         g.st = h->dev; g.lane_active = s.lane_active; g.lane_t = s.lane_t; g.ep_all = s.ep_all; g.J = d.J;
-        g.look = look; g.lane_stride = d.NLp;
+        g.look = look; g.lane_stride = d.NLp; g.act = d.act;
         launch_gemm<kEpiJointAct>(g, up(d.J, 32), n_lanes, st);
     }
     GemmArgs g{};
@@ -2040,7 +2045,7 @@ void hw_micro_step(wr_decoder *h, int n_lanes, hipStream_t st)
         g.A0 = h->hw_biasT; g.B0 = s.predffn_wt; g.K0 = d.Pp;
         g.lda = d.NLp; g.ldb = up(d.J, 32); g.bias = s.predffn_b; g.C = s.ht; g.ldc = kMaxLook * d.NLp; g.N = d.J; g.n_lanes = n_lanes;
         g.st = h->dev; g.lane_active = s.lane_active; g.lane_t = s.lane_t; g.ep_all = h->hw_ep2; g.J = d.J;
-        g.look = 1; g.lane_stride = d.NLp;
+        g.look = 1; g.lane_stride = d.NLp; g.act = d.act;
         g.ep_gate = h->hw_state; g.ep_gate_stride = (size_t)h->max_utt * h->Tmax * d.J;
         launch_gemm<kEpiJointAct>(g, up(d.J, 32), n_lanes, st);
     }

@@ -56,10 +56,11 @@ __global__ void joint_transpose_w_kernel(const float *__restrict__ w, int V, int
     }
 }
 
-// Fill the k-major activation tile: Ht[k][row] = tanh(ep[bt,k] + pp[bu,k]) for the 64 cells m0..m0+63.
+// Fill the k-major activation tile: Ht[k][row] = act(ep[bt,k] + pp[bu,k]) for the 64 cells m0..m0+63 (act: tanh unless
+// the module was built with another activation, wr_common.hpp act_value).
 __device__ __forceinline__ void fill_h_tile(float *__restrict__ Ht, const float *__restrict__ ep,
                                             const float *__restrict__ pp, long m0, long M, int T, int U1, int J,
-                                            int Jp)
+                                            int Jp, int act)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int row = wave; row < kBM; row += nw) {
@@ -70,7 +71,7 @@ __device__ __forceinline__ void fill_h_tile(float *__restrict__ Ht, const float 
             const long b = bt / T;
             const float *__restrict__ e = ep + (size_t)bt * J;
             const float *__restrict__ p = pp + ((size_t)b * U1 + u) * J;
-            for (int k = lane; k < Jp; k += 64) Ht[k * kHPad + row] = (k < J) ? tanhf(e[k] + p[k]) : 0.f;
+            for (int k = lane; k < Jp; k += 64) Ht[k * kHPad + row] = (k < J) ? act_value(act, e[k] + p[k]) : 0.f;
         } else {
             for (int k = lane; k < Jp; k += 64) Ht[k * kHPad + row] = 0.f;
         }
@@ -88,7 +89,7 @@ template <int PFK, int CT /* 32-column tiles per wave: 1 -> 8 waves */, bool LSE
 __global__ __launch_bounds__(CT == 2 ? 256 : 512) void joint_fwd_direct_kernel(
     const float *__restrict__ ep, const float *__restrict__ pp, const float *__restrict__ wt /* [Jp, Vp] */,
     const float *__restrict__ bias, const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens,
-    int B, int T, int U1, int J, int Jp, int V, int Vp, float *__restrict__ out, JointLse lse)
+    int B, int T, int U1, int J, int Jp, int V, int Vp, int act, float *__restrict__ out, JointLse lse)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *Ht = lds;                                  // [Jp][65]
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(CT == 2 ? 256 : 512) void joint_fwd_direct_kernel(
         }
         if (!__syncthreads_or(valid)) return;
     }
-    fill_h_tile(Ht, ep, pp, m0, M, T, U1, J, Jp);
+    fill_h_tile(Ht, ep, pp, m0, M, T, U1, J, Jp, act);
     __syncthreads();
 
     const int nchunks = Vp / kBN;
@@ -194,7 +195,7 @@ constexpr int kBwdWaves = 8;
 __global__ __launch_bounds__(512) void joint_bwd_dz_kernel(
     const float *__restrict__ gout /* [M, V] */, const float *__restrict__ ep, const float *__restrict__ pp,
     const float *__restrict__ w /* [V, J] */, const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens,
-    int B, int T, int U1, int J, int V, float *__restrict__ dz /* [M, J] */, float *__restrict__ hout /* [M,J] or null */)
+    int B, int T, int U1, int J, int V, int act, float *__restrict__ dz /* [M, J] */, float *__restrict__ hout /* [M,J] or null */)
 {
     __shared__ float As[2][kBKv][kHPad];               // dY slice, v-major
     const long M = (long)B * T * U1;
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(512) void joint_bwd_dz_kernel(
         __syncthreads();
     }
     if (!wave_on) return;
-    // epilogue: dZ = dH * (1 - H^2), H recomputed per element
+    // epilogue: dZ = dH * act'(z) (tanh: 1 - H^2), H recomputed per element
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -325,8 +326,9 @@ __global__ __launch_bounds__(512) void joint_bwd_dz_kernel(
             for (int c = 0; c < 2; ++c) {
                 const int k = wcol + c * 32 + l31;
                 if (k >= J) continue;
-                const float h = tanhf(e[k] + p[k]);
-                const float g = valid ? acc[i][c][r] * (1.f - h * h) : 0.f;
+                float h, dh;
+                act_value_grad(act, e[k] + p[k], h, dh);
+                const float g = valid ? acc[i][c][r] * dh : 0.f;
                 dz[(size_t)m * J + k] = g;
                 if (hout) hout[(size_t)m * J + k] = valid ? h : 0.f;
             }
@@ -473,10 +475,12 @@ inline int dw_parts(int V)
     return parts < 1 ? 1 : parts;
 }
 
-int joint_check(int B, int T, int U1, int J, int V)
+int joint_check(int B, int T, int U1, int J, int V, int activation = WR_ACT_TANH)
 {
     WR_REQUIRE(B > 0 && T > 0 && U1 > 0 && J > 0 && V > 0, WR_EINVAL,
                "joint: B, T, U1, J, V must be positive (got %d,%d,%d,%d,%d)", B, T, U1, J, V);
+    WR_REQUIRE(activation >= WR_ACT_TANH && activation <= WR_ACT_GELU, WR_EINVAL,
+               "joint: activation code %d is not a wr_activation", activation);
     WR_REQUIRE(J % 4 == 0 && J <= 512, WR_EUNSUPPORTED,
                "joint: join_dim=%d not supported (must be a multiple of 4, at most 512)", J);
     WR_REQUIRE(((long)B * T * U1 + kBM - 1) / kBM < (1L << 31), WR_EUNSUPPORTED, "joint: too many lattice cells");
@@ -498,7 +502,7 @@ namespace {
 // shared body of wr_joint_fwd / wr_joint_fwd_lse
 int joint_fwd_launch(const float *ep_d, const float *pp_d, const float *w_out_d, const float *b_out_d,
                      const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B, int T, int U1, int J, int V,
-                     float *out_d, void *workspace_d, size_t workspace_bytes, const JointLse *lse, hipStream_t st)
+                     int act, float *out_d, void *workspace_d, size_t workspace_bytes, const JointLse *lse, hipStream_t st)
 {
     const int Vp = joint_vpad(V), Jp = joint_jpad(J);
     WR_REQUIRE(workspace_bytes >= (size_t)Jp * Vp * sizeof(float), WR_EWORKSPACE, "joint_fwd: workspace too small");
@@ -513,7 +517,7 @@ int joint_fwd_launch(const float *ep_d, const float *pp_d, const float *w_out_d,
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_fwd_direct_kernel<8, 1, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile);
         hipLaunchKernelGGL((joint_fwd_direct_kernel<8, 1, false>), grid, dim3(512), tile, st, ep_d, pp_d, wt, b_out_d,
-                           logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, out_d, JointLse{});
+                           logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, act, out_d, JointLse{});
     } else {
         // the statistics exchange reuses the activation tile's storage
         const size_t lds = tile > joint_lse_exchange_bytes(8) ? tile : joint_lse_exchange_bytes(8);
@@ -521,7 +525,7 @@ int joint_fwd_launch(const float *ep_d, const float *pp_d, const float *w_out_d,
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_fwd_direct_kernel<8, 1, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((joint_fwd_direct_kernel<8, 1, true>), grid, dim3(512), lds, st, ep_d, pp_d, wt, b_out_d,
-                           logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, out_d, *lse);
+                           logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, act, out_d, *lse);
     }
     WR_CHECK_LAUNCH("joint_fwd_direct_kernel");
     return WR_OK;
@@ -530,23 +534,24 @@ int joint_fwd_launch(const float *ep_d, const float *pp_d, const float *w_out_d,
 
 extern "C" int wr_joint_fwd(const float *ep_d, const float *pp_d, const float *w_out_d, const float *b_out_d,
                             const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B, int T, int U1,
-                            int J, int V, float *out_d, void *workspace_d, size_t workspace_bytes, void *stream)
+                            int J, int V, int activation, float *out_d, void *workspace_d, size_t workspace_bytes,
+                            void *stream)
 {
-    if (int rc = joint_check(B, T, U1, J, V)) return rc;
+    if (int rc = joint_check(B, T, U1, J, V, activation)) return rc;
     WR_REQUIRE(ep_d && pp_d && w_out_d && b_out_d && out_d && workspace_d, WR_EINVAL, "joint_fwd: null pointer argument");
     WR_REQUIRE((logit_lengths_d == nullptr) == (target_lengths_d == nullptr), WR_EINVAL,
                "joint_fwd: pass both length arrays or neither");
-    return joint_fwd_launch(ep_d, pp_d, w_out_d, b_out_d, logit_lengths_d, target_lengths_d, B, T, U1, J, V, out_d,
-                            workspace_d, workspace_bytes, nullptr, static_cast<hipStream_t>(stream));
+    return joint_fwd_launch(ep_d, pp_d, w_out_d, b_out_d, logit_lengths_d, target_lengths_d, B, T, U1, J, V, activation,
+                            out_d, workspace_d, workspace_bytes, nullptr, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int wr_joint_fwd_lse(const float *ep_d, const float *pp_d, const float *w_out_d, const float *b_out_d,
                                 const int32_t *logit_lengths_d, const int32_t *target_lengths_d,
-                                const int32_t *targets_d, int B, int T, int U1, int J, int V, int blank, float *out_d,
-                                void *workspace_d, size_t workspace_bytes, void *rnnt_workspace_d,
+                                const int32_t *targets_d, int B, int T, int U1, int J, int V, int activation, int blank,
+                                float *out_d, void *workspace_d, size_t workspace_bytes, void *rnnt_workspace_d,
                                 size_t rnnt_workspace_bytes, void *stream)
 {
-    if (int rc = joint_check(B, T, U1, J, V)) return rc;
+    if (int rc = joint_check(B, T, U1, J, V, activation)) return rc;
     WR_REQUIRE(ep_d && pp_d && w_out_d && b_out_d && out_d && workspace_d && rnnt_workspace_d, WR_EINVAL,
                "joint_fwd_lse: null pointer argument");
     WR_REQUIRE(logit_lengths_d && target_lengths_d, WR_EINVAL, "joint_fwd_lse: both length arrays are required");
@@ -559,25 +564,25 @@ extern "C" int wr_joint_fwd_lse(const float *ep_d, const float *pp_d, const floa
     char *rws = static_cast<char *>(rnnt_workspace_d);
     JointLse lse{targets_d, blank, w.S, reinterpret_cast<float2 *>(rws + w.lp_off), reinterpret_cast<float *>(rws + w.denom_off),
                  reinterpret_cast<int32_t *>(rws + w.flag_off)};
-    return joint_fwd_launch(ep_d, pp_d, w_out_d, b_out_d, logit_lengths_d, target_lengths_d, B, T, U1, J, V, out_d,
-                            workspace_d, workspace_bytes, &lse, static_cast<hipStream_t>(stream));
+    return joint_fwd_launch(ep_d, pp_d, w_out_d, b_out_d, logit_lengths_d, target_lengths_d, B, T, U1, J, V, activation,
+                            out_d, workspace_d, workspace_bytes, &lse, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int wr_joint_bwd_dz(const float *gout_d, const float *ep_d, const float *pp_d, const float *w_out_d,
                                const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B, int T, int U1,
-                               int J, int V, float *dz_d, float *h_d, void *stream)
+                               int J, int V, int activation, float *dz_d, float *h_d, void *stream)
 {
-    if (int rc = joint_check(B, T, U1, J, V)) return rc;
+    if (int rc = joint_check(B, T, U1, J, V, activation)) return rc;
     WR_REQUIRE(gout_d && ep_d && pp_d && w_out_d && dz_d, WR_EINVAL, "joint_bwd_dz: null pointer argument");
     WR_REQUIRE((logit_lengths_d == nullptr) == (target_lengths_d == nullptr), WR_EINVAL,
                "joint_bwd_dz: pass both length arrays or neither");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (V % 4 == 0 && V >= 16 && J % 4 == 0 && tune_get(kTuneDzExact) != 1)   // default: 256 x 256 block tiling (knob 10 = 1: 64-cell tiling)
-        return joint_bwd_dz_block(gout_d, ep_d, pp_d, w_out_d, logit_lengths_d, target_lengths_d, B, T, U1, J, V, dz_d, h_d, st);
+        return joint_bwd_dz_block(gout_d, ep_d, pp_d, w_out_d, logit_lengths_d, target_lengths_d, B, T, U1, J, V, activation, dz_d, h_d, st);
     const long M = (long)B * T * U1;
     const dim3 grid((unsigned)((M + kBM - 1) / kBM));
     hipLaunchKernelGGL(joint_bwd_dz_kernel, grid, dim3(64 * kBwdWaves), 0, st, gout_d, ep_d, pp_d, w_out_d,
-                       logit_lengths_d, target_lengths_d, B, T, U1, J, V, dz_d, h_d);
+                       logit_lengths_d, target_lengths_d, B, T, U1, J, V, activation, dz_d, h_d);
     WR_CHECK_LAUNCH("joint_bwd_dz_kernel");
     return WR_OK;
 }

@@ -108,7 +108,7 @@ template <int TERMS, typename OutT, bool LSE = false>
 __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
     const float *__restrict__ ep, const float *__restrict__ pp, const u32x4 *__restrict__ wh, const u32x4 *__restrict__ wl,
     const float *__restrict__ bias, const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens, int B, int T,
-    int U1, int J, int Jp, int V, int Vp, int npart, OutT *__restrict__ out, JointLse lse = JointLse{})
+    int U1, int J, int Jp, int V, int Vp, int npart, int act, OutT *__restrict__ out, JointLse lse = JointLse{})
 {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds_s[];
     const int JS = Jp + 8;                                 // padded row stride (bf16 elements): 16-byte pad
@@ -209,8 +209,11 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
                 const int k = 2 * lane + 128 * i;
                 if (k >= Jp) continue;
                 const bool kin = in && k < J;
-                const float x0 = kin ? tanh_fast(ev[q][i].x + pv[q][i].x) : 0.f;
-                const float x1 = kin ? tanh_fast(ev[q][i].y + pv[q][i].y) : 0.f;
+                const float z0 = ev[q][i].x + pv[q][i].x, z1 = ev[q][i].y + pv[q][i].y;
+                const float a0 = act == WR_ACT_TANH ? tanh_fast(z0) : act_value(act, z0);
+                const float a1 = act == WR_ACT_TANH ? tanh_fast(z1) : act_value(act, z1);
+                const float x0 = kin ? a0 : 0.f;
+                const float x1 = kin ? a1 : 0.f;
                 unsigned hp, lp;
                 split_pair(x0, x1, hp, lp);
                 *reinterpret_cast<unsigned *>(Ahi + (size_t)row * JS + k) = hp;
@@ -385,7 +388,7 @@ template <int TERMS>
 __global__ __launch_bounds__(256) void joint_bwd_dz_split128_kernel(
     const float *__restrict__ gout /* [M, V] */, const float *__restrict__ ep, const float *__restrict__ pp,
     const u32x4 *__restrict__ wh, const u32x4 *__restrict__ wl, const int32_t *__restrict__ llens,
-    const int32_t *__restrict__ tlens, int B, int T, int U1, int J, int V, int D, int n_jt,
+    const int32_t *__restrict__ tlens, int B, int T, int U1, int J, int V, int D, int n_jt, int act,
     float *__restrict__ dz /* [M, J] */, float *__restrict__ hout /* [M, J] or null */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char dz_lds[];
@@ -543,8 +546,9 @@ __global__ __launch_bounds__(256) void joint_bwd_dz_split128_kernel(
         for (int c = 0; c < 16; ++c) {
             const int k = c * 32 + l31;
             if (c >= n_jt || k >= J) continue;
-            const float h = tanhf(e[k] + p[k]);
-            dz[(size_t)m * J + k] = ok ? acc[c][q] * (1.f - h * h) : 0.f;
+            float h, dh;
+            act_value_grad(act, e[k] + p[k], h, dh);
+            dz[(size_t)m * J + k] = ok ? acc[c][q] * dh : 0.f;
             if (hout) hout[(size_t)m * J + k] = ok ? h : 0.f;
         }
     }
@@ -874,10 +878,13 @@ __global__ __launch_bounds__(256) void joint_bwd_dw_block_kernel(
 constexpr int kZB = 256;         // block edge (cells and join columns)
 constexpr int kZApad = kZB + 4;  // transposed dY stage row stride (floats)
 
+// ANY_ACT = false: tanh only (the shipped joiner) -- the generic activation switch in this epilogue costs the 256-register
+// accumulator kernel its register allocation (121 -> 42 TFLOP/s measured), so it is compiled separately.
+template <bool ANY_ACT>
 __global__ __launch_bounds__(256) void joint_bwd_dz_block_kernel(
     const float *__restrict__ gout /* [M, V] */, const float *__restrict__ ep, const float *__restrict__ pp,
     const float *__restrict__ w /* [V, J] */, const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens, int B,
-    int T, int U1, int J, int V, int n_js, float *__restrict__ dz /* [M, J] */, float *__restrict__ hout /* [M,J] or null */)
+    int T, int U1, int J, int V, int n_js, int act, float *__restrict__ dz /* [M, J] */, float *__restrict__ hout /* [M,J] or null */)
 {
     extern __shared__ __attribute__((aligned(16))) float zstage[];   // [kWStages]{ A^T [16][260], B [16][256] }, row tables
     constexpr int kStageFloats = 16 * kZApad + 16 * kZB;
@@ -1021,9 +1028,15 @@ __global__ __launch_bounds__(256) void joint_bwd_dz_block_kernel(
                 f32x4 h4, g4;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const float hh = tanhf(e4[u] + p4[u]);
+                    float hh, dh;
+                    if (ANY_ACT) {
+                        act_value_grad(act, e4[u] + p4[u], hh, dh);
+                    } else {
+                        hh = tanhf(e4[u] + p4[u]);
+                        dh = 1.f - hh * hh;
+                    }
                     h4[u] = ok ? hh : 0.f;
-                    g4[u] = ok ? acc[t][u][q] * (1.f - hh * hh) : 0.f;
+                    g4[u] = ok ? acc[t][u][q] * dh : 0.f;
                 }
                 *reinterpret_cast<f32x4 *>(dz + (size_t)m * J + jcol) = g4;
                 if (hout) *reinterpret_cast<f32x4 *>(hout + (size_t)m * J + jcol) = h4;
@@ -1054,8 +1067,10 @@ inline int split_dw_parts(int V, int J)
     return parts < 1 ? 1 : parts;
 }
 
-int split_check(int B, int T, int U1, int J, int V, int terms, int out_dtype)
+int split_check(int B, int T, int U1, int J, int V, int terms, int out_dtype, int activation = WR_ACT_TANH)
 {
+    WR_REQUIRE(activation >= WR_ACT_TANH && activation <= WR_ACT_GELU, WR_EINVAL,
+               "joint_split: activation code %d is not a wr_activation", activation);
     WR_REQUIRE(B > 0 && T > 0 && U1 > 0 && J > 0 && V > 0, WR_EINVAL,
                "joint_split: B, T, U1, J, V must be positive (got %d,%d,%d,%d,%d)", B, T, U1, J, V);
     WR_REQUIRE(J % 4 == 0 && J <= 512, WR_EUNSUPPORTED,
@@ -1070,17 +1085,24 @@ int split_check(int B, int T, int U1, int J, int V, int terms, int out_dtype)
 
 // Exact-fp32 activation gradient with the block tiling (called by wr_joint_bwd_dz in joint.hip).
 int joint_bwd_dz_block(const float *gout_d, const float *ep_d, const float *pp_d, const float *w_d, const int32_t *llens_d,
-                       const int32_t *tlens_d, int B, int T, int U1, int J, int V, float *dz_d, float *h_d, hipStream_t st)
+                       const int32_t *tlens_d, int B, int T, int U1, int J, int V, int act, float *dz_d, float *h_d, hipStream_t st)
 {
     const long M = (long)B * T * U1;
     const int n_js = (J + kZB - 1) / kZB;
     const long blocks = (M + kZB - 1) / kZB * n_js;
     WR_REQUIRE(blocks < (1L << 31), WR_EUNSUPPORTED, "joint_bwd_dz: too many lattice cells");
     const size_t lds = (size_t)kWStages * (16 * kZApad + 16 * kZB) * sizeof(float) + (size_t)kZB * (2 * sizeof(long) + sizeof(int));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_bwd_dz_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    hipLaunchKernelGGL(joint_bwd_dz_block_kernel, dim3((unsigned)blocks), dim3(256), lds, st, gout_d, ep_d, pp_d, w_d, llens_d,
-                       tlens_d, B, T, U1, J, V, n_js, dz_d, h_d);
+    if (act == WR_ACT_TANH) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_bwd_dz_block_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(joint_bwd_dz_block_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, st, gout_d, ep_d, pp_d, w_d,
+                           llens_d, tlens_d, B, T, U1, J, V, n_js, act, dz_d, h_d);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_bwd_dz_block_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(joint_bwd_dz_block_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, st, gout_d, ep_d, pp_d, w_d,
+                           llens_d, tlens_d, B, T, U1, J, V, n_js, act, dz_d, h_d);
+    }
     WR_CHECK_LAUNCH("joint_bwd_dz_block_kernel");
     return WR_OK;
 }
@@ -1121,7 +1143,7 @@ extern "C" size_t wr_joint_split_workspace_bytes(int J, int V)
 namespace {
 int joint_fwd_split_launch(const float *ep_d, const float *pp_d, const float *w_out_d, const float *b_out_d,
                            const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B, int T, int U1, int J,
-                           int V, int terms, void *out_d, int out_dtype, void *workspace_d, size_t workspace_bytes,
+                           int V, int act, int terms, void *out_d, int out_dtype, void *workspace_d, size_t workspace_bytes,
                            const JointLse *lse, hipStream_t st)
 {
     const int Vp = split_vpad(V), Jp = split_jpad(J);
@@ -1157,7 +1179,7 @@ int joint_fwd_split_launch(const float *ep_d, const float *pp_d, const float *w_
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
         hipLaunchKernelGGL((joint_fwd_split_kernel<TERMS, OutT>), grid, dim3(64 * kSWaves), lds, st, ep_d, pp_d,       \
                            reinterpret_cast<const u32x4 *>(wh), reinterpret_cast<const u32x4 *>(wl), b_out_d,          \
-                           logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, npart, static_cast<OutT *>(out_d), \
+                           logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, npart, act, static_cast<OutT *>(out_d), \
                            JointLse{});                                                                               \
     } while (0)
 #define WR_LAUNCH_SPLIT_LSE(TERMS)                                                                                    \
@@ -1166,7 +1188,7 @@ int joint_fwd_split_launch(const float *ep_d, const float *pp_d, const float *w_
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
         hipLaunchKernelGGL((joint_fwd_split_kernel<TERMS, float, true>), grid, dim3(64 * kSWaves), lds, st, ep_d, pp_d, \
                            reinterpret_cast<const u32x4 *>(wh), reinterpret_cast<const u32x4 *>(wl), b_out_d,          \
-                           logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, npart, static_cast<float *>(out_d), \
+                           logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, npart, act, static_cast<float *>(out_d), \
                            *lse);                                                                                     \
     } while (0)
     if (lse) {
@@ -1189,25 +1211,25 @@ int joint_fwd_split_launch(const float *ep_d, const float *pp_d, const float *w_
 
 extern "C" int wr_joint_fwd_split(const float *ep_d, const float *pp_d, const float *w_out_d, const float *b_out_d,
                                   const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B, int T, int U1,
-                                  int J, int V, int terms, void *out_d, int out_dtype, void *workspace_d,
+                                  int J, int V, int activation, int terms, void *out_d, int out_dtype, void *workspace_d,
                                   size_t workspace_bytes, void *stream)
 {
-    if (int rc = split_check(B, T, U1, J, V, terms, out_dtype)) return rc;
+    if (int rc = split_check(B, T, U1, J, V, terms, out_dtype, activation)) return rc;
     WR_REQUIRE(ep_d && pp_d && w_out_d && b_out_d && out_d && workspace_d, WR_EINVAL,
                "joint_fwd_split: null pointer argument");
     WR_REQUIRE((logit_lengths_d == nullptr) == (target_lengths_d == nullptr), WR_EINVAL,
                "joint_fwd_split: pass both length arrays or neither");
-    return joint_fwd_split_launch(ep_d, pp_d, w_out_d, b_out_d, logit_lengths_d, target_lengths_d, B, T, U1, J, V, terms,
-                                  out_d, out_dtype, workspace_d, workspace_bytes, nullptr, static_cast<hipStream_t>(stream));
+    return joint_fwd_split_launch(ep_d, pp_d, w_out_d, b_out_d, logit_lengths_d, target_lengths_d, B, T, U1, J, V, activation,
+                                  terms, out_d, out_dtype, workspace_d, workspace_bytes, nullptr, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int wr_joint_fwd_split_lse(const float *ep_d, const float *pp_d, const float *w_out_d, const float *b_out_d,
                                       const int32_t *logit_lengths_d, const int32_t *target_lengths_d,
-                                      const int32_t *targets_d, int B, int T, int U1, int J, int V, int blank, int terms,
-                                      float *out_d, void *workspace_d, size_t workspace_bytes, void *rnnt_workspace_d,
+                                      const int32_t *targets_d, int B, int T, int U1, int J, int V, int activation, int blank,
+                                      int terms, float *out_d, void *workspace_d, size_t workspace_bytes, void *rnnt_workspace_d,
                                       size_t rnnt_workspace_bytes, void *stream)
 {
-    if (int rc = split_check(B, T, U1, J, V, terms, WR_F32)) return rc;
+    if (int rc = split_check(B, T, U1, J, V, terms, WR_F32, activation)) return rc;
     WR_REQUIRE(ep_d && pp_d && w_out_d && b_out_d && out_d && workspace_d && rnnt_workspace_d, WR_EINVAL,
                "joint_fwd_split_lse: null pointer argument");
     WR_REQUIRE(logit_lengths_d && target_lengths_d, WR_EINVAL, "joint_fwd_split_lse: both length arrays are required");
@@ -1220,8 +1242,8 @@ extern "C" int wr_joint_fwd_split_lse(const float *ep_d, const float *pp_d, cons
     char *rws = static_cast<char *>(rnnt_workspace_d);
     JointLse lse{targets_d, blank, w.S, reinterpret_cast<float2 *>(rws + w.lp_off), reinterpret_cast<float *>(rws + w.denom_off),
                  reinterpret_cast<int32_t *>(rws + w.flag_off)};
-    return joint_fwd_split_launch(ep_d, pp_d, w_out_d, b_out_d, logit_lengths_d, target_lengths_d, B, T, U1, J, V, terms,
-                                  out_d, WR_F32, workspace_d, workspace_bytes, &lse, static_cast<hipStream_t>(stream));
+    return joint_fwd_split_launch(ep_d, pp_d, w_out_d, b_out_d, logit_lengths_d, target_lengths_d, B, T, U1, J, V, activation,
+                                  terms, out_d, WR_F32, workspace_d, workspace_bytes, &lse, static_cast<hipStream_t>(stream));
 }
 
 extern "C" size_t wr_joint_dz_split_workspace_bytes(int J, int V)
@@ -1233,10 +1255,10 @@ extern "C" size_t wr_joint_dz_split_workspace_bytes(int J, int V)
 
 extern "C" int wr_joint_bwd_dz_split(const float *gout_d, const float *ep_d, const float *pp_d, const float *w_out_d,
                                      const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B, int T, int U1,
-                                     int J, int V, int terms, float *dz_d, float *h_d, void *workspace_d,
+                                     int J, int V, int activation, int terms, float *dz_d, float *h_d, void *workspace_d,
                                      size_t workspace_bytes, void *stream)
 {
-    if (int rc = split_check(B, T, U1, J, V, terms, 0)) return rc;
+    if (int rc = split_check(B, T, U1, J, V, terms, 0, activation)) return rc;
     WR_REQUIRE(V % 4 == 0 && V >= 32, WR_EUNSUPPORTED,
                "joint_bwd_dz_split: V=%d not supported (16-byte aligned gradient rows: V a multiple of 4, at least 32)", V);
     WR_REQUIRE(gout_d && ep_d && pp_d && w_out_d && dz_d && workspace_d, WR_EINVAL, "joint_bwd_dz_split: null pointer argument");
@@ -1261,7 +1283,7 @@ extern "C" int wr_joint_bwd_dz_split(const float *gout_d, const float *ep_d, con
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
             hipLaunchKernelGGL(joint_bwd_dz_split128_kernel<TERMS>, grid2, dim3(256), lds, st, gout_d, ep_d, pp_d,      \
                                reinterpret_cast<const u32x4 *>(wh), reinterpret_cast<const u32x4 *>(wl),               \
-                               logit_lengths_d, target_lengths_d, B, T, U1, J, V, D, n_jt, dz_d, h_d);                 \
+                               logit_lengths_d, target_lengths_d, B, T, U1, J, V, D, n_jt, activation, dz_d, h_d);     \
         } while (0)
         if (terms == 3) WR_LAUNCH_DZ2(3); else WR_LAUNCH_DZ2(1);
 #undef WR_LAUNCH_DZ2

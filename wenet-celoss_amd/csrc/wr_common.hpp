@@ -46,7 +46,7 @@ int tune_get(int key);
 
 // joint_split.hip: exact-fp32 activation gradient, 256 x 256 block tiling
 int joint_bwd_dz_block(const float *gout_d, const float *ep_d, const float *pp_d, const float *w_d, const int32_t *llens_d,
-                       const int32_t *tlens_d, int B, int T, int U1, int J, int V, float *dz_d, float *h_d, hipStream_t st);
+                       const int32_t *tlens_d, int B, int T, int U1, int J, int V, int act, float *dz_d, float *h_d, hipStream_t st);
 
 // joint_split.hip: exact-fp32 weight gradient, 256 x 256 block tiling (the partial blocks go to `part_dw`, sized by the
 // caller for `max_parts` parts of V*J + V floats)
@@ -90,6 +90,52 @@ void rnnt_launch_sweep(const RnntWs &w, char *ws, const int32_t *llens, const in
 // ---- device helpers ---------------------------------------------------------
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+
+// Joiner activations (wenet/utils/common.py:228-242 get_activation; codes WR_ACT_* of wr_api.h).  `act` is a kernel
+// argument (wave-uniform: the switch is scalar control flow).  Value and derivative w.r.t. the pre-activation z as
+// torch computes them: Hardtanh passes the gradient strictly inside (-1, 1), ReLU for z > 0, SELU / SiLU / GELU(erf)
+// by their closed forms.
+constexpr float kSeluAlpha = 1.6732632423543772848170429916717f;
+constexpr float kSeluScale = 1.0507009873554804934193349852946f;
+
+__device__ __forceinline__ float act_value(int act, float z)
+{
+    switch (act) {
+    case WR_ACT_RELU: return fmaxf(z, 0.f);
+    case WR_ACT_HARDTANH: return fminf(fmaxf(z, -1.f), 1.f);
+    case WR_ACT_SELU: return kSeluScale * (z > 0.f ? z : kSeluAlpha * expm1f(z));
+    case WR_ACT_SWISH: return z / (1.f + expf(-z));
+    case WR_ACT_GELU: return 0.5f * z * (1.f + erff(z * 0.70710678118654752f));
+    default: return tanhf(z);
+    }
+}
+
+__device__ __forceinline__ void act_value_grad(int act, float z, float &h, float &d)
+{
+    switch (act) {
+    case WR_ACT_RELU: h = fmaxf(z, 0.f); d = z > 0.f ? 1.f : 0.f; break;
+    case WR_ACT_HARDTANH: h = fminf(fmaxf(z, -1.f), 1.f); d = (z > -1.f && z < 1.f) ? 1.f : 0.f; break;
+    case WR_ACT_SELU: {
+        const float e = kSeluAlpha * expf(z);
+        h = kSeluScale * (z > 0.f ? z : kSeluAlpha * expm1f(z));
+        d = kSeluScale * (z > 0.f ? 1.f : e);
+        break;
+    }
+    case WR_ACT_SWISH: {
+        const float sg = 1.f / (1.f + expf(-z));
+        h = z * sg;
+        d = sg * (1.f + z * (1.f - sg));
+        break;
+    }
+    case WR_ACT_GELU: {
+        const float cdf = 0.5f * (1.f + erff(z * 0.70710678118654752f));
+        h = z * cdf;
+        d = cdf + z * 0.39894228040143267794f * expf(-0.5f * z * z);
+        break;
+    }
+    default: h = tanhf(z); d = 1.f - h * h; break;
+    }
+}
 
 // log(exp(a)+exp(b)) in the natural-log domain; -inf safe.
 __device__ __forceinline__ float log_add_exp(float a, float b)

@@ -20,6 +20,24 @@ def _f32(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def _joint_activation_code(joint) -> int:
+    """wr_activation of a joiner module: ours carries `act_code`; the reference's module (joint.py:25) only the
+    instantiated activation under its attribute `activatoin`."""
+    code = getattr(joint, "act_code", None)
+    if code is not None:
+        return int(code)
+    act = getattr(joint, "activatoin", None)
+    if act is None:
+        return _lib.ACTIVATIONS["tanh"]
+    by_type = {"Tanh": "tanh", "ReLU": "relu", "Hardtanh": "hardtanh", "SELU": "selu", "SiLU": "swish", "Swish": "swish",
+               "GELU": "gelu"}
+    name = by_type.get(type(act).__name__)
+    if name is None or (name == "gelu" and getattr(act, "approximate", "none") != "none") or \
+            (name == "hardtanh" and (act.min_val, act.max_val) != (-1.0, 1.0)):
+        raise NotImplementedError(f"wenet_celoss_amd decoding: joiner activation {act!r} is not one of get_activation's")
+    return _lib.ACTIVATIONS[name]
+
+
 class DeviceDecoder:
     """One handle per (predictor, joint) pair and capacity.  Not thread-safe."""
 
@@ -61,6 +79,7 @@ class DeviceDecoder:
         w.hidden = rnn.hidden_size
         w.n_layers = rnn.num_layers
         w.join_dim = joint.ffn_out.weight.shape[1]
+        w.activation = _joint_activation_code(joint)
         w.embed = hold(predictor.embed.weight)
         if rnn.num_layers > 4:
             raise NotImplementedError("at most 4 LSTM layers")

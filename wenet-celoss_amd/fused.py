@@ -20,13 +20,13 @@ from typing import Optional
 import torch
 
 from . import _lib
-from .joint import _PRECISIONS, _resolve_precision, joint_backward
+from .joint import _PRECISIONS, _resolve_precision, activation_code, joint_backward
 
 
 class _JointRnntFn(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, ep, pp, w, b, targets, llens, tlens, blank, clamp, terms):
+    def forward(ctx, ep, pp, w, b, targets, llens, tlens, blank, clamp, terms, act=0):
         if not ep.is_cuda:
             raise RuntimeError("wenet_celoss_amd.joint_rnnt_loss: tensors must live on a HIP device "
                                "(this package has no CPU path)")
@@ -46,21 +46,21 @@ class _JointRnntFn(torch.autograd.Function):
                 ws_bytes = lib.wr_joint_workspace_bytes(J, V)
                 ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
                 rc = lib.wr_joint_fwd_lse(_lib.ptr(ep), _lib.ptr(pp), _lib.ptr(w), _lib.ptr(b), _lib.ptr(llens),
-                                          _lib.ptr(tlens), _lib.ptr(targets), B, T, U1, J, V, blank, _lib.ptr(logits),
+                                          _lib.ptr(tlens), _lib.ptr(targets), B, T, U1, J, V, act, blank, _lib.ptr(logits),
                                           _lib.ptr(ws), ws_bytes, _lib.ptr(rws), rws_bytes, st)
                 _lib.check(rc, "wr_joint_fwd_lse")
             else:
                 ws_bytes = lib.wr_joint_split_workspace_bytes(J, V)
                 ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
                 rc = lib.wr_joint_fwd_split_lse(_lib.ptr(ep), _lib.ptr(pp), _lib.ptr(w), _lib.ptr(b), _lib.ptr(llens),
-                                                _lib.ptr(tlens), _lib.ptr(targets), B, T, U1, J, V, blank, terms,
+                                                _lib.ptr(tlens), _lib.ptr(targets), B, T, U1, J, V, act, blank, terms,
                                                 _lib.ptr(logits), _lib.ptr(ws), ws_bytes, _lib.ptr(rws), rws_bytes, st)
                 _lib.check(rc, "wr_joint_fwd_split_lse")
             rc = lib.wr_rnnt_loss_fwd_from_lse(_lib.ptr(logits), _lib.ptr(targets), _lib.ptr(llens), _lib.ptr(tlens), B, T, U1,
                                                V, blank, _lib.ptr(costs), _lib.ptr(rws), rws_bytes, st)
             _lib.check(rc, "wr_rnnt_loss_fwd_from_lse")
         ctx.save_for_backward(ep, pp, w, targets, llens, tlens, logits, rws)
-        ctx.blank, ctx.clamp, ctx.terms = blank, clamp, terms
+        ctx.blank, ctx.clamp, ctx.terms, ctx.act = blank, clamp, terms, act
         return costs
 
     @staticmethod
@@ -82,8 +82,8 @@ class _JointRnntFn(torch.autograd.Function):
                                       _lib.ptr(rws), rws.numel(), _lib.current_stream(dev))
         _lib.check(rc, "wr_rnnt_loss_bwd")
         d_ep, d_pp, d_w, d_b = joint_backward(grads, ep, pp, w, llens, tlens, ctx.terms, ctx.needs_input_grad[2],
-                                              ctx.needs_input_grad[3], gout_zero_in_padding=True)
-        return d_ep, d_pp, d_w, d_b, None, None, None, None, None, None
+                                              ctx.needs_input_grad[3], gout_zero_in_padding=True, act=ctx.act)
+        return d_ep, d_pp, d_w, d_b, None, None, None, None, None, None, None
 
 
 def plan_buckets(t_lens, u_lens, max_buckets: int = 4, min_gain: float = 0.08, min_cells: int = 20000):
@@ -136,8 +136,8 @@ def plan_buckets(t_lens, u_lens, max_buckets: int = 4, min_gain: float = 0.08, m
 def joint_rnnt_loss(ep: torch.Tensor, pp: torch.Tensor, w_out: torch.Tensor, b_out: torch.Tensor,
                     targets: torch.Tensor, logit_lengths: torch.Tensor, target_lengths: torch.Tensor, blank: int = 0,
                     clamp: float = -1.0, reduction: str = "mean", precision: Optional[str] = None,
-                    buckets: Optional[int] = None) -> torch.Tensor:
-    """rnnt_loss(ffn_out(tanh(ep[:, :, None] + pp[:, None])), targets, logit_lengths, target_lengths) without the
+                    buckets: Optional[int] = None, activation: str = "tanh") -> torch.Tensor:
+    """rnnt_loss(ffn_out(act(ep[:, :, None] + pp[:, None])), targets, logit_lengths, target_lengths) without the
     logits ever leaving the node.  ep (B, T, J) = enc_ffn(encoder_out), pp (B, U+1, J) = pred_ffn(predictor_out);
     targets (B, U) int32 with padding already mapped to a valid class; lengths (B,) int32; requires
     max(logit_lengths) == T and max(target_lengths) + 1 == U+1 like torchaudio's rnnt_loss.
@@ -173,8 +173,9 @@ def joint_rnnt_loss(ep: torch.Tensor, pp: torch.Tensor, w_out: torch.Tensor, b_o
         buckets = int(os.environ.get("WR_FUSED_BUCKETS", "4"))
     groups = plan_buckets(lens[0].tolist(), lens[1].tolist(), max_buckets=buckets) if buckets > 1 else None
     terms = _PRECISIONS[precision]
+    act = activation_code(activation)
     if groups is None:
-        costs = _JointRnntFn.apply(ep, pp, w_out, b_out, tg, ll, tl, int(blank), float(clamp), terms)
+        costs = _JointRnntFn.apply(ep, pp, w_out, b_out, tg, ll, tl, int(blank), float(clamp), terms, act)
     else:
         costs = torch.empty(B, dtype=torch.float32, device=dev)
         parts, index = [], []
@@ -183,7 +184,7 @@ def joint_rnnt_loss(ep: torch.Tensor, pp: torch.Tensor, w_out: torch.Tensor, b_o
             tg_max, ug_max = int(lens[0][g].max()), int(lens[1][g].max())
             parts.append(_JointRnntFn.apply(ep[idx, :tg_max], pp[idx, :ug_max + 1], w_out, b_out,
                                             tg[idx, :ug_max].contiguous(), ll[idx].contiguous(), tl[idx].contiguous(),
-                                            int(blank), float(clamp), terms))
+                                            int(blank), float(clamp), terms, act))
             index.append(idx)
         costs = torch.cat(parts)[torch.argsort(torch.cat(index))]      # back to the caller's order (differentiable)
     if reduction == "mean":

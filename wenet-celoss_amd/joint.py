@@ -18,10 +18,11 @@ under autocast the logits come out in the autocast dtype.  In both modes the act
 and the weight gradient ``dW = dY^T H`` use the same split (``wr_joint_bwd_dz_split``, ``wr_joint_bwd_dw_split``,
 when V is a multiple of 4; otherwise the exact kernels); the bias gradient is summed in fp32.
 
-Supported configurations: ``joint_mode='add'`` with ``activation='tanh'`` (the kernels fuse tanh and its
-derivative), ``prejoin_linear`` on (shipped, conf/encoder_bias_conformer_rnnt_*.yaml:21-26) or off,
+Supported configurations: ``joint_mode='add'`` (the only mode the reference accepts, joint.py:22); every
+``activation`` of ``get_activation`` (common.py:228-242: tanh -- shipped --, relu, hardtanh, selu, swish, gelu; value
+and derivative are evaluated inside the kernels from the pre-activation), ``prejoin_linear`` on (shipped, conf/encoder_bias_conformer_rnnt_*.yaml:21-26) or off,
 ``postjoin_linear`` off (shipped) or on (training forward; distributed over the two addends, see
-``pre_activation``).  Other activations raise -- there is no silent fallback.
+``pre_activation``).
 """
 from __future__ import annotations
 
@@ -37,6 +38,17 @@ from . import _lib
 _PRECISIONS = {"fp32": 0, "bf16x3": 3, "bf16": 1}
 
 
+def activation_code(activation: str) -> int:
+    """wr_activation code of a get_activation name (wenet/utils/common.py:228-242)."""
+    if activation not in _lib.ACTIVATIONS:
+        raise KeyError(f"joint activation must be one of {sorted(_lib.ACTIVATIONS)}, got {activation!r}")
+    return _lib.ACTIVATIONS[activation]
+
+
+_TORCH_ACTIVATIONS = {"tanh": nn.Tanh, "relu": nn.ReLU, "hardtanh": nn.Hardtanh, "selu": nn.SELU, "swish": nn.SiLU,
+                      "gelu": nn.GELU}
+
+
 def _resolve_precision(precision: Optional[str]) -> str:
     if precision is None:
         precision = os.environ.get("WR_JOINT_PRECISION", "fp32")
@@ -50,7 +62,7 @@ class _JointFn(torch.autograd.Function):
     # activations; the MFMA kernels are exact-fp32, so inputs are cast up and the logits come out fp32.
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, ep, pp, w, b, llens, tlens, terms=0, out_dtype=torch.float32):
+    def forward(ctx, ep, pp, w, b, llens, tlens, terms=0, out_dtype=torch.float32, act=0):
         if not ep.is_cuda:
             raise RuntimeError("wenet_celoss_amd.TransducerJoint: tensors must live on a HIP device "
                                "(this package has no CPU path)")
@@ -66,7 +78,7 @@ class _JointFn(torch.autograd.Function):
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             with torch.cuda.device(dev):
                 rc = lib.wr_joint_fwd(_lib.ptr(ep), _lib.ptr(pp), _lib.ptr(w), _lib.ptr(b), _lib.ptr(llens),
-                                      _lib.ptr(tlens), B, T, U1, J, V, _lib.ptr(out), _lib.ptr(ws), ws_bytes,
+                                      _lib.ptr(tlens), B, T, U1, J, V, act, _lib.ptr(out), _lib.ptr(ws), ws_bytes,
                                       _lib.current_stream(dev))
             _lib.check(rc, "wr_joint_fwd")
         else:
@@ -75,12 +87,13 @@ class _JointFn(torch.autograd.Function):
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             with torch.cuda.device(dev):
                 rc = lib.wr_joint_fwd_split(_lib.ptr(ep), _lib.ptr(pp), _lib.ptr(w), _lib.ptr(b), _lib.ptr(llens),
-                                            _lib.ptr(tlens), B, T, U1, J, V, terms, _lib.ptr(out),
+                                            _lib.ptr(tlens), B, T, U1, J, V, act, terms, _lib.ptr(out),
                                             _lib.dtype_code(out_dtype), _lib.ptr(ws), ws_bytes,
                                             _lib.current_stream(dev))
             _lib.check(rc, "wr_joint_fwd_split")
         ctx.save_for_backward(ep, pp, w, llens, tlens)
         ctx.terms = terms
+        ctx.act = act
         return out
 
     @staticmethod
@@ -88,12 +101,12 @@ class _JointFn(torch.autograd.Function):
     def backward(ctx, gout):
         ep, pp, w, llens, tlens = ctx.saved_tensors
         d_ep, d_pp, d_w, d_b = joint_backward(gout, ep, pp, w, llens, tlens, ctx.terms, ctx.needs_input_grad[2],
-                                              ctx.needs_input_grad[3])
-        return d_ep, d_pp, d_w, d_b, None, None, None, None
+                                              ctx.needs_input_grad[3], act=ctx.act)
+        return d_ep, d_pp, d_w, d_b, None, None, None, None, None
 
 
 def joint_backward(gout, ep, pp, w, llens, tlens, terms: int, need_w: bool, need_b: bool,
-                   gout_zero_in_padding: bool = False):
+                   gout_zero_in_padding: bool = False, act: int = 0):
     """Backward of the joiner from the logits gradient `gout` (B,T,U1,V): returns (d_ep, d_pp, d_w, d_b).
     Shared by the joiner's autograd Function and by the fused joiner + RNN-T loss Function (fused.py).
     `gout_zero_in_padding`: the caller guarantees gout == 0 outside [0,T_b) x [0,U_b] (the RNN-T gradient pass
@@ -112,13 +125,13 @@ def joint_backward(gout, ep, pp, w, llens, tlens, terms: int, need_w: bool, need
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             rc = lib.wr_joint_bwd_dz_split(_lib.ptr(gout), _lib.ptr(ep), _lib.ptr(pp), _lib.ptr(w), _lib.ptr(llens),
-                                           _lib.ptr(tlens), B, T, U1, J, V, terms, _lib.ptr(dz), _lib.ptr(h),
+                                           _lib.ptr(tlens), B, T, U1, J, V, act, terms, _lib.ptr(dz), _lib.ptr(h),
                                            _lib.ptr(ws), wsb, _lib.current_stream(dev))
         _lib.check(rc, "wr_joint_bwd_dz_split")
     else:
         with torch.cuda.device(dev):
             rc = lib.wr_joint_bwd_dz(_lib.ptr(gout), _lib.ptr(ep), _lib.ptr(pp), _lib.ptr(w), _lib.ptr(llens),
-                                     _lib.ptr(tlens), B, T, U1, J, V, _lib.ptr(dz), _lib.ptr(h),
+                                     _lib.ptr(tlens), B, T, U1, J, V, act, _lib.ptr(dz), _lib.ptr(h),
                                      _lib.current_stream(dev))
         _lib.check(rc, "wr_joint_bwd_dz")
     d_ep = dz.sum(dim=2)
@@ -158,8 +171,9 @@ def joint_backward(gout, ep, pp, w, llens, tlens, terms: int, need_w: bool, need
 
 def joint_logits(ep: torch.Tensor, pp: torch.Tensor, w_out: torch.Tensor, b_out: torch.Tensor,
                  logit_lengths: Optional[torch.Tensor] = None,
-                 target_lengths: Optional[torch.Tensor] = None, precision: Optional[str] = None) -> torch.Tensor:
-    """ffn_out(tanh(ep[:, :, None] + pp[:, None])) -> (B, T, U1, V).  With lengths, cells in the
+                 target_lengths: Optional[torch.Tensor] = None, precision: Optional[str] = None,
+                 activation: str = "tanh") -> torch.Tensor:
+    """ffn_out(act(ep[:, :, None] + pp[:, None])) -> (B, T, U1, V); `activation` one of _lib.ACTIVATIONS (default tanh).  With lengths, cells in the
     padded region are left unwritten (they are never read by the RNN-T loss).  ``precision``: see the
     module docstring ("fp32" exact, "bf16x3" split, "bf16" AMP)."""
     precision = _resolve_precision(precision)
@@ -172,7 +186,7 @@ def joint_logits(ep: torch.Tensor, pp: torch.Tensor, w_out: torch.Tensor, b_out:
     if logit_lengths is not None:
         logit_lengths = logit_lengths.to(device=ep.device, dtype=torch.int32).contiguous()
         target_lengths = target_lengths.to(device=ep.device, dtype=torch.int32).contiguous()
-    return _JointFn.apply(ep, pp, w_out, b_out, logit_lengths, target_lengths, terms, out_dtype)
+    return _JointFn.apply(ep, pp, w_out, b_out, logit_lengths, target_lengths, terms, out_dtype, activation_code(activation))
 
 
 class TransducerJoint(nn.Module):
@@ -183,9 +197,9 @@ class TransducerJoint(nn.Module):
                  activation: str = "tanh", precision: Optional[str] = None):
         assert joint_mode in ["add"]
         super().__init__()
-        if activation != "tanh":
-            raise NotImplementedError("wenet_celoss_amd.TransducerJoint implements activation='tanh' (the shipped "
-                                      f"configuration; the kernels fuse tanh and its derivative); got {activation!r}")
+        self.activation = activation
+        self.act_code = activation_code(activation)      # KeyError for an unknown name, as get_activation's lookup
+        self.activatoin = _TORCH_ACTIVATIONS[activation]()   # the reference's attribute (sic); used by the export body only
         self.precision = precision                 # None: WR_JOINT_PRECISION or exact fp32
         self.prejoin_linear = prejoin_linear
         self.postjoin_linear = postjoin_linear
@@ -228,7 +242,7 @@ class TransducerJoint(nn.Module):
         out = enc.unsqueeze(2) + pred.unsqueeze(1)
         if self.post_ffn is not None:
             out = self.post_ffn(out)
-        return self.ffn_out(torch.tanh(out))
+        return self.ffn_out(self.activatoin(out))
 
     @torch.jit.unused      # backed by a ctypes autograd Function: opaque to TorchScript (train.py:203-205 smoke export)
     def forward(self, enc_out: torch.Tensor, pred_out: torch.Tensor,
@@ -238,4 +252,4 @@ class TransducerJoint(nn.Module):
         extension (skip cells the loss never reads); the reference call passes none."""
         enc_out, pred_out = self.pre_activation(enc_out, pred_out)
         return joint_logits(enc_out, pred_out, self.ffn_out.weight, self.ffn_out.bias, logit_lengths, target_lengths,
-                            self.precision)
+                            self.precision, self.activation)

@@ -108,7 +108,7 @@ class Transducer(nn.Module):
             ep, pp = jt.pre_activation(encoder_out, predictor_out)
             loss = joint_rnnt_loss(ep, pp, jt.ffn_out.weight, jt.ffn_out.bias,
                                    rnnt_text, encoder_out_lens, rnnt_text_lengths, blank=self.blank, reduction="mean",
-                                   precision=jt.precision)
+                                   precision=jt.precision, activation=jt.activation)
             return None, loss
         if self.fused_loss and isinstance(self.joint, TransducerJoint):
             # the AMP single-term joiner keeps 16-bit logits (two ops), but a ragged batch is still cut into
@@ -231,7 +231,7 @@ class Transducer(nn.Module):
             ep, pp = self.joint.pre_activation(encoder_out, predictor_out)
             loss_td = joint_rnnt_loss(ep, pp, self.joint.ffn_out.weight, self.joint.ffn_out.bias, rnnt_text,
                                       xs_in_lens, hyps_lens.int(), blank=self.blank, reduction="none",
-                                      precision=self.joint.precision)
+                                      precision=self.joint.precision, activation=self.joint.activation)
             return loss_td * -1
         joint_out = self.joint(encoder_out, predictor_out)
         loss_td = rnnt_loss(joint_out, rnnt_text.contiguous(), xs_in_lens.contiguous(), hyps_lens.int().contiguous(),
