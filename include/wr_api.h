@@ -262,7 +262,8 @@ int wr_joint_bwd_dw_split(const float *gout_d /* [B,T,U1,V] */, const float *h_d
  *           Transducer.greedy_search (wenet/transducer/transducer.py:515-598)
  *   beam    PrefixBeamSearch.prefix_beam_search, wenet/transducer/search/prefix_beam_search.py:42-148
  *           (called from Transducer.beam_search, transducer.py:332-377)
- *   step    RNNPredictor.forward_step, wenet/transducer/predictor.py:160-200, and the joiner for
+ *   step    RNNPredictor.forward_step, wenet/transducer/predictor.py:160-200 (EmbeddingPredictor.forward_step
+ *           :325-372 and ConvPredictor.forward_step :455-481 with predictor_type 1 / 2), and the joiner for
  *           step shapes (joint.py:45-70), i.e. forward_predictor_step / forward_joint_step
  *           (transducer.py:613-629)
  *
@@ -295,6 +296,20 @@ typedef struct wr_transducer_weights {
     const float *enc_ffn_w, *enc_ffn_b;        /* joint.enc_ffn                [J, E], [J] */
     const float *pred_ffn_w, *pred_ffn_b;      /* joint.pred_ffn               [J, P], [J] */
     const float *out_w, *out_b;                /* joint.ffn_out                [V, J], [V] */
+    /* The stateless predictors of wenet/transducer/predictor.py:203-481 (not in the shipped configuration).  Their
+     * state is the embeddings of the last context_size - 1 tokens; it travels through the same cache tensors as the
+     * LSTM state: n_layers = context_size - 1 "layers" of width hidden = embed_dim = pred_dim (slot 0 oldest), the
+     * cell-state tensors are carried and ignored.  LSTM fields above are unused (may be NULL) for types 1 and 2. */
+    int32_t predictor_type;    /* 0 RNNPredictor (LSTM), 1 EmbeddingPredictor, 2 ConvPredictor */
+    int32_t context_size;      /* history_size + 1: 2..5 */
+    int32_t n_head;            /* type 1: heads of the positional weighting; n_head * context_size <= 64 */
+    int32_t pred_activation;   /* wr_activation applied after the LayerNorm */
+    float ln_eps;              /* LayerNorm epsilon */
+    int32_t reserved;
+    const float *pos_w;                        /* type 1: pos_embed.weight     [n_head, D * context_size] (bias unused) */
+    const float *ffn_w, *ffn_b;                /* type 1: ffn                  [D, D], [D] */
+    const float *norm_w, *norm_b;              /* types 1, 2: norm             [D], [D] */
+    const float *conv_w, *conv_b;              /* type 2: conv.weight [D, 1, context_size], conv.bias [D] or NULL */
 } wr_transducer_weights;
 
 typedef struct wr_decoder wr_decoder;

@@ -15,6 +15,8 @@ for modules that are absent from the image -- `typeguard`, used only for
   wenet/transducer/joint.py           TransducerJoint.forward        -> joint_ref_*.npz, joint_var_*.npz (other activations,
                                       prejoin_linear off, postjoin_linear on)
   wenet/transducer/predictor.py       RNNPredictor.forward_step ...  -> predictor_step_*.npz
+                                      EmbeddingPredictor / ConvPredictor -> predictor_var_*.npz, decode_var_*.npz (greedy
+                                      loop and PrefixBeamSearch over them, with non-tanh joiners)
   wenet/transducer/search/greedy_search copy.py  basic_greedy_search -> greedy_core_*.npz
   wenet/transducer/search/prefix_beam_search.py  PrefixBeamSearch    -> prefix_beam_*.npz
   wenet/utils/common.py               add_blank, log_add             -> common_ref.npz
@@ -178,6 +180,102 @@ def gen_predictor():
         save(f"predictor_step_{i}", toks=toks.numpy(), padding=padding.numpy(), outs=np.stack(outs), m=np.stack(ms),
              c=np.stack(cs), full_first_lane=full, n_layers=np.array(L), hidden=np.array(H),
              **{"w_" + k: v for k, v in sd(pred).items()})
+
+
+def gen_predictor_variants():
+    """EmbeddingPredictor / ConvPredictor (predictor.py:203-481): forward_step sequences and the training forward."""
+    from wenet.transducer.predictor import ConvPredictor, EmbeddingPredictor
+    cases = [dict(kind="embedding", V=40, D=16, n_head=4, history=2, act="swish", bias=False, N=3, steps=7),
+             dict(kind="embedding", V=30, D=24, n_head=2, history=4, act="gelu", bias=True, N=2, steps=6),
+             dict(kind="conv", V=40, D=16, history=2, act="relu", bias=False, N=3, steps=7),
+             dict(kind="conv", V=25, D=40, history=1, act="tanh", bias=True, N=1, steps=5)]
+    for i, c in enumerate(cases):
+        torch.manual_seed(60 + i)
+        if c["kind"] == "embedding":
+            pred = EmbeddingPredictor(c["V"], c["D"], 0.1, c["n_head"], c["history"], c["act"], c["bias"]).eval()
+        else:
+            pred = ConvPredictor(c["V"], c["D"], 0.1, c["history"], c["act"], c["bias"]).eval()
+        with torch.no_grad():
+            pred.norm.weight.add_(torch.randn(c["D"]) * 0.3)
+            pred.norm.bias.add_(torch.randn(c["D"]) * 0.3)
+        N, steps = c["N"], c["steps"]
+        toks = torch.randint(0, c["V"], (steps, N))
+        cache = pred.init_state(N, device=torch.device("cpu"))
+        outs, hist = [], []
+        with torch.no_grad():
+            for s_ in range(steps):
+                o, cache = pred.forward_step(toks[s_].reshape(N, 1), torch.zeros(N, 1), cache)
+                outs.append(o.numpy()); hist.append(cache[0].numpy())
+            full = pred(toks.t().contiguous()).numpy()                  # (N, steps, D): equals the step outputs
+        split = pred.batch_to_cache(cache)
+        assert torch.equal(pred.cache_to_batch(split)[0], cache[0])
+        save(f"predictor_var_{i}", kind=np.array(c["kind"]), history=np.array(c["history"]), n_head=np.array(c.get("n_head", 0)),
+             act=np.array(c["act"]), bias=np.array(c["bias"]), toks=toks.numpy(), outs=np.stack(outs), hist=np.stack(hist),
+             full=full, **{"w_" + k: v for k, v in sd(pred).items()})
+
+
+def build_variant_modules(seed, kind, V, E, D, J, joint_act, blank_bias, weight_scale=2.0):
+    from wenet.transducer.joint import TransducerJoint
+    from wenet.transducer.predictor import ConvPredictor, EmbeddingPredictor
+    from wenet.transformer.ctc import CTC
+    g = torch.Generator().manual_seed(seed)
+    pred = (EmbeddingPredictor(V, D, 0.1, 4, 2, "swish") if kind == "embedding" else ConvPredictor(V, D, 0.1, 2, "relu", True)).eval()
+    joint = TransducerJoint(V, E, D, J, activation=joint_act).eval()
+    ctc = CTC(V, E).eval()
+    with torch.no_grad():
+        for m in (pred, joint, ctc):
+            for n_, p_ in m.named_parameters():
+                if n_.startswith("norm."):
+                    continue                                   # LayerNorm keeps weight 1 / bias 0
+                p_.copy_(dyadic(p_.shape, g, scale=16, lim=0.5) * weight_scale)
+        joint.ffn_out.bias[0] += blank_bias
+    return pred, joint, ctc
+
+
+def gen_decode_variants():
+    """The reference's greedy loop and PrefixBeamSearch over the stateless predictors and a non-tanh joiner."""
+    path = os.path.join(REF, "wenet", "transducer", "search", "greedy_search copy.py")
+    spec = importlib.util.spec_from_file_location("ref_greedy_core", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    from wenet.transducer.search.prefix_beam_search import PrefixBeamSearch
+    V, E, D, J = 64, 16, 16, 32
+    cases = [dict(kind="embedding", joint_act="relu", seed=700, T=30, n_steps=64, blank_bias=6.0, beam=4),
+             dict(kind="conv", joint_act="swish", seed=701, T=40, n_steps=3, blank_bias=4.0, beam=5),
+             dict(kind="conv", joint_act="tanh", seed=702, T=25, n_steps=64, blank_bias=5.0, beam=8)]
+    for i, c in enumerate(cases):
+        for attempt in range(300):
+            seed = c["seed"] + 1000 * attempt
+            pred, joint, ctc = build_variant_modules(seed, c["kind"], V, E, D, J, c["joint_act"], c["blank_bias"])
+            model = types.SimpleNamespace(blank=0, predictor=pred, joint=joint, context_bias=PassThroughBias())
+            g = torch.Generator().manual_seed(seed + 7)
+            enc = dyadic((1, c["T"], E), g, scale=8, lim=2.0)
+            with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+                hyps = mod.basic_greedy_search(model, enc, torch.tensor(c["T"]), n_steps=c["n_steps"])
+            min_margin = replay_margin(pred, joint, enc, c["T"], c["n_steps"], hyps[0])
+            if not (margins_ok(min_margin) and len(hyps[0]) >= 4):
+                continue
+            bs = PrefixBeamSearch(GivenEncoder(enc), pred, joint, ctc, 0)
+            with torch.no_grad():
+                beam, _ = bs.prefix_beam_search(torch.zeros(1, c["T"], 80), torch.tensor([c["T"]]), beam_size=c["beam"])
+            scores = np.array([s_.score for s_ in beam], dtype=np.float64)
+            if len(scores) > 1 and np.abs(np.diff(scores)).min() < 1e-3:
+                continue
+            break
+        else:
+            raise AssertionError(f"no seed with clear margins for variant case {i}")
+        maxlen = max(len(s_.hyp) for s_ in beam)
+        bh = np.full((len(beam), maxlen), -1, dtype=np.int64)
+        for k, s_ in enumerate(beam):
+            bh[k, :len(s_.hyp)] = s_.hyp
+        print(f"  variant case {i}: seed {seed}, greedy {len(hyps[0])} tokens (margin {min_margin:.4f}), beam lens "
+              f"{[len(s_.hyp) for s_ in beam]}")
+        save(f"decode_var_{i}", kind=np.array(c["kind"]), joint_act=np.array(c["joint_act"]), enc=enc.numpy(), T=np.array(c["T"]),
+             n_steps=np.array(c["n_steps"]), hyp=np.array(hyps[0], dtype=np.int64), min_margin=np.array(min_margin),
+             beam=np.array(c["beam"]), beam_hyps=bh, beam_lens=np.array([len(s_.hyp) for s_ in beam]), beam_scores=scores,
+             beam_hist=np.stack([s_.cache[0].numpy() for s_ in beam]),
+             **{"pred_" + k: v for k, v in sd(pred).items()}, **{"joint_" + k: v for k, v in sd(joint).items()},
+             **{"ctc_" + k: v for k, v in sd(ctc).items()})
 
 
 # --------------------------------------------------------- decode models --
@@ -786,8 +884,10 @@ if __name__ == "__main__":
     gen_joint()
     gen_joint_variants()
     gen_predictor()
+    gen_predictor_variants()
     gen_greedy()
     gen_beam()
+    gen_decode_variants()
     gen_ctc_decode()
     gen_ctc_align()
     gen_greedy_fork()

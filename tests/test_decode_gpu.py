@@ -114,6 +114,69 @@ def test_greedy_batched_streams_equal_single_streams():
             assert hyps[i][:3] == ref[:3]
 
 
+def build_history_predictor(d, prefix, kind, history, n_head=4, act=None, bias=None):
+    import wenet_celoss_amd as w
+    pw = sub(d, prefix)
+    V, D = pw["embed.weight"].shape
+    if kind == "embedding":
+        pred = w.EmbeddingPredictor(V, D, 0.1, n_head, history, act or "swish", "pos_embed.bias" in pw)
+    else:
+        pred = w.ConvPredictor(V, D, 0.1, history, act or "relu", "conv.bias" in pw)
+    pred.load_state_dict({k: torch.tensor(v) for k, v in pw.items()})
+    return pred.to(DEV).eval()
+
+
+@pytest.mark.parametrize("path", names("predictor_var_*.npz"))
+def test_stateless_predictor_step_matches_reference(path):
+    """EmbeddingPredictor / ConvPredictor forward_step on the device (history in the decoder's state slots) against the
+    reference modules' step outputs and caches (predictor.py:325-372, :455-481), plus the training forward."""
+    d = np.load(path)
+    pred = build_history_predictor(d, "w_", str(d["kind"]), int(d["history"]), int(d["n_head"]), str(d["act"]))
+    steps, N = d["toks"].shape
+    cache = pred.init_state(N, device=torch.device(DEV))
+    assert cache[0].shape == (N, int(d["history"]), pred.embed_size)
+    for s in range(steps):
+        out, cache = pred.forward_step(torch.tensor(d["toks"][s], device=DEV).reshape(N, 1), torch.zeros(N, 1, device=DEV), cache)
+        np.testing.assert_allclose(out.cpu().numpy(), d["outs"][s], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(cache[0].cpu().numpy(), d["hist"][s], rtol=0, atol=0)     # embeddings, copied
+    back = pred.cache_to_batch(pred.batch_to_cache(cache))
+    assert torch.equal(back[0], cache[0])
+    full = pred(torch.tensor(d["toks"].T.copy(), device=DEV))
+    np.testing.assert_allclose(full.detach().cpu().numpy(), d["full"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+@pytest.mark.parametrize("path", names("decode_var_*.npz"))
+def test_stateless_predictors_and_other_joiner_activations_decode_like_the_reference(path, use_graph):
+    """Greedy loop and PrefixBeamSearch of the reference over EmbeddingPredictor / ConvPredictor with relu / swish / tanh
+    joiners: same tokens, same n-best order and scores."""
+    import wenet_celoss_amd as w
+    d = np.load(path)
+    pred = build_history_predictor(d, "pred_", str(d["kind"]), 2)
+    jw = {k: v for k, v in sub(d, "joint_").items() if k != "act"}          # "joint_act" is the activation's name
+    J, E = jw["enc_ffn.weight"].shape
+    V = jw["ffn_out.weight"].shape[0]
+    joint = w.TransducerJoint(V, E, pred.embed_size, J, activation=str(d["joint_act"])).to(DEV).eval()
+    joint.load_state_dict({k: torch.tensor(v) for k, v in jw.items()})
+    ctc = w.CTC(V, E).to(DEV).eval()
+    ctc.load_state_dict({k[4:]: torch.tensor(d[k]) for k in d.files if k.startswith("ctc_ctc_lo")})
+    enc = torch.tensor(d["enc"], device=DEV)
+    T, n_steps = int(d["T"]), int(d["n_steps"])
+    model = types.SimpleNamespace(blank=0, predictor=pred, joint=joint)
+    from wenet_celoss_amd.decoder import DecoderCache
+    model._decoder_cache = DecoderCache()
+    dec = model._decoder_cache.get(pred, joint, lanes=1, utts=1, tmax=T, max_hyp=T * n_steps, beam=1)
+    dec.set_graph(use_graph)
+    hyps = w.basic_greedy_search(model, enc, torch.tensor(T), n_steps=n_steps)
+    assert hyps == [list(d["hyp"])]
+    bs = w.PrefixBeamSearch(None, pred, joint, ctc, 0)
+    beam = bs.search_encoded(enc, torch.tensor([T], dtype=torch.int32), beam_size=int(d["beam"]))[0]
+    assert len(beam) == len(d["beam_scores"])
+    for k, sq in enumerate(beam):
+        assert sq.hyp == list(d["beam_hyps"][k][: d["beam_lens"][k]]), k
+        assert sq.score == pytest.approx(d["beam_scores"][k], rel=1e-5)
+
+
 @pytest.mark.parametrize("path", names("prefix_beam_*.npz"))
 def test_prefix_beam_matches_reference(path):
     import wenet_celoss_amd as w

@@ -1,8 +1,10 @@
 """CPU tests of the host-side logic: helpers pinned against the reference's own
 outputs (tests/golden/common_ref.npz), shard arithmetic, and the N>1 path with
 a world-size-2 gloo group."""
+import glob
 import os
 import sys
+from typing import List, Tuple
 
 import numpy as np
 import pytest
@@ -217,6 +219,19 @@ def test_joiner_and_predictor_variants_accepted_or_refused_loudly():
     p = w.RNNPredictor(10, 8, 8, 0.1, 8, 1)
     with pytest.raises(NotImplementedError, match="postjoin_linear"):
         DeviceDecoder(p, j2, 1, 1, 4)
+    # the stateless predictors keep the reference's parameter names and state layout (predictor.py:203-481)
+    e = w.EmbeddingPredictor(10, 8, 0.1, 4, history_size=2)
+    c = w.ConvPredictor(10, 8, 0.1, history_size=3, bias=True)
+    assert set(e.state_dict()) == {"pos_embed.weight", "embed.weight", "ffn.weight", "ffn.bias", "norm.weight", "norm.bias"}
+    assert set(c.state_dict()) == {"embed.weight", "conv.weight", "conv.bias", "norm.weight", "norm.bias"}
+    assert e.init_state(3, torch.device("cpu"))[0].shape == (3, 2, 8) and c.init_state(2, torch.device("cpu"))[0].shape == (2, 3, 8)
+    x = torch.randint(0, 10, (2, 6))
+    assert e.eval()(x).shape == (2, 6, 8) and c.eval()(x).shape == (2, 6, 8)
+    assert len(c.batch_to_cache(c.init_state(2, torch.device("cpu")))) == 2
+    with pytest.raises(RuntimeError, match="HIP device|no CPU path"):          # forward_step is the device path
+        e.forward_step(x[:, :1], torch.zeros(2, 1), e.init_state(2, torch.device("cpu")))
+    with pytest.raises(NotImplementedError, match="base predictor"):
+        w.PredictorBase().init_state(1, torch.device("cpu"))
     e, pp = j2.pre_activation(torch.randn(2, 3, 8), torch.randn(2, 4, 8))
     assert e.shape == (2, 3, 8) and pp.shape == (2, 4, 8)
 
@@ -354,3 +369,42 @@ def test_joint_precision_selection(monkeypatch):
         assert m.precision == prec
         with pytest.raises(RuntimeError, match="HIP device"):
             m(torch.zeros(1, 2, 4), torch.zeros(1, 3, 4))
+
+
+class _StepExport(torch.nn.Module):
+    """What Transducer.forward_predictor_step does for the runtime: an exported method that calls forward_step."""
+
+    def __init__(self, p):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.p(x)
+
+    @torch.jit.export
+    def step(self, x: torch.Tensor, pad: torch.Tensor, cache: List[torch.Tensor]) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+        return self.p.forward_step(x, pad, cache)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "predictor_var_*.npz"))))
+def test_stateless_predictors_script_and_reproduce_the_reference_steps(path):
+    """torch.jit.script (train.py:203-205, export_jit.py) over EmbeddingPredictor / ConvPredictor: the exported step body
+    and the training forward reproduce the reference modules' outputs stored in the fixtures (CPU, library ops)."""
+    import wenet_celoss_amd as w
+    d = np.load(path)
+    pw = {k[2:]: torch.tensor(d[k]) for k in d.files if k.startswith("w_")}
+    V, D = pw["embed.weight"].shape
+    if str(d["kind"]) == "embedding":
+        m = w.EmbeddingPredictor(V, D, 0.1, int(d["n_head"]), int(d["history"]), str(d["act"]), "pos_embed.bias" in pw)
+    else:
+        m = w.ConvPredictor(V, D, 0.1, int(d["history"]), str(d["act"]), "conv.bias" in pw)
+    m.load_state_dict(pw)
+    m.eval()
+    sm = torch.jit.script(_StepExport(m))
+    steps, N = d["toks"].shape
+    cache = m.init_state(N, torch.device("cpu"))
+    for s_ in range(steps):
+        out, cache = sm.step(torch.tensor(d["toks"][s_]).reshape(N, 1), torch.zeros(N, 1), cache)
+        np.testing.assert_allclose(out.detach().numpy(), d["outs"][s_], rtol=1e-5, atol=1e-6)
+        np.testing.assert_array_equal(cache[0].detach().numpy(), d["hist"][s_])
+    np.testing.assert_allclose(sm(torch.tensor(d["toks"].T.copy())).detach().numpy(), d["full"], rtol=1e-5, atol=1e-6)

@@ -74,12 +74,10 @@ def test_install_swaps_classes_in_stub_tree(tmp_path):
         assert type(m) is w.Transducer and type(m.joint) is w.TransducerJoint and type(m.ctc) is w.CTC
         assert type(m.predictor) is w.RNNPredictor
         import wenet.transducer.predictor as p
-        try:
-            p.ConvPredictor(3)
-        except NotImplementedError as e:
-            assert "RNNPredictor" in str(e)
-        else:
-            raise AssertionError("ConvPredictor placeholder must refuse")
+        assert p.ConvPredictor is w.ConvPredictor and p.EmbeddingPredictor is w.EmbeddingPredictor
+        assert issubclass(p.RNNPredictor, p.PredictorBase)
+        c = p.ConvPredictor(7, 4, 0.1)
+        assert c.context_size == 3 and c.conv.weight.shape == (4, 1, 3)
         patch.uninstall()
         assert not patch.installed()
         print("OK")

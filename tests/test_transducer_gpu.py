@@ -98,6 +98,52 @@ def test_forward_dict_and_gradients_match_float64():
         assert err <= 1e-4 * scale + 1e-9, (name, err, scale)
 
 
+@pytest.mark.parametrize("kind,act", [("embedding", "gelu"), ("conv", "relu"), ("conv", "selu")])
+def test_stateless_predictors_and_other_activations_train_like_float64(kind, act):
+    """Transducer.forward with EmbeddingPredictor / ConvPredictor (predictor.py:203-481) and a non-tanh joiner
+    (joint.py:25): the loss and every parameter gradient against a float64 evaluation of the same modules (CPU, library
+    ops; the joiner by its formula; the RNN-T loss through the oracle), at the 1e-4 bar."""
+    import copy
+    import wenet_celoss_amd as w
+    torch.manual_seed(5)
+    V, E, D, J = 23, 12, 10, 16
+    pred = w.EmbeddingPredictor(V, D, 0.0, 2, 2) if kind == "embedding" else w.ConvPredictor(V, D, 0.0, 2, bias=True)
+    m = w.Transducer(V, 0, TinyEncoder(8, E), pred, w.TransducerJoint(V, E, D, J, activation=act), ctc=w.CTC(V, E),
+                     ctc_weight=0.0, transducer_weight=1.0, hw_weight=0.0).to(DEV)
+    B = 3
+    g = torch.Generator().manual_seed(2)
+    speech = torch.randn(B, 11, 8, generator=g).to(DEV)
+    slen = torch.tensor([11, 7, 9], dtype=torch.int32, device=DEV)
+    text = torch.tensor([[3, 5, 2, 9], [4, 4, -1, -1], [7, 1, 6, -1]], device=DEV)
+    tlen = torch.tensor([4, 2, 3], dtype=torch.int32, device=DEV)
+    out = m(speech, slen, text, tlen)
+    out["loss"].backward()
+
+    ref = copy.deepcopy(m).cpu().double()
+    enc, _ = ref.encoder(speech.double().cpu(), slen.cpu())
+    ys_in = torch.cat([torch.zeros(B, 1, dtype=torch.long), torch.where(text.cpu() < 0, 0, text.cpu())], 1)
+    po = ref.predictor(ys_in)
+    ep, pp = ref.joint.enc_ffn(enc), ref.joint.pred_ffn(po)
+    logits = ref.joint.ffn_out(ref.joint.activatoin(ep[:, :, None] + pp[:, None]))
+    ytxt = np.where(text.cpu().numpy() < 0, 0, text.cpu().numpy()).astype(np.int32)
+    rc, rg = oracle.rnnt_loss_f64(logits.detach().float().numpy(), ytxt, slen.cpu().numpy(), tlen.cpu().numpy())
+    assert out["loss"].item() == pytest.approx(rc.mean(), rel=1e-5)
+    ref.zero_grad()
+    (logits * torch.tensor(rg, dtype=torch.double) / B).sum().backward()
+    checked = 0
+    for (name, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        if q.grad is None:                       # pos_embed.bias-like parameters the forward never touches
+            continue
+        scale = float(q.grad.abs().max())
+        assert float((p.grad.double().cpu() - q.grad).abs().max()) <= 1e-4 * scale + 1e-9, name
+        checked += 1
+    assert checked >= 9
+    # and the decoders take the same modules
+    hyps, _ = m.greedy_search(speech[:1], slen[:1])
+    best, _ = m.beam_search(speech[:1], slen[:1], beam_size=3)
+    assert isinstance(hyps[0], list) and isinstance(best, list)
+
+
 def test_decode_wrappers_shapes_and_consistency():
     import wenet_celoss_amd as w
     m = build().eval()

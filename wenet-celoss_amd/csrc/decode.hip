@@ -51,6 +51,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kMaxLayers = WR_MAX_LSTM_LAYERS;
+enum PredictorType { kPredLstm = 0, kPredEmbedding = 1, kPredConv = 2 };
 constexpr int kMaxLanes = 1024;      // streams (greedy) or utterances x beam decoded together
 constexpr int kMaxBeam = 16;
 constexpr int kMaxLook = 4;          // greedy look-ahead: encoder frames evaluated per micro-step against one predictor state
@@ -63,6 +64,8 @@ struct Dims {
     int G4p, Vp;                  // N dimensions: 4H padded to 32, V padded to 256
     int NL, NLp;                  // lanes, lanes padded to 32
     int act;                      // joiner activation (wr_activation)
+    int ptype, ctx, heads, pact;  // predictor: 0 LSTM / 1 embedding / 2 conv; context size, heads, activation (types 1, 2)
+    float ln_eps;
 };
 
 // Device-resident decoder state; all pointers are carved from the caller's workspace.
@@ -74,6 +77,11 @@ struct DevState {
     float *wt_ih[kMaxLayers], *wt_hh[kMaxLayers], *bsum[kMaxLayers];
     float *proj_wt, *predffn_wt, *encffn_wt, *out_wt;
     const float *proj_b, *predffn_b, *encffn_b, *out_b;
+    // stateless predictors (predictor.py:203-481): the LSTM slots above stay empty; the "LSTM state" cache_hT[l] holds
+    // the embedding of history slot l (l = 0 oldest), L = ctx - 1, H = D
+    const float *pos_w, *pffn_b, *pnorm_w, *pnorm_b, *conv_w, *conv_b;
+    float *pffn_wt;               // [Dp][up(D,32)] k-major ffn weight (type 1)
+    float *combT, *ffnT;          // [Dp][NLp] head-weighted context sum / ffn output (type 1)
     // per-call inputs
     const float *enc;             // [n_utt, T, E]
     const int32_t *enc_lens;      // [n_utt]
@@ -432,6 +440,145 @@ __device__ __forceinline__ void write_embedding_column(DevState *s, int n, int t
 {
     const Dims &d = s->d;
     for (int k = threadIdx.x; k < d.D; k += blockDim.x) s->xT[(size_t)k * d.NLp + n] = s->embed[(size_t)tok * d.D + k];
+}
+
+// ---------------------------------------------------- stateless predictors --
+// EmbeddingPredictor.forward_step (predictor.py:325-372) and ConvPredictor.forward_step (:455-481), one lane per
+// workgroup.  context = [history slots 0 .. ctx-2 (cache_hT), embedding of the lane's token (xT)];
+//   embedding:  weight[h][c] = sum_e context[c][e] * pos[h][e][c]        (pos = pos_embed.weight viewed [heads, D, ctx])
+//               comb[e] = sum_h sum_c weight[h][c] * context[c][e] / (heads * ctx)   -> ffn -> LayerNorm -> activation
+//   conv:       comb[e] = sum_c context[c][e] * conv_w[e][c] (+ conv_b[e])            -> LayerNorm -> activation
+// The new history is context[1 ..] (new_hT): the search kernels commit it on an emission exactly like an LSTM state.
+// STAGE 0: embedding predictor, context weighting -> combT (+ new history); the ffn runs as a lane GEMM in between;
+// STAGE 1: LayerNorm + activation of ffnT -> outT;  STAGE 2: conv predictor, all of it.
+constexpr int kCtxThreads = 256;
+constexpr int kCtxPer = 4;                    // embedding width <= 1024
+constexpr int kMaxCtx = WR_MAX_LSTM_LAYERS + 1;
+
+__device__ __forceinline__ float ctx_block_sum(float v, float *red)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// LayerNorm (biased variance, as torch.nn.LayerNorm) + activation of this thread's elements e = tid + 256 j
+__device__ __forceinline__ void ctx_norm_act_store(const DevState &S, const float (&x)[kCtxPer], int n, float *red)
+{
+    const Dims &d = S.d;
+    const int tid = threadIdx.x;
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < kCtxPer; ++j) part += (tid + kCtxThreads * j < d.D) ? x[j] : 0.f;
+    const float mean = ctx_block_sum(part, red) / (float)d.D;
+    part = 0.f;
+#pragma unroll
+    for (int j = 0; j < kCtxPer; ++j) {
+        const float t = x[j] - mean;
+        part += (tid + kCtxThreads * j < d.D) ? t * t : 0.f;
+    }
+    const float rstd = 1.f / sqrtf(ctx_block_sum(part, red) / (float)d.D + d.ln_eps);
+#pragma unroll
+    for (int j = 0; j < kCtxPer; ++j) {
+        const int e = tid + kCtxThreads * j;
+        if (e < d.D) S.outT[(size_t)e * d.NLp + n] = act_value(d.pact, (x[j] - mean) * rstd * S.pnorm_w[e] + S.pnorm_b[e]);
+    }
+}
+
+template <int STAGE>
+__global__ __launch_bounds__(kCtxThreads) void ctx_predictor_kernel(DevState *sp)
+{
+    const DevState &S = *sp;
+    const Dims &d = S.d;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    if (!(S.lane_active[n] && S.need_pred[n])) return;      // predicated per lane, like the LSTM cell epilogue
+    __shared__ float red[4];
+    __shared__ float part[64 * 4];
+    const int D = d.D, ctx = d.ctx;
+    const size_t ls = (size_t)d.Hp * d.NLp;
+    if (STAGE == 1) {
+        float x[kCtxPer];
+#pragma unroll
+        for (int j = 0; j < kCtxPer; ++j) {
+            const int e = tid + kCtxThreads * j;
+            x[j] = e < D ? S.ffnT[(size_t)e * d.NLp + n] : 0.f;
+        }
+        ctx_norm_act_store(S, x, n, red);
+        return;
+    }
+    float cin[kMaxCtx][kCtxPer];
+#pragma unroll
+    for (int c = 0; c < kMaxCtx; ++c)
+#pragma unroll
+        for (int j = 0; j < kCtxPer; ++j) {
+            const int e = tid + kCtxThreads * j;
+            float v = 0.f;
+            if (c < ctx && e < D) v = c < ctx - 1 ? S.cache_hT[(size_t)c * ls + (size_t)e * d.NLp + n] : S.xT[(size_t)e * d.NLp + n];
+            cin[c][j] = v;
+        }
+    // new history = context[1 ..]
+#pragma unroll
+    for (int c = 1; c < kMaxCtx; ++c)
+#pragma unroll
+        for (int j = 0; j < kCtxPer; ++j) {
+            const int e = tid + kCtxThreads * j;
+            if (c < ctx && e < D) S.new_hT[(size_t)(c - 1) * ls + (size_t)e * d.NLp + n] = cin[c][j];
+        }
+    float o[kCtxPer];
+    if (STAGE == 0) {
+        const int heads = d.heads;
+#pragma unroll
+        for (int c = 0; c < kMaxCtx; ++c) {
+            if (c >= ctx) continue;
+            for (int h = 0; h < heads; ++h) {
+                float p = 0.f;
+#pragma unroll
+                for (int j = 0; j < kCtxPer; ++j) {
+                    const int e = tid + kCtxThreads * j;
+                    if (e < D) p += cin[c][j] * S.pos_w[((size_t)h * D + e) * ctx + c];
+                }
+                p = wave_sum(p);
+                if ((tid & 63) == 0) part[(h * ctx + c) * 4 + (tid >> 6)] = p;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kCtxPer; ++j) o[j] = 0.f;
+        for (int h = 0; h < heads; ++h) {                     // per head: weight[h] @ context, then the sum over heads
+            float t[kCtxPer];
+#pragma unroll
+            for (int j = 0; j < kCtxPer; ++j) t[j] = 0.f;
+#pragma unroll
+            for (int c = 0; c < kMaxCtx; ++c) {
+                if (c >= ctx) continue;
+                const float *q = part + (h * ctx + c) * 4;
+                const float w = q[0] + q[1] + q[2] + q[3];
+#pragma unroll
+                for (int j = 0; j < kCtxPer; ++j) t[j] += w * cin[c][j];
+            }
+#pragma unroll
+            for (int j = 0; j < kCtxPer; ++j) o[j] += t[j];
+        }
+        const float inv = 1.f / (float)(heads * ctx);
+#pragma unroll
+        for (int j = 0; j < kCtxPer; ++j) {
+            const int e = tid + kCtxThreads * j;
+            if (e < D) S.combT[(size_t)e * d.NLp + n] = o[j] * inv;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kCtxPer; ++j) {
+            const int e = tid + kCtxThreads * j;
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < kMaxCtx; ++c)
+                if (c < ctx && e < D) a += cin[c][j] * S.conv_w[(size_t)e * ctx + c];
+            o[j] = (e < D && S.conv_b) ? a + S.conv_b[e] : a;
+        }
+        ctx_norm_act_store(S, o, n, red);
+    }
 }
 
 // ---------------------------------------------------------------- greedy --
@@ -1446,6 +1593,8 @@ size_t carve(const wr_transducer_weights *w, int max_lanes, int max_utt, int Tma
     d.V = w->vocab_size; d.E = w->enc_dim; d.P = w->pred_dim; d.D = w->embed_dim; d.H = w->hidden; d.L = w->n_layers;
     d.J = w->join_dim;
     d.act = w->activation;
+    d.ptype = w->predictor_type; d.ctx = w->context_size; d.heads = w->n_head; d.pact = w->pred_activation;
+    d.ln_eps = w->ln_eps;
     auto up = [](int x, int m) { return (x + m - 1) / m * m; };
     d.Dp = up(d.D, 16); d.Hp = up(d.H, 16); d.Pp = up(d.P, 16); d.Jp = up(d.J, 16);   // K: 8 waves x k-pairs
     d.G4p = 4 * d.Hp;                                      // 32-column tiles = i,f,g,o of 8 hidden units
@@ -1457,14 +1606,19 @@ size_t carve(const wr_transducer_weights *w, int max_lanes, int max_utt, int Tma
     s.d = d;
     DevState *devp = c.take<DevState>(1);
     const size_t zero_begin = align_up(c.off, 256);       // everything from here to zero_end is zero-filled at create
-    for (int l = 0; l < d.L; ++l) {
+    for (int l = 0; l < d.L && d.ptype == kPredLstm; ++l) {
         const int in_p = l == 0 ? d.Dp : d.Hp;
         s.wt_ih[l] = c.take<float>((size_t)in_p * d.G4p);
         s.wt_hh[l] = c.take<float>((size_t)d.Hp * d.G4p);
         s.bsum[l] = c.take<float>((size_t)d.G4p);
     }
     const int Pn = up(d.P, 32), Jn = up(d.J, 32);
-    s.proj_wt = c.take<float>((size_t)d.Hp * Pn);
+    if (d.ptype == kPredLstm) s.proj_wt = c.take<float>((size_t)d.Hp * Pn);
+    if (d.ptype == kPredEmbedding) {
+        s.pffn_wt = c.take<float>((size_t)d.Dp * up(d.D, 32));
+        s.combT = c.take<float>((size_t)d.Dp * d.NLp);
+        s.ffnT = c.take<float>((size_t)d.Dp * d.NLp);
+    }
     s.predffn_wt = c.take<float>((size_t)d.Pp * Jn);
     s.encffn_wt = c.take<float>((size_t)d.E * d.J);
     s.out_wt = c.take<float>((size_t)d.Jp * d.Vp);
@@ -1513,10 +1667,32 @@ int check_weights(const wr_transducer_weights *w)
                WR_EUNSUPPORTED, "decoder: a layer dimension exceeds 1024");
     WR_REQUIRE(w->vocab_size * sizeof(float) <= 64 * 1024, WR_EUNSUPPORTED, "decoder: vocab_size=%d exceeds 16384",
                w->vocab_size);
-    WR_REQUIRE(w->embed && w->proj_w && w->proj_b && w->enc_ffn_w && w->enc_ffn_b && w->pred_ffn_w && w->pred_ffn_b &&
-                   w->out_w && w->out_b, WR_EINVAL, "decoder: null weight pointer");
-    for (int l = 0; l < w->n_layers; ++l)
-        WR_REQUIRE(w->w_ih[l] && w->w_hh[l] && w->b_ih[l] && w->b_hh[l], WR_EINVAL, "decoder: null LSTM weight (layer %d)", l);
+    WR_REQUIRE(w->embed && w->enc_ffn_w && w->enc_ffn_b && w->pred_ffn_w && w->pred_ffn_b && w->out_w && w->out_b, WR_EINVAL,
+               "decoder: null weight pointer");
+    WR_REQUIRE(w->predictor_type >= kPredLstm && w->predictor_type <= kPredConv, WR_EINVAL, "decoder: predictor_type %d",
+               w->predictor_type);
+    if (w->predictor_type == kPredLstm) {
+        WR_REQUIRE(w->proj_w && w->proj_b, WR_EINVAL, "decoder: null weight pointer");
+        for (int l = 0; l < w->n_layers; ++l)
+            WR_REQUIRE(w->w_ih[l] && w->w_hh[l] && w->b_ih[l] && w->b_hh[l], WR_EINVAL, "decoder: null LSTM weight (layer %d)", l);
+        return WR_OK;
+    }
+    // stateless predictors: the token history rides in the LSTM-state slots
+    WR_REQUIRE(w->context_size >= 2 && w->context_size <= kMaxCtx && w->n_layers == w->context_size - 1, WR_EUNSUPPORTED,
+               "decoder: context_size=%d (history_size + 1) must be 2..%d with n_layers = context_size - 1 (got %d)",
+               w->context_size, kMaxCtx, w->n_layers);
+    WR_REQUIRE(w->hidden == w->embed_dim && w->pred_dim == w->embed_dim, WR_EINVAL,
+               "decoder: a stateless predictor has hidden = pred_dim = embed_dim");
+    WR_REQUIRE(w->pred_activation >= WR_ACT_TANH && w->pred_activation <= WR_ACT_GELU, WR_EINVAL,
+               "decoder: pred_activation code %d is not a wr_activation", w->pred_activation);
+    WR_REQUIRE(w->ln_eps > 0.f && w->norm_w && w->norm_b, WR_EINVAL, "decoder: LayerNorm weights / epsilon missing");
+    if (w->predictor_type == kPredEmbedding) {
+        WR_REQUIRE(w->n_head >= 1 && w->n_head * w->context_size <= 64, WR_EUNSUPPORTED,
+                   "decoder: n_head * context_size = %d exceeds 64", w->n_head * w->context_size);
+        WR_REQUIRE(w->pos_w && w->ffn_w && w->ffn_b, WR_EINVAL, "decoder: null EmbeddingPredictor weight");
+    } else {
+        WR_REQUIRE(w->conv_w, WR_EINVAL, "decoder: null ConvPredictor weight");
+    }
     return WR_OK;
 }
 
@@ -1546,6 +1722,19 @@ void launch_predictor(wr_decoder *h, int n_lanes, hipStream_t st)
     const DevState &s = h->host;
     auto up = [](int x, int m) { return (x + m - 1) / m * m; };
     const size_t ls = (size_t)d.Hp * d.NLp;
+    if (d.ptype == kPredEmbedding) {            // context weighting -> ffn (lane GEMM) -> LayerNorm + activation
+        hipLaunchKernelGGL(ctx_predictor_kernel<0>, dim3(n_lanes), dim3(kCtxThreads), 0, st, h->dev);
+        GemmArgs g{};
+        g.A0 = s.combT; g.B0 = s.pffn_wt; g.K0 = d.Dp;
+        g.lda = d.NLp; g.ldb = up(d.D, 32); g.bias = s.pffn_b; g.C = s.ffnT; g.ldc = d.NLp; g.N = d.D; g.n_lanes = n_lanes;
+        launch_gemm<kEpiKMajor>(g, up(d.D, 32), n_lanes, st);
+        hipLaunchKernelGGL(ctx_predictor_kernel<1>, dim3(n_lanes), dim3(kCtxThreads), 0, st, h->dev);
+        return;
+    }
+    if (d.ptype == kPredConv) {
+        hipLaunchKernelGGL(ctx_predictor_kernel<2>, dim3(n_lanes), dim3(kCtxThreads), 0, st, h->dev);
+        return;
+    }
     for (int l = 0; l < d.L; ++l) {
         GemmArgs g{};
         g.A0 = l == 0 ? s.xT : s.new_hT + (size_t)(l - 1) * ls;  g.B0 = s.wt_ih[l];  g.K0 = l == 0 ? d.Dp : d.Hp;
@@ -1650,14 +1839,17 @@ extern "C" int wr_decoder_create(const wr_transducer_weights *w, int max_lanes, 
     s.embed = w->embed; s.proj_b = w->proj_b; s.predffn_b = w->pred_ffn_b; s.encffn_b = w->enc_ffn_b; s.out_b = w->out_b;
     (void)hipMemsetAsync(h->ws + h->zero_range[0], 0, h->zero_range[1] - h->zero_range[0], st);
     auto up = [](int x, int m) { return (x + m - 1) / m * m; };
-    for (int l = 0; l < d.L; ++l) {
+    s.pos_w = w->pos_w; s.pffn_b = w->ffn_b; s.pnorm_w = w->norm_w; s.pnorm_b = w->norm_b; s.conv_w = w->conv_w;
+    s.conv_b = w->conv_b;
+    if (d.ptype == kPredEmbedding) launch_transpose(w->ffn_w, d.D, d.D, up(d.D, 32), d.Dp, s.pffn_wt, st);
+    for (int l = 0; l < d.L && d.ptype == kPredLstm; ++l) {
         const int in_dim = l == 0 ? d.D : d.H, in_p = l == 0 ? d.Dp : d.Hp;
         hipLaunchKernelGGL(lstm_weight_prep_kernel, dim3(256), dim3(256), 0, st, w->w_ih[l], d.H, d.Hp, in_dim, in_p, s.wt_ih[l]);
         hipLaunchKernelGGL(lstm_weight_prep_kernel, dim3(256), dim3(256), 0, st, w->w_hh[l], d.H, d.Hp, d.H, d.Hp, s.wt_hh[l]);
         hipLaunchKernelGGL(lstm_bias_prep_kernel, dim3((d.G4p + 255) / 256), dim3(256), 0, st, w->b_ih[l], w->b_hh[l], d.H, d.Hp,
                            s.bsum[l]);
     }
-    launch_transpose(w->proj_w, d.P, d.H, up(d.P, 32), d.Hp, s.proj_wt, st);
+    if (d.ptype == kPredLstm) launch_transpose(w->proj_w, d.P, d.H, up(d.P, 32), d.Hp, s.proj_wt, st);
     launch_transpose(w->pred_ffn_w, d.J, d.P, up(d.J, 32), d.Pp, s.predffn_wt, st);
     launch_transpose(w->enc_ffn_w, d.J, d.E, d.J, d.E, s.encffn_wt, st);
     launch_transpose(w->out_w, d.V, d.J, d.Vp, d.Jp, s.out_wt, st);

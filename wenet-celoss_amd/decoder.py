@@ -20,15 +20,15 @@ def _f32(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
-def _joint_activation_code(joint) -> int:
-    """wr_activation of a joiner module: ours carries `act_code`; the reference's module (joint.py:25) only the
-    instantiated activation under its attribute `activatoin`."""
+def _joint_activation_code(joint, default: str = "tanh") -> int:
+    """wr_activation of a joiner (or stateless predictor) module: ours carries `act_code`; the reference's modules
+    (joint.py:25, predictor.py:237,387) only the instantiated activation under their attribute `activatoin`."""
     code = getattr(joint, "act_code", None)
     if code is not None:
         return int(code)
     act = getattr(joint, "activatoin", None)
     if act is None:
-        return _lib.ACTIVATIONS["tanh"]
+        return _lib.ACTIVATIONS[default]
     by_type = {"Tanh": "tanh", "ReLU": "relu", "Hardtanh": "hardtanh", "SELU": "selu", "SiLU": "swish", "Swish": "swish",
                "GELU": "gelu"}
     name = by_type.get(type(act).__name__)
@@ -43,10 +43,12 @@ class DeviceDecoder:
 
     def __init__(self, predictor, joint, max_lanes: int, max_utt: int, tmax: int, max_hyp: int = 0, max_beam: int = 1):
         lib = _lib.load()
-        rnn = predictor.rnn
-        if not isinstance(rnn, torch.nn.LSTM):
-            raise NotImplementedError("wenet_celoss_amd decoding implements the LSTM RNNPredictor "
-                                      f"(the shipped configuration); got {type(rnn).__name__}")
+        rnn = getattr(predictor, "rnn", None)
+        kind = 0 if rnn is not None else 1 if hasattr(predictor, "pos_embed") else 2 if hasattr(predictor, "conv") else -1
+        if kind < 0 or (kind == 0 and not isinstance(rnn, torch.nn.LSTM)):
+            raise NotImplementedError("wenet_celoss_amd decoding implements RNNPredictor with an LSTM (the shipped "
+                                      "configuration), EmbeddingPredictor and ConvPredictor; got "
+                                      f"{type(predictor).__name__}" + (f" / {type(rnn).__name__}" if rnn is not None else ""))
         if getattr(joint, "post_ffn", None) is not None:
             raise NotImplementedError("wenet_celoss_amd decoding does not take postjoin_linear=True (the step kernels fuse "
                                       "pred_ffn with the activation; the shipped configuration has no post-join Linear)")
@@ -74,21 +76,43 @@ class DeviceDecoder:
         w = _lib.TransducerWeights()
         w.vocab_size = joint.ffn_out.weight.shape[0]
         w.enc_dim = enc_w.shape[1]
-        w.pred_dim = predictor.projection.weight.shape[0]
         w.embed_dim = predictor.embed.weight.shape[1]
-        w.hidden = rnn.hidden_size
-        w.n_layers = rnn.num_layers
         w.join_dim = joint.ffn_out.weight.shape[1]
         w.activation = _joint_activation_code(joint)
         w.embed = hold(predictor.embed.weight)
-        if rnn.num_layers > 4:
-            raise NotImplementedError("at most 4 LSTM layers")
-        for l in range(rnn.num_layers):
-            w.w_ih[l] = hold(getattr(rnn, f"weight_ih_l{l}"))
-            w.w_hh[l] = hold(getattr(rnn, f"weight_hh_l{l}"))
-            w.b_ih[l] = hold(getattr(rnn, f"bias_ih_l{l}"))
-            w.b_hh[l] = hold(getattr(rnn, f"bias_hh_l{l}"))
-        w.proj_w, w.proj_b = hold(predictor.projection.weight), hold(predictor.projection.bias)
+        w.predictor_type = kind
+        if kind == 0:
+            w.pred_dim = predictor.projection.weight.shape[0]
+            w.hidden = rnn.hidden_size
+            w.n_layers = rnn.num_layers
+            if rnn.num_layers > 4:
+                raise NotImplementedError("at most 4 LSTM layers")
+            for l in range(rnn.num_layers):
+                w.w_ih[l] = hold(getattr(rnn, f"weight_ih_l{l}"))
+                w.w_hh[l] = hold(getattr(rnn, f"weight_hh_l{l}"))
+                w.b_ih[l] = hold(getattr(rnn, f"bias_ih_l{l}"))
+                w.b_hh[l] = hold(getattr(rnn, f"bias_hh_l{l}"))
+            w.proj_w, w.proj_b = hold(predictor.projection.weight), hold(predictor.projection.bias)
+        else:
+            # stateless predictors (predictor.py:203-481): the history of context_size - 1 token embeddings takes the
+            # place of the LSTM state: that many "layers" of width embed_dim
+            ctx = int(predictor.context_size)
+            if not 2 <= ctx <= 5:
+                raise NotImplementedError(f"history_size must be 1..4 (got {ctx - 1}): the token history travels in the "
+                                          "decoder's four state slots")
+            w.pred_dim = w.hidden = w.embed_dim
+            w.n_layers = ctx - 1
+            w.context_size = ctx
+            w.pred_activation = _joint_activation_code(predictor, "swish" if kind == 1 else "relu")
+            w.ln_eps = float(predictor.norm.eps)
+            w.norm_w, w.norm_b = hold(predictor.norm.weight), hold(predictor.norm.bias)
+            if kind == 1:
+                w.n_head = int(predictor.num_heads)
+                w.pos_w = hold(predictor.pos_embed.weight)
+                w.ffn_w, w.ffn_b = hold(predictor.ffn.weight), hold(predictor.ffn.bias)
+            else:
+                w.conv_w = hold(predictor.conv.weight)
+                w.conv_b = hold(predictor.conv.bias) if predictor.conv.bias is not None else None
         w.enc_ffn_w, w.enc_ffn_b = hold(enc_w), hold(enc_b)
         w.pred_ffn_w, w.pred_ffn_b = hold(pred_w), hold(pred_b)
         w.out_w, w.out_b = hold(joint.ffn_out.weight), hold(joint.ffn_out.bias)

@@ -90,12 +90,12 @@ def install() -> None:
 
 
 def _unavailable(module: str, name: str):
-    """Placeholder for classes the reference imports by name but the shipped configuration never constructs
-    (init_model.py:76-87 only builds them for `predictor: embedding|conv`)."""
+    """Placeholder for a name the reference's importers expect in a replaced module but this package does not define
+    (none at present: all three predictors, the joiner, CTC, Transducer and the search entry points exist); it refuses
+    at construction instead of failing the import."""
     class _Unavailable:
         def __init__(self, *a, **k):
-            raise NotImplementedError(f"{module}.{name} is not implemented by wenet_celoss_amd "
-                                      f"(the shipped configuration uses RNNPredictor)")
+            raise NotImplementedError(f"{module}.{name} is not implemented by wenet_celoss_amd")
     _Unavailable.__name__ = name
     return _Unavailable
 
