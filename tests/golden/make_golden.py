@@ -214,13 +214,16 @@ def gen_predictor_variants():
              full=full, **{"w_" + k: v for k, v in sd(pred).items()})
 
 
-def build_variant_modules(seed, kind, V, E, D, J, joint_act, blank_bias, weight_scale=2.0):
+def build_variant_modules(seed, kind, V, E, D, J, joint_act, blank_bias, weight_scale=2.0, postjoin=False):
     from wenet.transducer.joint import TransducerJoint
-    from wenet.transducer.predictor import ConvPredictor, EmbeddingPredictor
+    from wenet.transducer.predictor import ConvPredictor, EmbeddingPredictor, RNNPredictor
     from wenet.transformer.ctc import CTC
     g = torch.Generator().manual_seed(seed)
-    pred = (EmbeddingPredictor(V, D, 0.1, 4, 2, "swish") if kind == "embedding" else ConvPredictor(V, D, 0.1, 2, "relu", True)).eval()
-    joint = TransducerJoint(V, E, D, J, activation=joint_act).eval()
+    if kind == "lstm_nobias":
+        pred = RNNPredictor(V, D, D, 0.1, D, 2, bias=False).eval()
+    else:
+        pred = (EmbeddingPredictor(V, D, 0.1, 4, 2, "swish") if kind == "embedding" else ConvPredictor(V, D, 0.1, 2, "relu", True)).eval()
+    joint = TransducerJoint(V, E, D, J, activation=joint_act, postjoin_linear=postjoin).eval()
     ctc = CTC(V, E).eval()
     with torch.no_grad():
         for m in (pred, joint, ctc):
@@ -242,11 +245,15 @@ def gen_decode_variants():
     V, E, D, J = 64, 16, 16, 32
     cases = [dict(kind="embedding", joint_act="relu", seed=700, T=30, n_steps=64, blank_bias=6.0, beam=4),
              dict(kind="conv", joint_act="swish", seed=701, T=40, n_steps=3, blank_bias=4.0, beam=5),
-             dict(kind="conv", joint_act="tanh", seed=702, T=25, n_steps=64, blank_bias=5.0, beam=8)]
+             dict(kind="conv", joint_act="tanh", seed=702, T=25, n_steps=64, blank_bias=5.0, beam=8),
+             # LSTM without biases, post-join Linear (needs enc_output_size == join_dim, joint.py:41), hardtanh
+             dict(kind="lstm_nobias", joint_act="hardtanh", seed=703, T=30, n_steps=64, blank_bias=5.0, beam=4, postjoin=True, E=32)]
     for i, c in enumerate(cases):
+        E = c.get("E", 16)
         for attempt in range(300):
             seed = c["seed"] + 1000 * attempt
-            pred, joint, ctc = build_variant_modules(seed, c["kind"], V, E, D, J, c["joint_act"], c["blank_bias"])
+            pred, joint, ctc = build_variant_modules(seed, c["kind"], V, E, D, J, c["joint_act"], c["blank_bias"],
+                                                     postjoin=c.get("postjoin", False))
             model = types.SimpleNamespace(blank=0, predictor=pred, joint=joint, context_bias=PassThroughBias())
             g = torch.Generator().manual_seed(seed + 7)
             enc = dyadic((1, c["T"], E), g, scale=8, lim=2.0)
@@ -273,7 +280,7 @@ def gen_decode_variants():
         save(f"decode_var_{i}", kind=np.array(c["kind"]), joint_act=np.array(c["joint_act"]), enc=enc.numpy(), T=np.array(c["T"]),
              n_steps=np.array(c["n_steps"]), hyp=np.array(hyps[0], dtype=np.int64), min_margin=np.array(min_margin),
              beam=np.array(c["beam"]), beam_hyps=bh, beam_lens=np.array([len(s_.hyp) for s_ in beam]), beam_scores=scores,
-             beam_hist=np.stack([s_.cache[0].numpy() for s_ in beam]),
+             beam_hist=np.stack([s_.cache[0].numpy() for s_ in beam]), postjoin=np.array(c.get("postjoin", False)),
              **{"pred_" + k: v for k, v in sd(pred).items()}, **{"joint_" + k: v for k, v in sd(joint).items()},
              **{"ctc_" + k: v for k, v in sd(ctc).items()})
 
@@ -382,13 +389,15 @@ def replay_margin(pred, joint, enc, T, n_steps, hyp):
             mm = min(mm, float(top.values[0] - top.values[1]))
             a = int(top.indices[0])
             if a != 0:
-                assert hyp[k] == a
+                if k >= len(hyp) or hyp[k] != a:
+                    return 0.0                     # an exact tie resolved differently by topk and argmax: not a usable seed
                 k += 1; prev = True; nblk += 1; tok = torch.tensor([[a]]); cache = new_cache
             if a == 0 or nblk >= n_steps:
                 if a == 0:
                     prev = False
                 t += 1; nblk = 0
-        assert k == len(hyp)
+        if k != len(hyp):
+            return 0.0
     return mm
 
 

@@ -114,6 +114,26 @@ def test_greedy_batched_streams_equal_single_streams():
             assert hyps[i][:3] == ref[:3]
 
 
+def test_lstm_predictor_without_biases_steps_like_the_module_graph():
+    """RNNPredictor(bias=False) (predictor.py:66): the HIP step against the plain module graph on the same weights."""
+    import wenet_celoss_amd as w
+    torch.manual_seed(3)
+    pred = w.RNNPredictor(30, 12, 10, 0.0, 16, 2, bias=False, dropout=0.0).to(DEV).eval()
+    assert not any("bias" in n for n, _ in pred.rnn.named_parameters())
+    N = 4
+    cache = pred.init_state(N, device=torch.device(DEV))
+    ref_cache = [c.clone() for c in cache]
+    pad = torch.zeros(N, 1, device=DEV)
+    for s in range(5):
+        tok = torch.randint(0, 30, (N, 1), device=DEV)
+        out, cache = pred.forward_step(tok, pad, cache)
+        with torch.no_grad():
+            ro, ref_cache = pred._export_step(tok, pad, ref_cache)
+        torch.testing.assert_close(out, ro, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(cache[0], ref_cache[0], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(cache[1], ref_cache[1], rtol=1e-4, atol=1e-5)
+
+
 def build_history_predictor(d, prefix, kind, history, n_head=4, act=None, bias=None):
     import wenet_celoss_amd as w
     pw = sub(d, prefix)
@@ -152,11 +172,19 @@ def test_stateless_predictors_and_other_joiner_activations_decode_like_the_refer
     joiners: same tokens, same n-best order and scores."""
     import wenet_celoss_amd as w
     d = np.load(path)
-    pred = build_history_predictor(d, "pred_", str(d["kind"]), 2)
     jw = {k: v for k, v in sub(d, "joint_").items() if k != "act"}          # "joint_act" is the activation's name
     J, E = jw["enc_ffn.weight"].shape
     V = jw["ffn_out.weight"].shape[0]
-    joint = w.TransducerJoint(V, E, pred.embed_size, J, activation=str(d["joint_act"])).to(DEV).eval()
+    if str(d["kind"]) == "lstm_nobias":                  # RNNPredictor(bias=False) + post-join Linear + hardtanh
+        pw = sub(d, "pred_")
+        P = pw["projection.weight"].shape[0]
+        pred = w.RNNPredictor(V, pw["embed.weight"].shape[1], P, 0.1, pw["rnn.weight_hh_l0"].shape[1], 2, bias=False)
+        pred.load_state_dict({k: torch.tensor(v) for k, v in pw.items()})
+        pred = pred.to(DEV).eval()
+    else:
+        pred = build_history_predictor(d, "pred_", str(d["kind"]), 2)
+        P = pred.embed_size
+    joint = w.TransducerJoint(V, E, P, J, activation=str(d["joint_act"]), postjoin_linear=bool(d["postjoin"])).to(DEV).eval()
     joint.load_state_dict({k: torch.tensor(v) for k, v in jw.items()})
     ctc = w.CTC(V, E).to(DEV).eval()
     ctc.load_state_dict({k[4:]: torch.tensor(d[k]) for k in d.files if k.startswith("ctc_ctc_lo")})

@@ -205,7 +205,6 @@ def test_label_width_limits_are_reported_before_launch():
 
 def test_joiner_and_predictor_variants_accepted_or_refused_loudly():
     import wenet_celoss_amd as w
-    from wenet_celoss_amd.decoder import DeviceDecoder
     j = w.TransducerJoint(10, 8, 8, 8, prejoin_linear=False)
     assert j.enc_ffn is None and j.pred_ffn is None and j.post_ffn is None
     j2 = w.TransducerJoint(10, 8, 8, 8, postjoin_linear=True)
@@ -216,9 +215,9 @@ def test_joiner_and_predictor_variants_accepted_or_refused_loudly():
         assert w.TransducerJoint(10, 8, 8, 8, activation=act).act_code == w._lib.ACTIVATIONS[act]
     with pytest.raises(KeyError):
         w.TransducerJoint(10, 8, 8, 8, activation="sigmoid")
-    p = w.RNNPredictor(10, 8, 8, 0.1, 8, 1)
-    with pytest.raises(NotImplementedError, match="postjoin_linear"):
-        DeviceDecoder(p, j2, 1, 1, 4)
+    with pytest.raises(NotImplementedError, match="lstm"):
+        w.RNNPredictor(10, 8, 8, 0.1, 8, 1, rnn_type="gru")
+    assert w.RNNPredictor(10, 8, 8, 0.1, 8, 1, bias=False).rnn.bias is False
     # the stateless predictors keep the reference's parameter names and state layout (predictor.py:203-481)
     e = w.EmbeddingPredictor(10, 8, 0.1, 4, history_size=2)
     c = w.ConvPredictor(10, 8, 0.1, history_size=3, bias=True)

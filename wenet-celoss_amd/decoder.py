@@ -49,9 +49,6 @@ class DeviceDecoder:
             raise NotImplementedError("wenet_celoss_amd decoding implements RNNPredictor with an LSTM (the shipped "
                                       "configuration), EmbeddingPredictor and ConvPredictor; got "
                                       f"{type(predictor).__name__}" + (f" / {type(rnn).__name__}" if rnn is not None else ""))
-        if getattr(joint, "post_ffn", None) is not None:
-            raise NotImplementedError("wenet_celoss_amd decoding does not take postjoin_linear=True (the step kernels fuse "
-                                      "pred_ffn with the activation; the shipped configuration has no post-join Linear)")
         dev = joint.ffn_out.weight.device
         if joint.enc_ffn is None or joint.pred_ffn is None:
             # prejoin_linear=False (joint.py:30-31 then requires enc == pred == join width): the step kernels multiply by
@@ -63,6 +60,16 @@ class DeviceDecoder:
         else:
             enc_w, enc_b = joint.enc_ffn.weight, joint.enc_ffn.bias
             pred_w, pred_b = joint.pred_ffn.weight, joint.pred_ffn.bias
+        post = getattr(joint, "post_ffn", None)
+        if post is not None:
+            # postjoin_linear (joint.py:66-67): post(e + p) = (W e + b) + W p -- a Linear distributes over the sum, so
+            # it is folded into the two pre-join projections once (products formed in float64, rounded to fp32 once)
+            with torch.no_grad():
+                pw64 = post.weight.double()
+                enc_b = (pw64 @ enc_b.double() + post.bias.double()).float()
+                enc_w = (pw64 @ enc_w.double()).float()
+                pred_b = (pw64 @ pred_b.double()).float()
+                pred_w = (pw64 @ pred_w.double()).float()
         if dev.type != "cuda":
             raise RuntimeError("wenet_celoss_amd decoding: modules must live on a HIP device (this package has no CPU path)")
         self.device = dev
@@ -90,8 +97,11 @@ class DeviceDecoder:
             for l in range(rnn.num_layers):
                 w.w_ih[l] = hold(getattr(rnn, f"weight_ih_l{l}"))
                 w.w_hh[l] = hold(getattr(rnn, f"weight_hh_l{l}"))
-                w.b_ih[l] = hold(getattr(rnn, f"bias_ih_l{l}"))
-                w.b_hh[l] = hold(getattr(rnn, f"bias_hh_l{l}"))
+                if rnn.bias:
+                    w.b_ih[l] = hold(getattr(rnn, f"bias_ih_l{l}"))
+                    w.b_hh[l] = hold(getattr(rnn, f"bias_hh_l{l}"))
+                else:                                        # RNNPredictor(bias=False): zero biases
+                    w.b_ih[l] = w.b_hh[l] = hold(torch.zeros(4 * rnn.hidden_size, device=dev))
             w.proj_w, w.proj_b = hold(predictor.projection.weight), hold(predictor.projection.bias)
         else:
             # stateless predictors (predictor.py:203-481): the history of context_size - 1 token embeddings takes the

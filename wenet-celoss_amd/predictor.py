@@ -47,9 +47,11 @@ class RNNPredictor(PredictorBase):
     def __init__(self, voca_size: int, embed_size: int, output_size: int, embed_dropout: float, hidden_size: int,
                  num_layers: int, bias: bool = True, rnn_type: str = "lstm", dropout: float = 0.1) -> None:
         super().__init__()
-        if rnn_type != "lstm" or not bias:
-            raise NotImplementedError("wenet_celoss_amd.RNNPredictor implements the shipped configuration "
-                                      "(rnn_type='lstm', bias=True)")
+        if rnn_type != "lstm":
+            # the reference's own forward / forward_step unpack an (m, c) state tuple (predictor.py:113,190), which
+            # torch.nn.GRU / RNN do not return: only 'lstm' runs there either
+            raise NotImplementedError("wenet_celoss_amd.RNNPredictor implements rnn_type='lstm' (the reference's forward "
+                                      "unpacks an LSTM state tuple, so 'gru' / 'rnn' do not run there either)")
         self.n_layers = num_layers
         self.hidden_size = hidden_size
         self.embed = nn.Embedding(voca_size, embed_size)
