@@ -58,8 +58,10 @@ const char *wr_last_error(void);
  * key 5: retired (the superseded joiner forward variants were removed), key 6: decoder GEMM lane
  * tile (0: by occupancy, 1: 32 lanes, 2: 64 lanes), key 7: column parts of the split joiner forward (0: automatic),
  * key 8: retired (the 64-cell split dZ tiling was removed), key 9 / key 10: exact dW / dZ tiling (0: 256 x 256 blocks,
- * 1: the first tilings of joint.hip).  Keys 6-10 pick between kernels that compute the same sums; the two dZ tilings
- * are bit-identical, the dW tilings differ in the order of fp32 additions. */
+ * 1: the first tilings of joint.hip), key 11: greedy / beam micro-step with an LSTM predictor (0: projection folded
+ * into pred_ffn -- one launch less, the default; 1: two launches).  Keys 6-11 pick between kernels that compute the
+ * same sums; the two dZ tilings are bit-identical, the dW tilings differ in the order of fp32 additions, the folded
+ * projection in the rounding of one composed weight matrix (formed in float64). */
 int wr_tune_set(int key, int value);
 
 /* ------------------------------------------------------------------------

@@ -81,6 +81,9 @@ struct DevState {
     // the embedding of history slot l (l = 0 oldest), L = ctx - 1, H = D
     const float *pos_w, *pffn_b, *pnorm_w, *pnorm_b, *conv_w, *conv_b;
     float *pffn_wt;               // [Dp][up(D,32)] k-major ffn weight (type 1)
+    // LSTM predictor: projection followed by pred_ffn is ONE linear map (nothing non-linear sits between predictor.py:198
+    // and joint.py:57): pred_ffn(projection(h)) = (Wf Wp) h + (Wf bp + bf), composed once per handle
+    float *projffn_wt, *projffn_b;   // [Hp][up(J,32)], [up(J,32)]
     float *combT, *ffnT;          // [Dp][NLp] head-weighted context sum / ffn output (type 1)
     // per-call inputs
     const float *enc;             // [n_utt, T, E]
@@ -440,6 +443,26 @@ __device__ __forceinline__ void write_embedding_column(DevState *s, int n, int t
 {
     const Dims &d = s->d;
     for (int k = threadIdx.x; k < d.D; k += blockDim.x) s->xT[(size_t)k * d.NLp + n] = s->embed[(size_t)tok * d.D + k];
+}
+
+// wt[k][j] = sum_p wf[j][p] * wp[p][k]  (k-major, as lane_gemm reads it),  bias[j] = bf[j] + sum_p wf[j][p] * bp[p];
+// products and sums in float64, rounded to fp32 once (setup, once per handle)
+__global__ void compose_proj_ffn_kernel(const float *__restrict__ wf /* [J][P] */, const float *__restrict__ bf,
+                                        const float *__restrict__ wp /* [P][H] */, const float *__restrict__ bp, int J, int P,
+                                        int H, int Jn, float *__restrict__ wt /* [Hp][Jn] */, float *__restrict__ bias)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)H * J) {
+        const int k = (int)(idx / J), j = (int)(idx - (long)k * J);
+        double a = 0.0;
+        for (int p = 0; p < P; ++p) a += (double)wf[(size_t)j * P + p] * (double)wp[(size_t)p * H + k];
+        wt[(size_t)k * Jn + j] = (float)a;
+    } else if (idx < (long)H * J + J) {
+        const int j = (int)(idx - (long)H * J);
+        double a = (double)bf[j];
+        for (int p = 0; p < P; ++p) a += (double)wf[(size_t)j * P + p] * (double)bp[p];
+        bias[j] = (float)a;
+    }
 }
 
 // ---------------------------------------------------- stateless predictors --
@@ -1613,7 +1636,11 @@ size_t carve(const wr_transducer_weights *w, int max_lanes, int max_utt, int Tma
         s.bsum[l] = c.take<float>((size_t)d.G4p);
     }
     const int Pn = up(d.P, 32), Jn = up(d.J, 32);
-    if (d.ptype == kPredLstm) s.proj_wt = c.take<float>((size_t)d.Hp * Pn);
+    if (d.ptype == kPredLstm) {
+        s.proj_wt = c.take<float>((size_t)d.Hp * Pn);
+        s.projffn_wt = c.take<float>((size_t)d.Hp * Jn);
+        s.projffn_b = c.take<float>((size_t)Jn);
+    }
     if (d.ptype == kPredEmbedding) {
         s.pffn_wt = c.take<float>((size_t)d.Dp * up(d.D, 32));
         s.combT = c.take<float>((size_t)d.Dp * d.NLp);
@@ -1716,7 +1743,7 @@ void launch_gemm(const GemmArgs &g, int n_cols_padded, int n_lanes, hipStream_t 
 }
 
 // predictor step (predicated per lane): L LSTM layers (cell fused) + projection
-void launch_predictor(wr_decoder *h, int n_lanes, hipStream_t st)
+void launch_predictor(wr_decoder *h, int n_lanes, hipStream_t st, bool with_projection = true)
 {
     const Dims &d = h->d;
     const DevState &s = h->host;
@@ -1744,6 +1771,7 @@ void launch_predictor(wr_decoder *h, int n_lanes, hipStream_t st)
         g.cache_cT = s.cache_cT + (size_t)l * ls; g.new_cT = s.new_cT + (size_t)l * ls; g.new_hT = s.new_hT + (size_t)l * ls;
         launch_gemm<kEpiLstmCell>(g, d.G4p, n_lanes, st);
     }
+    if (!with_projection) return;                 // the caller applies the composed projection + pred_ffn
     GemmArgs g{};
     g.A0 = s.new_hT + (size_t)(d.L - 1) * ls; g.B0 = s.proj_wt; g.K0 = d.Hp;
     g.lda = d.NLp; g.ldb = up(d.P, 32); g.bias = s.proj_b; g.C = s.outT; g.ldc = d.NLp; g.N = d.P; g.n_lanes = n_lanes;
@@ -1755,11 +1783,18 @@ void launch_predictor_and_joint(wr_decoder *h, int n_lanes, hipStream_t st, int 
     const Dims &d = h->d;
     const DevState &s = h->host;
     auto up = [](int x, int m) { return (x + m - 1) / m * m; };
-    launch_predictor(h, n_lanes, st);
+    // LSTM predictor: the projection is folded into pred_ffn (one launch less per micro-step; wr_tune_set(11, 1) keeps
+    // them apart).  The hot-word search and wr_predictor_step need the projected output itself and keep the two stages.
+    const bool fold = d.ptype == kPredLstm && tune_get(kTuneFoldProj) != 1;
+    launch_predictor(h, n_lanes, st, !fold);
     {   // pred_ffn with the joiner activation as epilogue
         GemmArgs g{};
-        g.A0 = s.outT; g.B0 = s.predffn_wt; g.K0 = d.Pp;
-        g.lda = d.NLp; g.ldb = up(d.J, 32); g.bias = s.predffn_b; g.C = s.ht; g.ldc = kMaxLook * d.NLp; g.N = d.J; g.n_lanes = n_lanes;
+        if (fold) {
+            g.A0 = s.new_hT + (size_t)(d.L - 1) * d.Hp * d.NLp; g.B0 = s.projffn_wt; g.K0 = d.Hp; g.bias = s.projffn_b;
+        } else {
+            g.A0 = s.outT; g.B0 = s.predffn_wt; g.K0 = d.Pp; g.bias = s.predffn_b;
+        }
+        g.lda = d.NLp; g.ldb = up(d.J, 32); g.C = s.ht; g.ldc = kMaxLook * d.NLp; g.N = d.J; g.n_lanes = n_lanes;
         g.st = h->dev; g.lane_active = s.lane_active; g.lane_t = s.lane_t; g.ep_all = s.ep_all; g.J = d.J;
         g.look = look; g.lane_stride = d.NLp; g.act = d.act;
         launch_gemm<kEpiJointAct>(g, up(d.J, 32), n_lanes, st);
@@ -1849,7 +1884,12 @@ extern "C" int wr_decoder_create(const wr_transducer_weights *w, int max_lanes, 
         hipLaunchKernelGGL(lstm_bias_prep_kernel, dim3((d.G4p + 255) / 256), dim3(256), 0, st, w->b_ih[l], w->b_hh[l], d.H, d.Hp,
                            s.bsum[l]);
     }
-    if (d.ptype == kPredLstm) launch_transpose(w->proj_w, d.P, d.H, up(d.P, 32), d.Hp, s.proj_wt, st);
+    if (d.ptype == kPredLstm) {
+        launch_transpose(w->proj_w, d.P, d.H, up(d.P, 32), d.Hp, s.proj_wt, st);
+        const long n = (long)d.H * d.J + d.J;
+        hipLaunchKernelGGL(compose_proj_ffn_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w->pred_ffn_w, w->pred_ffn_b,
+                           w->proj_w, w->proj_b, d.J, d.P, d.H, up(d.J, 32), s.projffn_wt, s.projffn_b);
+    }
     launch_transpose(w->pred_ffn_w, d.J, d.P, up(d.J, 32), d.Pp, s.predffn_wt, st);
     launch_transpose(w->enc_ffn_w, d.J, d.E, d.J, d.E, s.encffn_wt, st);
     launch_transpose(w->out_w, d.V, d.J, d.Vp, d.Jp, s.out_wt, st);
