@@ -165,6 +165,58 @@ def test_stateless_predictor_step_matches_reference(path):
     np.testing.assert_allclose(full.detach().cpu().numpy(), d["full"], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("kind,D,history,heads", [("embedding", 300, 2, 4), ("embedding", 520, 4, 8), ("conv", 300, 3, 0),
+                                                  ("conv", 1024, 1, 0), ("embedding", 8, 1, 1)])
+def test_stateless_predictor_step_wide_embeddings_against_the_module_graph(kind, D, history, heads):
+    """Widths beyond one element per thread (D > 256), the longest history (4 slots) and the smallest sizes: the HIP
+    step against the plain module graph (`_export_step`, library ops) on the same weights, several lanes at once."""
+    import wenet_celoss_amd as w
+    torch.manual_seed(D + history)
+    V, N = 50, 5
+    pred = (w.EmbeddingPredictor(V, D, 0.0, heads, history, "swish") if kind == "embedding"
+            else w.ConvPredictor(V, D, 0.0, history, "relu", True)).to(DEV).eval()
+    with torch.no_grad():
+        pred.norm.weight.add_(torch.randn(D, device=DEV) * 0.2)
+        pred.norm.bias.add_(torch.randn(D, device=DEV) * 0.2)
+    cache = pred.init_state(N, device=torch.device(DEV))
+    ref = [c.clone() for c in cache]
+    pad = torch.zeros(N, 1, device=DEV)
+    for s_ in range(history + 3):
+        tok = torch.randint(0, V, (N, 1), device=DEV)
+        out, cache = pred.forward_step(tok, pad, cache)
+        with torch.no_grad():
+            ro, ref = pred._export_step(tok, pad, ref)
+        torch.testing.assert_close(out, ro, rtol=1e-4, atol=2e-5)
+        assert torch.equal(cache[0], ref[0])
+
+
+def test_stateless_predictor_streams_batched_equal_single():
+    """Several streams with different lengths through the greedy kernels with a ConvPredictor: every stream decodes as it
+    does alone (lanes that wait for a blank keep their pending history; predication per lane)."""
+    import wenet_celoss_amd as w
+    d = np.load(names("decode_var_2.npz")[0])
+    pred = build_history_predictor(d, "pred_", str(d["kind"]), 2)
+    jw = {k: v for k, v in sub(d, "joint_").items() if k != "act"}
+    J, E = jw["enc_ffn.weight"].shape
+    V = jw["ffn_out.weight"].shape[0]
+    joint = w.TransducerJoint(V, E, pred.embed_size, J, activation=str(d["joint_act"])).to(DEV).eval()
+    joint.load_state_dict({k: torch.tensor(v) for k, v in jw.items()})
+    model = types.SimpleNamespace(blank=0, predictor=pred, joint=joint)
+    enc0 = d["enc"][0]
+    T = enc0.shape[0]
+    lens = [T, T // 2, 3, T - 4, T]
+    encs = np.zeros((len(lens), T, enc0.shape[1]), np.float32)
+    for i, l in enumerate(lens):
+        encs[i, :l] = enc0[:l] if i % 2 == 0 else enc0[T - l:]
+    encs[-1] = enc0[::-1]
+    n_steps = int(d["n_steps"])
+    batch = w.basic_greedy_search(model, torch.tensor(encs, device=DEV), torch.tensor(lens), n_steps=n_steps)
+    assert batch[0] == list(d["hyp"])
+    for i, l in enumerate(lens):
+        single = w.basic_greedy_search(model, torch.tensor(encs[i:i + 1, :l], device=DEV), torch.tensor([l]), n_steps=n_steps)
+        assert single[0] == batch[i], i
+
+
 @pytest.mark.parametrize("use_graph", [True, False])
 @pytest.mark.parametrize("path", names("decode_var_*.npz"))
 def test_stateless_predictors_and_other_joiner_activations_decode_like_the_reference(path, use_graph):
