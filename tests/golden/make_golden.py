@@ -792,14 +792,27 @@ def gen_transducer_wrappers():
     sys.modules["torchaudio.functional"] = ta.functional
     from wenet.transducer.transducer import Transducer
     from wenet.transducer.joint import TransducerJoint
-    from wenet.transducer.predictor import RNNPredictor
+    from wenet.transducer.predictor import EmbeddingPredictor, RNNPredictor
     from wenet.transformer.context_bias import ContextBias
     from wenet.transformer.ctc import CTC
+    for variant in ("", "_emb"):
+        _gen_transducer_wrappers_variant(variant, locals())
+
+
+def _gen_transducer_wrappers_variant(variant, env):
+    """variant "": the shipped module types (RNNPredictor, tanh joiner); "_emb": EmbeddingPredictor + gelu joiner."""
+    Transducer, TransducerJoint, RNNPredictor, EmbeddingPredictor = (env[k] for k in
+                                                                     ("Transducer", "TransducerJoint", "RNNPredictor", "EmbeddingPredictor"))
+    ContextBias, CTC, TinyEncoder, TinyAttnDecoder = (env[k] for k in ("ContextBias", "CTC", "TinyEncoder", "TinyAttnDecoder"))
     V, D, J, H, HW = 23, 12, 16, 14, 8
-    torch.manual_seed(41)
+    torch.manual_seed(41 if not variant else 43)
     enc = TinyEncoder(8, D)
-    pred = RNNPredictor(V, D, D, 0.0, H, 2, dropout=0.0)
-    joint = TransducerJoint(V, D, D, J)
+    if variant == "_emb":
+        pred = EmbeddingPredictor(V, D, 0.0, 2, 2, "swish")
+        joint = TransducerJoint(V, D, D, J, activation="gelu")
+    else:
+        pred = RNNPredictor(V, D, D, 0.0, H, 2, dropout=0.0)
+        joint = TransducerJoint(V, D, D, J)
     ctc = CTC(V, D)
     dec = TinyAttnDecoder(V, D)
     cb = ContextBias(input_size=D, output_size=D, vocab_size=V, embedding_size=D, num_layers=1, attention_heads=2,
@@ -812,7 +825,7 @@ def gen_transducer_wrappers():
         m.joint.ffn_out.bias[0] += 1.5
         m.ctc.ctc_lo.weight *= 5
         m.ctc.ctc_lo.bias[0] += 1.0
-    g = torch.Generator().manual_seed(42)
+    g = torch.Generator().manual_seed(42 if not variant else 44)
     out = {}
     # ---- forward (the loss dictionary)
     B, Tin, U = 3, 13, 4
@@ -857,8 +870,8 @@ def gen_transducer_wrappers():
                                      context_filter_state="on", context_decoder_labels_padded=labels)
         out.update(greedy_hyp=np.array(gh[0], np.int64), greedy_dist=np.array(float(gd)), greedy_labels=labels.numpy())
         print("  greedy_search:", gh, gd)
-    save("transducer_wrappers", **out, **{"m_" + k: v for k, v in sd(m).items()}, heads=np.array(2), hw_dim=np.array(HW),
-         hw_heads=np.array(2))
+    save("transducer_wrappers" + variant, **out, **{"m_" + k: v for k, v in sd(m).items()}, heads=np.array(2),
+         hw_dim=np.array(HW), hw_heads=np.array(2))
 
 
 def gen_common():

@@ -445,24 +445,31 @@ def test_amp_two_op_path_buckets_ragged_batches(monkeypatch):
         assert float((res["4"][1][n].float() - gr.float()).abs().max()) <= 2e-2 * float(gr.float().abs().max()) + 1e-7, n
 
 
-def test_wrappers_match_the_reference_class():
+@pytest.mark.parametrize("fixture", ["transducer_wrappers.npz", "transducer_wrappers_emb.npz"])
+def test_wrappers_match_the_reference_class(fixture):
     """tests/golden/transducer_wrappers.npz was produced by the reference's OWN `Transducer` class
     (wenet/transducer/transducer.py) around the stand-in encoder / attention decoder of this file and the reference's
     predictor, joiner, CTC and ContextBias (make_golden.py::gen_transducer_wrappers; its torchaudio.functional.rnnt_loss
     was stubbed with the float64 oracle).  Same weights here: the loss dictionary of `forward` (all five entries),
     `beam_search`, `transducer_attention_rescoring` (both search types, with / without the right-to-left decoder) and
-    `greedy_search` with the hot-word module reproduce what the reference class returned."""
+    `greedy_search` with the hot-word module reproduce what the reference class returned.  `..._emb.npz`: the same through
+    the reference class built around its EmbeddingPredictor and a gelu joiner."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from conftest import GOLDEN
     from context_bias_mirror import ContextBiasMirror
     import wenet_celoss_amd as w
-    d = np.load(os.path.join(GOLDEN, "transducer_wrappers.npz"))
+    d = np.load(os.path.join(GOLDEN, fixture))
     sd = {k[2:]: torch.tensor(d[k]) for k in d.files if k.startswith("m_")}
     V, D = sd["predictor.embed.weight"].shape
-    J, H = sd["joint.enc_ffn.weight"].shape[0], sd["predictor.rnn.weight_hh_l0"].shape[1]
+    J = sd["joint.enc_ffn.weight"].shape[0]
     cb = ContextBiasMirror(V, D, layers=1, heads=int(d["heads"]), hw_dim=int(d["hw_dim"]), hw_heads=int(d["hw_heads"]))
-    m = w.Transducer(V, 0, TinyEncoder(8, D), w.RNNPredictor(V, D, D, 0.0, H, 2, dropout=0.0), w.TransducerJoint(V, D, D, J),
+    if "predictor.pos_embed.weight" in sd:
+        predictor, joint = w.EmbeddingPredictor(V, D, 0.0, 2, 2, "swish"), w.TransducerJoint(V, D, D, J, activation="gelu")
+    else:
+        predictor = w.RNNPredictor(V, D, D, 0.0, sd["predictor.rnn.weight_hh_l0"].shape[1], 2, dropout=0.0)
+        joint = w.TransducerJoint(V, D, D, J)
+    m = w.Transducer(V, 0, TinyEncoder(8, D), predictor, joint,
                      attention_decoder=TinyAttnDecoder(V, D), ctc=w.CTC(V, D), context_bias=cb, ctc_weight=0.1,
                      transducer_weight=0.75, attention_weight=0.15, reverse_weight=0.3, lsm_weight=0.1, hw_weight=0.4,
                      loss_mode="both")
