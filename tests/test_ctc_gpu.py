@@ -54,6 +54,8 @@ def make(rng, B, T, S, V, repeat=False, full=False):
     (2, 1100, 400, 25, True),   # 801 states, 13 waves
     (1, 1030, 511, 12, False),  # 1023 states: the supported maximum (16 waves)
     (5, 77, 12, 1000, True),
+    (1, 9, 3, 16384, False),    # the widest vocabulary the gradient kernel's LDS row takes
+    (2, 12, 4, 4099, True),     # rows alternate between the four 16-byte alignments
 ])
 def test_parity_vs_oracle(B, T, S, V, repeat):
     rng = np.random.default_rng(B * 7 + T + S * 3 + V)
@@ -64,6 +66,25 @@ def test_parity_vs_oracle(B, T, S, V, repeat):
     np.testing.assert_allclose(grad, og, rtol=1e-4, atol=1e-5)
     for b in range(B):
         assert not grad[b, ilens[b]:].any()
+
+
+def test_logits_at_an_odd_storage_offset():
+    """Logits whose storage starts 4 bytes past a 16-byte boundary (a contiguous view into a larger buffer): the gradient
+    rows no longer share the logits rows' alignment, which takes the kernels' scalar row path."""
+    import wenet_celoss_amd as w
+    rng = np.random.default_rng(5)
+    B, T, S, V = 2, 14, 5, 36
+    logits, targets, ilens, tlens = make(rng, B, T, S, V, True)
+    buf = torch.zeros(B * T * V + 1, device=DEV)
+    buf[1:] = torch.tensor(logits, device=DEV).reshape(-1)
+    x = buf[1:].view(B, T, V).requires_grad_(True)
+    assert x.data_ptr() % 16 == 4 and x.is_contiguous()
+    nll = w.ctc_loss(x, torch.tensor(targets, device=DEV), torch.tensor(ilens, device=DEV), torch.tensor(tlens, device=DEV),
+                     reduction="none")
+    g, = torch.autograd.grad(nll.sum(), x)
+    on, og = oracle.ctc_loss_f64(logits, targets, ilens, tlens)
+    np.testing.assert_allclose(nll.detach().cpu().numpy(), on, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(g.cpu().numpy(), og, rtol=1e-4, atol=1e-5)
 
 
 def test_infeasible_is_inf_and_grad_scaling():

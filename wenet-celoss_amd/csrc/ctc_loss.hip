@@ -21,6 +21,7 @@
 //           row out with 16-B stores.  Frames t >= T_b are zero-filled.
 //
 // Algorithmic traffic: 4*V per valid frame (pass 1) + 2*4*V per frame (pass 3).
+#include "row_stream.hpp"
 #include "wr_common.hpp"
 
 namespace wr {
@@ -53,36 +54,8 @@ inline CtcWs ctc_ws_layout(int B, int Tmax, int Smax)
 }
 
 // ------------------------------------------------------------------ pass 1 --
-__device__ __forceinline__ float wave_row_lse_cached(const float *__restrict__ row, int V, int lane)
-{
-    // Same online (max,sum) scheme as the RNN-T pass 1, but with default-policy loads:
-    // the CTC logits (B*T*V) are re-read by the gather below and by pass 3.
-    float m = -3.0e38f, s = 0.f;
-    const int head = (int)((4 - ((reinterpret_cast<uintptr_t>(row) >> 2) & 3)) & 3);
-    const int h = head < V ? head : V;
-    const int n4 = (V - h) >> 2;
-    const int tail = V - h - 4 * n4;
-    auto add1 = [&](float x) {
-        const float y = x * kLog2e, nm = fmaxf(m, y);
-        s = s * fast_exp2(m - nm) + fast_exp2(y - nm);
-        m = nm;
-    };
-    if (lane < h) add1(row[lane]);
-    if (lane < tail) add1(row[h + 4 * n4 + lane]);
-    const f32x4 *__restrict__ body = reinterpret_cast<const f32x4 *>(row + h);
-    for (int i = lane; i < n4; i += kWave) {
-        const f32x4 v = body[i];
-        const float y0 = v.x * kLog2e, y1 = v.y * kLog2e, y2 = v.z * kLog2e, y3 = v.w * kLog2e;
-        const float nm = fmaxf(m, fmaxf(fmaxf(y0, y1), fmaxf(y2, y3)));
-        s = s * fast_exp2(m - nm) + (fast_exp2(y0 - nm) + fast_exp2(y1 - nm)) +
-            (fast_exp2(y2 - nm) + fast_exp2(y3 - nm));
-        m = nm;
-    }
-    const float M = wave_max(m);
-    const float tot = wave_sum(s * fast_exp2(m - M));
-    return (M + fast_log2(tot)) * kLn2;
-}
-
+// Row log-sum-exp: wave_row_lse of row_stream.hpp (16-byte vectors, 8 in flight per lane), with default-policy loads --
+// the CTC logits (B*T*V) are re-read by the gather below and by pass 3.
 __global__ __launch_bounds__(256) void ctc_lse_kernel(
     const float *__restrict__ logits, const int32_t *__restrict__ targets,
     const int32_t *__restrict__ ilens, const int32_t *__restrict__ tlens,
@@ -98,14 +71,31 @@ __global__ __launch_bounds__(256) void ctc_lse_kernel(
         const int t = (int)(r - (long)b * Tmax);
         if (t >= ilens[b]) continue;
         const float *row = logits + (size_t)r * V;
-        const float d = normalized ? 0.f : wave_row_lse_cached(row, V, lane);
         int S = tlens[b];
         S = S < 0 ? 0 : (S > Smax ? Smax : S);
+        // the label logits of the first 256 labels are gathered before the row is streamed, so that the two dependent
+        // loads (label, then logit) do not add their latency after it
+        constexpr int GQ = 4;
+        float xl[GQ];
+#pragma unroll
+        for (int q = 0; q < GQ; ++q) {
+            const int i = lane + kWave * q;
+            int lab = i < S ? targets[(size_t)b * Smax + i] : 0;
+            lab = lab < 0 ? 0 : (lab >= V ? V - 1 : lab);
+            xl[q] = row[lab];
+        }
+        const float xb = row[blank];
+        const float d = normalized ? 0.f : wave_row_lse<float, false, 8>(row, V, lane);
         if (lane == 0) {
             denom[r] = d;
-            lp_blank[r] = row[blank] - d;
+            lp_blank[r] = xb - d;
         }
-        for (int i = lane; i < S; i += kWave) {
+#pragma unroll
+        for (int q = 0; q < GQ; ++q) {
+            const int i = lane + kWave * q;
+            if (i < S) lp_label[(size_t)r * Smax + i] = xl[q] - d;
+        }
+        for (int i = lane + kWave * GQ; i < S; i += kWave) {
             int lab = targets[(size_t)b * Smax + i];
             lab = lab < 0 ? 0 : (lab >= V ? V - 1 : lab);
             lp_label[(size_t)r * Smax + i] = row[lab] - d;
@@ -248,14 +238,20 @@ __global__ __launch_bounds__(kCtcMaxStates) void ctc_sweep_kernel(
 }
 
 // ------------------------------------------------------------------ pass 3 --
-__global__ __launch_bounds__(256) void ctc_grad_kernel(
+// One workgroup per frame.  The state data of the frame (alpha, beta, log-probs, labels: this thread's states
+// tid, tid + 256, ...) is requested first so that its latency hides behind the row stream; the row is read and written
+// in 16-byte vectors through an LDS copy whose vector body is 16-byte aligned (index v + pad).
+constexpr int kCtcGradThreads = 256;
+constexpr int kCtcStatesPerThread = kCtcMaxStates / kCtcGradThreads;
+
+__global__ __launch_bounds__(kCtcGradThreads) void ctc_grad_kernel(
     const float *logits, const int32_t *__restrict__ targets, const int32_t *__restrict__ ilens,
     const int32_t *__restrict__ tlens, int B, int Tmax, int Smax, int SP, int V, int blank,
     const float *__restrict__ denom, const float *__restrict__ lp_blank, const float *__restrict__ lp_label,
     const double *__restrict__ alpha, const double *__restrict__ beta, const double *__restrict__ nll_ws,
     const float *__restrict__ grad_nll, float *grads)
 {
-    extern __shared__ __attribute__((aligned(16))) float srow[];   // V floats
+    extern __shared__ __attribute__((aligned(16))) float srow_raw[];   // V + 4 floats
     const long r = blockIdx.x;
     const int b = (int)(r / Tmax);
     const int t = (int)(r - (long)b * Tmax);
@@ -264,34 +260,96 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
     S = S < 0 ? 0 : (S > Smax ? Smax : S);
     const float *row = logits + (size_t)r * V;
     float *grow = grads + (size_t)r * V;
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = threadIdx.x;
+    constexpr int nt = kCtcGradThreads;
+    const RowSplit<float> sp(grow, V);            // logits and grads rows share their alignment when both bases are 16-byte
+    const bool same = ((reinterpret_cast<uintptr_t>(row) ^ reinterpret_cast<uintptr_t>(grow)) & 15) == 0;
+    const int h = same ? sp.h : V, nv = same ? sp.nv : 0, tail = same ? sp.tail : 0;   // else: scalar path for the whole row
+    f32x4 *gbody = reinterpret_cast<f32x4 *>(grow + h);
 
     if (t >= T) {
-        for (int v = tid; v < V; v += nt) grow[v] = 0.f;
+        if (tid < h && h < V) grow[tid] = 0.f;
+        if (h == V) for (int v = tid; v < V; v += nt) grow[v] = 0.f;
+        if (tid < tail) grow[h + 4 * nv + tid] = 0.f;
+        for (int i = tid; i < nv; i += nt) gbody[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         return;
     }
-    const float go = grad_nll ? grad_nll[b] : 1.f;
-    const float d2 = denom[r] * kLog2e;
-    for (int v = tid; v < V; v += nt) srow[v] = go * fast_exp2(fmaf(row[v], kLog2e, -d2));
-    __syncthreads();
-    const double nll = nll_ws[b];
+    // ---- state data in flight first
     const int NS = 2 * S + 1;
     const double *al = alpha + (size_t)r * SP;
     const double *be = beta + (size_t)r * SP;
-    for (int s = tid; s < NS; s += nt) {
-        int lab = blank;
-        float lp = lp_blank[r];
-        if (s & 1) {
-            lab = targets[(size_t)b * Smax + (s >> 1)];
-            lab = lab < 0 ? 0 : (lab >= V ? V - 1 : lab);
-            lp = lp_label[(size_t)r * Smax + (s >> 1)];
+    double a_s[kCtcStatesPerThread], b_s[kCtcStatesPerThread];
+    float lp_s[kCtcStatesPerThread];
+    int lab_s[kCtcStatesPerThread];
+    const float lpb = lp_blank[r];
+#pragma unroll
+    for (int q = 0; q < kCtcStatesPerThread; ++q) {
+        const int s = tid + nt * q;
+        a_s[q] = 0.0; b_s[q] = 0.0; lp_s[q] = lpb; lab_s[q] = blank;
+        if (s < NS) {
+            a_s[q] = al[s];
+            b_s[q] = be[s];
+            if (s & 1) {
+                int lab = targets[(size_t)b * Smax + (s >> 1)];
+                lab_s[q] = lab < 0 ? 0 : (lab >= V ? V - 1 : lab);
+                lp_s[q] = lp_label[(size_t)r * Smax + (s >> 1)];
+            }
         }
-        // occupancy of state s at frame t: exp(alpha + beta - lp + nll)   (alpha and beta both include lp)
-        const float e = (float)(al[s] + be[s] + nll - (double)lp);
-        atomicAdd(&srow[lab], -go * fast_exp2(e * kLog2e));
+    }
+    const double nll = nll_ws[b];
+    const float go = grad_nll ? grad_nll[b] : 1.f;
+    const float d2 = denom[r] * kLog2e;
+    // ---- softmax row (times the incoming gradient) into LDS
+    const int pad = (4 - (h & 3)) & 3;
+    float *srow = srow_raw + pad;                         // element v at srow[v]: the body (v = h + 4 i) is 16-byte aligned
+    if (h == V) {
+        for (int v = tid; v < V; v += nt) srow[v] = go * fast_exp2(fmaf(row[v], kLog2e, -d2));
+    } else {
+        if (tid < h) srow[tid] = go * fast_exp2(fmaf(row[tid], kLog2e, -d2));
+        if (tid < tail) srow[h + 4 * nv + tid] = go * fast_exp2(fmaf(row[h + 4 * nv + tid], kLog2e, -d2));
+        const f32x4 *body = reinterpret_cast<const f32x4 *>(row + h);
+        f32x4 *sbody = reinterpret_cast<f32x4 *>(srow + h);
+        constexpr int UN = 4;
+        int i = tid;
+        for (; i + (UN - 1) * nt < nv; i += UN * nt) {
+            f32x4 x[UN];
+#pragma unroll
+            for (int q = 0; q < UN; ++q) x[q] = body[i + q * nt];
+#pragma unroll
+            for (int q = 0; q < UN; ++q) {
+                f32x4 o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = go * fast_exp2(fmaf(x[q][c], kLog2e, -d2));
+                sbody[i + q * nt] = o;
+            }
+        }
+        for (; i < nv; i += nt) {
+            const f32x4 x = body[i];
+            f32x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = go * fast_exp2(fmaf(x[c], kLog2e, -d2));
+            sbody[i] = o;
+        }
     }
     __syncthreads();
-    for (int v = tid; v < V; v += nt) grow[v] = srow[v];
+    // ---- subtract the state occupancies exp(alpha + beta - lp + nll)   (alpha and beta both include lp)
+#pragma unroll
+    for (int q = 0; q < kCtcStatesPerThread; ++q) {
+        const int s = tid + nt * q;
+        if (s < NS) {
+            const float e = (float)(a_s[q] + b_s[q] + nll - (double)lp_s[q]);
+            atomicAdd(&srow[lab_s[q]], -go * fast_exp2(e * kLog2e));
+        }
+    }
+    __syncthreads();
+    if (h == V) {
+        for (int v = tid; v < V; v += nt) grow[v] = srow[v];
+    } else {
+        if (tid < h) grow[tid] = srow[tid];
+        if (tid < tail) grow[h + 4 * nv + tid] = srow[h + 4 * nv + tid];
+        const f32x4 *sbody = reinterpret_cast<const f32x4 *>(srow + h);
+        for (int i = tid; i < nv; i += nt) gbody[i] = sbody[i];
+    }
 }
 
 // ------------------------------------------------------- forced alignment --
@@ -408,7 +466,7 @@ extern "C" int wr_ctc_loss_fwd(const void *logits_d, int dtype, const int32_t *t
     const long nrows = (long)B * Tmax;
     const int SmaxA = Smax > 0 ? Smax : 1;
     long blocks = (nrows + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 2048) blocks = 2048;      // measured flat between 1 024 and 8 192 workgroups at the BASELINE shape (153-161 us)
     hipLaunchKernelGGL(ctc_lse_kernel, dim3((int)blocks), dim3(256), 0, st, static_cast<const float *>(logits_d),
                        targets_d, input_lengths_d, target_lengths_d, B, Tmax, SmaxA, V, blank,
                        reinterpret_cast<float *>(ws + w.denom_off), reinterpret_cast<float *>(ws + w.lpb_off),
@@ -435,7 +493,9 @@ extern "C" int wr_ctc_loss_bwd(const void *logits_d, int dtype, const int32_t *t
     hipStream_t st = static_cast<hipStream_t>(stream);
     const char *ws = static_cast<const char *>(workspace_d);
     const int SmaxA = Smax > 0 ? Smax : 1;
-    hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)((long)B * Tmax)), dim3(256), (size_t)V * sizeof(float), st,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((size_t)(V + 4) * sizeof(float)));      // V = 16384: 16 bytes above the 64 KB default
+    hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)((long)B * Tmax)), dim3(kCtcGradThreads), (size_t)(V + 4) * sizeof(float), st,
                        static_cast<const float *>(logits_d), targets_d, input_lengths_d, target_lengths_d, B, Tmax,
                        SmaxA, w.SP, V, blank, reinterpret_cast<const float *>(ws + w.denom_off),
                        reinterpret_cast<const float *>(ws + w.lpb_off), reinterpret_cast<const float *>(ws + w.lpl_off),
