@@ -30,6 +30,8 @@ bwd = lambda: _lib.check(lib.wr_rnnt_loss_bwd(P(logits), 0, P(targets), P(ll), P
 variants = [dict(lse=l, grad=g, nt=6, un=u, lun=lu) for u in (4, 8) for lu in (4, 8) for l, g in ((8, 8), (6, 6), (12, 12))]
 if os.environ.get("SWEEP") == "grad":          # gradient pass only: grid size x non-temporal bits (1: NT loads, 2: NT stores)
     variants = [dict(lse=12, grad=g, nt=4 | nt, un=8, lun=8) for g in (6, 8, 12, 16, 24) for nt in (2, 3, 0, 1)]
+if os.environ.get("SWEEP") == "r2":            # round 2: non-temporal loads x vectors in flight x grid, full fwd + bwd sequence
+    variants = [dict(lse=12, grad=g, nt=nt, un=u, lun=8) for nt in (6, 7) for u in (8, 16) for g in (12, 16)]
 res = {i: ([], []) for i in range(len(variants))}
 for rnd in range(int(os.environ.get("ROUNDS", 5))):
     for i, v in enumerate(variants):

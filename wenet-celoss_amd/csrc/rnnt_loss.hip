@@ -497,7 +497,8 @@ extern "C" int wr_rnnt_loss_bwd(const void *logits_d, int dtype, const int32_t *
                        reinterpret_cast<const double *>(ws + w.cost_off), grad_costs_d, static_cast<T *>(grads_d))
 #define WR_LAUNCH_GRAD(T, NT)                                             \
     do {                                                                   \
-        if (tune_get(kTuneGradUnroll) >= 8) { WR_LAUNCH_GRAD_U(T, NT, 8); } \
+        if (tune_get(kTuneGradUnroll) >= 16) { WR_LAUNCH_GRAD_U(T, NT, 16); } \
+        else if (tune_get(kTuneGradUnroll) >= 8) { WR_LAUNCH_GRAD_U(T, NT, 8); } \
         else { WR_LAUNCH_GRAD_U(T, NT, 4); }                               \
     } while (0)
     const bool nt = (tune_get(kTuneNonTemporal) & 1) != 0;
