@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Interleaved A/B of the RNN-T streaming kernels' launch knobs in ONE process (rule: never compare
-timings across processes).  Prints median ms of fwd (lse+sweep) and bwd (grad) per variant."""
+timings across processes).  Prints median ms of fwd (lse+sweep) and bwd (grad) per variant.
+SWEEP=grad | r2 | grid pick the variant lists of rounds 1 / 2; STEPS=n (default 1) times n back-to-back fwd + bwd steps per
+measurement -- sustained operation runs the parts ~5 % slower than isolated launches, and the grid-size effects of round 2
+only show there."""
 import itertools
 import json
 import os
@@ -32,14 +35,23 @@ if os.environ.get("SWEEP") == "grad":          # gradient pass only: grid size x
     variants = [dict(lse=12, grad=g, nt=4 | nt, un=8, lun=8) for g in (6, 8, 12, 16, 24) for nt in (2, 3, 0, 1)]
 if os.environ.get("SWEEP") == "r2":            # round 2: non-temporal loads x vectors in flight x grid, full fwd + bwd sequence
     variants = [dict(lse=12, grad=g, nt=nt, un=u, lun=8) for nt in (6, 7) for u in (8, 16) for g in (12, 16)]
+if os.environ.get("SWEEP") == "grid":          # round 2: workgroups per CU (0 = automatic: short-lived workgroups, see stream_grid)
+    variants = [dict(lse=l, grad=g, nt=7, un=16, lun=16) for l, g in ((12, 16), (0, 0), (128, 128), (1024, 1024), (4800, 1024),
+                                                                       (4800, 2048), (2360, 512))]
+if os.environ.get("SWEEP") == "grid2":         # gradient-pass grid with the row pass on its automatic grid
+    variants = [dict(lse=0, grad=g, nt=7, un=16, lun=16) for g in (16, 64, 128, 256, 512, 768, 1024, 1400, 0)]
+STEPS = int(os.environ.get("STEPS", 1))
 res = {i: ([], []) for i in range(len(variants))}
 for rnd in range(int(os.environ.get("ROUNDS", 5))):
     for i, v in enumerate(variants):
         lib.wr_tune_set(0, v["lse"]); lib.wr_tune_set(1, v["grad"]); lib.wr_tune_set(2, v["nt"]); lib.wr_tune_set(3, v["un"]); lib.wr_tune_set(4, v["lun"])
         fwd(); bwd(); torch.cuda.synchronize()
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        e[0].record(); fwd(); e[1].record(); bwd(); e[2].record(); torch.cuda.synchronize()
-        res[i][0].append(e[0].elapsed_time(e[1])); res[i][1].append(e[1].elapsed_time(e[2]))
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(STEPS)]
+        for e in ev:
+            e[0].record(); fwd(); e[1].record(); bwd(); e[2].record()
+        torch.cuda.synchronize()
+        res[i][0].append(sum(e[0].elapsed_time(e[1]) for e in ev) / STEPS)
+        res[i][1].append(sum(e[1].elapsed_time(e[2]) for e in ev) / STEPS)
 med = lambda a: sorted(a)[len(a) // 2]
 # same-process, same-device calibration: a plain 1:1 device copy of the same tensors (read + write)
 cp = []

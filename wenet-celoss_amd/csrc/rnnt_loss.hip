@@ -375,16 +375,36 @@ int check_shape(int B, int Tmax, int U1max, int V, int blank)
     return WR_OK;
 }
 
-int stream_grid(long nrows, int blocks_per_cu)
+// Grid of a streaming pass: 4-wave workgroups, each wave visits rows r, r + G, r + 2G, ... (G = waves of the grid).
+// Round 1 ran persistent grids (12 workgroups per CU, ~390 rows per wave at the BASELINE shape).  Measured in round 2
+// (tools/tune_rnnt.py SWEEP=grid, sustained fwd + bwd sequence): many short-lived workgroups are faster -- the hardware
+// dispatches them in index order as slots free up, so what is in flight at any moment is a tight window of adjacent rows
+// (a few short-lived windows for k rows per wave) instead of 12 288 persistent waves that drift apart:
+//     read-only row pass:         15.71 ms at 12 per CU -> 14.64 ms with one row per wave (monotonic in between);
+//     read + write gradient pass: 34.49 ms at 16 per CU -> 33.65 (128) -> 33.35 (512) -> 33.18 (1 024) -> 32.96 ms at
+//                                 1 400 per CU (3.4 rows per wave); one or two rows per wave lose again (2 048 per CU =
+//                                 2.3 rows per wave: +2 %).
+// `knob` > 0 forces that many workgroups per CU (the round-1 meaning of tuning keys 0 and 1); 0 = automatic: every wave
+// gets about `bytes_per_wave` of logits.
+int stream_grid(long nrows, int knob, size_t row_bytes, size_t bytes_per_wave)
 {
-    // HBM-streaming grid: 4-wave blocks, `blocks_per_cu` per CU (all resident: no tail of late blocks),
-    // grid-stride beyond.
     long blocks = (nrows + 3) / 4;
-    const long cap = 256L * blocks_per_cu;
-    if (blocks > cap) blocks = cap;
+    if (knob > 0) {
+        const long cap = 256L * knob;
+        if (blocks > cap) blocks = cap;
+    } else {
+        const long all = blocks;                                  // one row per wave
+        blocks = (long)(((double)nrows * (double)row_bytes) / (4.0 * (double)bytes_per_wave)) + 1;
+        if (blocks > all) blocks = all;
+        const long floor_blocks = 256L * 12 < (nrows + 3) / 4 ? 256L * 12 : (nrows + 3) / 4;   // never fewer than a persistent grid
+        if (blocks < floor_blocks) blocks = floor_blocks;
+    }
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
+
+constexpr size_t kLseBytesPerWave = 16 * 1024;     // one row of 5 000 fp32 logits
+constexpr size_t kGradBytesPerWave = 68 * 1024;    // 3.4 such rows on average
 
 }  // namespace
 
@@ -424,9 +444,10 @@ extern "C" int wr_rnnt_loss_fwd(const void *logits_d, int dtype, const int32_t *
     hipStream_t st = static_cast<hipStream_t>(stream);
     char *ws = static_cast<char *>(workspace_d);
     const long nrows = (long)B * Tmax * U1max;
-    const dim3 grid1(stream_grid(nrows, tune_get(kTuneLseBlocksPerCu)));
+    const size_t row_bytes = (size_t)V * (dtype == WR_F32 ? 4 : 2);
+    const dim3 grid1(stream_grid(nrows, tune_get(kTuneLseBlocksPerCu), row_bytes, kLseBytesPerWave));
 #define WR_LAUNCH_LSE(T, NT)                                                                                        \
-    if (tune_get(kTuneLseUnroll) >= 8) WR_LAUNCH_LSE_U(T, NT, 8); else WR_LAUNCH_LSE_U(T, NT, 4)
+    if (tune_get(kTuneLseUnroll) >= 16) WR_LAUNCH_LSE_U(T, NT, 16); else if (tune_get(kTuneLseUnroll) >= 8) WR_LAUNCH_LSE_U(T, NT, 8); else WR_LAUNCH_LSE_U(T, NT, 4)
 #define WR_LAUNCH_LSE_U(T, NT, UN)                                                                                  \
     hipLaunchKernelGGL((rnnt_lse_kernel<T, NT, UN>), grid1, dim3(256), 0, st, static_cast<const T *>(logits_d), targets_d, \
                        logit_lengths_d, target_lengths_d, B, Tmax, U1max, V, blank, w.K, w.S,                        \
@@ -459,7 +480,7 @@ extern "C" int wr_rnnt_loss_fwd_from_lse(const float *logits_d, const int32_t *t
     // repair pass: the stand-alone row statistics, executed only if the joiner's epilogue raised the flag (a partial
     // sum overflowed: more than 88 nats of spread inside one row); otherwise every workgroup leaves at once
     const long nrows = (long)B * Tmax * U1max;
-    hipLaunchKernelGGL((rnnt_lse_kernel<float, false, 8>), dim3(stream_grid(nrows, tune_get(kTuneLseBlocksPerCu))), dim3(256), 0, st,
+    hipLaunchKernelGGL((rnnt_lse_kernel<float, false, 8>), dim3(stream_grid(nrows, tune_get(kTuneLseBlocksPerCu), (size_t)V * 4, kLseBytesPerWave)), dim3(256), 0, st,
                        logits_d, targets_d, logit_lengths_d, target_lengths_d, B, Tmax, U1max, V, blank, w.K, w.S,
                        reinterpret_cast<float2 *>(ws + w.lp_off), reinterpret_cast<float *>(ws + w.denom_off),
                        reinterpret_cast<const int32_t *>(ws + w.flag_off));
@@ -485,7 +506,8 @@ extern "C" int wr_rnnt_loss_bwd(const void *logits_d, int dtype, const int32_t *
     hipStream_t st = static_cast<hipStream_t>(stream);
     const char *ws = static_cast<const char *>(workspace_d);
     const long nrows = (long)B * Tmax * U1max;
-    const dim3 grid3(stream_grid(nrows, tune_get(kTuneGradBlocksPerCu)));
+    const size_t row_bytes = (size_t)V * (dtype == WR_F32 ? 4 : 2);
+    const dim3 grid3(stream_grid(nrows, tune_get(kTuneGradBlocksPerCu), row_bytes, kGradBytesPerWave));
 #define WR_LAUNCH_GRAD_U(T, NT, UN)                                                                                 \
     if (nts) WR_LAUNCH_GRAD_US(T, NT, true, UN); else WR_LAUNCH_GRAD_US(T, NT, false, UN)
 #define WR_LAUNCH_GRAD_US(T, NT, NTS, UN)                                                                           \
