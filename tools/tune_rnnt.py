@@ -40,6 +40,8 @@ if os.environ.get("SWEEP") == "grid":          # round 2: workgroups per CU (0 =
                                                                        (4800, 2048), (2360, 512))]
 if os.environ.get("SWEEP") == "grid2":         # gradient-pass grid with the row pass on its automatic grid
     variants = [dict(lse=0, grad=g, nt=7, un=16, lun=16) for g in (16, 64, 128, 256, 512, 768, 1024, 1400, 0)]
+if os.environ.get("SWEEP") == "auto":          # automatic grids: non-temporal bits and vectors in flight once more
+    variants = [dict(lse=0, grad=0, nt=nt, un=u, lun=lu) for nt in (7, 3, 5, 6) for u, lu in ((16, 16), (8, 8), (16, 8), (8, 16))]
 STEPS = int(os.environ.get("STEPS", 1))
 res = {i: ([], []) for i in range(len(variants))}
 for rnd in range(int(os.environ.get("ROUNDS", 5))):
