@@ -6,8 +6,7 @@ pass 1 read, gradient pass read + write, joiner backward read).  A joiner forwar
 its 64 lattice cells, so it produces the loss's row statistics (denom, skip / emit log-probabilities) in its
 epilogue (`wr_joint_fwd_lse`); the loss then only runs its lattice sweeps (`wr_rnnt_loss_fwd_from_lse`) -- pass 1,
 one full read of the logits (16.6 ms of the 50 ms loss step at B=32, T=1000, U=150, V=5000), is gone.  And because
-the logits are internal to the node, the gradient pass can write over them (done above 16 GiB of logits, where the
-footprint matters: one logits-sized tensor instead of two).
+the logits are internal to the node, the gradient pass writes over them: one logits-sized tensor instead of two.
 
 Results: costs and every gradient agree with the unfused path to fp32 rounding of the row log-sum-exp (the
 statistics are merged in a different order); tests/test_fused_gpu.py states the tolerance (1e-6 relative on costs).
@@ -71,10 +70,11 @@ class _JointRnntFn(torch.autograd.Function):
         B, T, U1, V = logits.shape
         dev = logits.device
         gc = grad_costs.to(torch.float32).contiguous()
-        # Nothing else holds the logits, so the gradient may overwrite them (one logits-sized tensor instead of two).
-        # Rewriting a line microseconds after reading it costs the gradient pass ~11 % (5.2 against 5.85 TB/s, DESIGN.md
-        # section 4), so this is done only where the footprint matters: above WR_FUSED_INPLACE_BYTES (default 16 GiB).
-        inplace = logits.numel() * logits.element_size() > int(os.environ.get("WR_FUSED_INPLACE_BYTES", str(16 << 30)))
+        # Nothing else holds the logits, so the gradient overwrites them (one logits-sized tensor instead of two).  With
+        # round 1's plain loads that cost the gradient pass ~11 % (a line rewritten microseconds after it was read); with
+        # the non-temporal loads of round 2 it costs nothing measurable (46.97 / 46.94 against 47.03 / 47.40 ms per
+        # 32-utterance step).  WR_FUSED_INPLACE_BYTES=n keeps a separate buffer below n bytes.
+        inplace = logits.numel() * logits.element_size() >= int(os.environ.get("WR_FUSED_INPLACE_BYTES", "0"))
         grads = logits if inplace else torch.empty_like(logits)
         with torch.cuda.device(dev):
             rc = lib.wr_rnnt_loss_bwd(_lib.ptr(logits), _lib.WR_F32, _lib.ptr(targets), _lib.ptr(llens), _lib.ptr(tlens),
