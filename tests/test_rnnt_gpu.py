@@ -122,6 +122,27 @@ def test_reductions_and_grad_scaling():
     np.testing.assert_allclose(grad, og * go[:, None, None, None], rtol=1e-4, atol=1e-5)
 
 
+def test_launch_shape_knobs_do_not_change_results():
+    """The streaming passes' launch shape (wr_tune_set keys 0-4: persistent grids of round 1, vectors in flight,
+    non-temporal bits) only changes which wave visits which row: costs and gradients are bit-identical to the automatic
+    grid's, on a shape large enough for several rows per wave (13 000 rows)."""
+    from wenet_celoss_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(12)
+    case = make_case(rng, 5, 130, 19, 200)
+    ref = run_hip(*case)
+    defaults = {0: 0, 1: 0, 2: 7, 3: 16, 4: 16}
+    try:
+        for knobs in ({0: 12, 1: 16}, {0: 1, 1: 1, 3: 4, 4: 4}, {2: 0, 3: 8, 4: 8}, {0: 4800, 1: 2048, 2: 6}):
+            for k, v in {**defaults, **knobs}.items():
+                assert lib.wr_tune_set(k, v) == 0
+            got = run_hip(*case)
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), knobs
+    finally:
+        for k, v in defaults.items():
+            lib.wr_tune_set(k, v)
+
+
 def test_inplace_gradient_matches():
     rng = np.random.default_rng(10)
     logits, targets, llens, tlens = make_case(rng, 3, 17, 8, 40)
