@@ -24,6 +24,8 @@
 //   fp32-equivalent (892 TFLOP/s of bf16 MFMA, 2.7x the exact-fp32 kernel), terms=1 13.8 ms; matrix cores 40 %
 //   busy (SQ_VALU_MFMA_BUSY_CYCLES) -- with one wave per SIMD the tile build, the k-loop and the epilogue of a
 //   workgroup do not overlap, and 138 KB of LDS per workgroup rules out a second one per CU.
+#include <type_traits>
+
 #include "wr_common.hpp"
 #include "joint_lse.hpp"
 
@@ -935,34 +937,78 @@ __global__ __launch_bounds__(256) void joint_bwd_dz_block_kernel(
     const float *__restrict__ gb = w + (b_in ? j0 + 4 * bc4 : 0);
     const int steps = (V + 15) / 16;
     struct Regs { f32x4 a[4], b[4]; };
-    auto gload = [&](int s, Regs &z) {
-        const int ss = s < steps ? s : steps - 1;
-        const int v = 16 * ss + 4 * av4;
-        const int vc = v < V ? v : V - 4;                   // V % 4 == 0
+    // staging in quarters (i = 0..3: one float4 of dY and one of W per thread), so that the main loop can spread a step's
+    // 8 global loads and 20 LDS writes over the MFMA groups of the step being computed
+    // `piece` 0..2 cuts a quarter once more (dY part / W part), so that a group of 4 MFMAs has at most three memory
+    // instructions and their address arithmetic in front of it; piece < 0: all of it
+    // Fast path (every step whose 16 v lie inside V): addresses are a wave-uniform base that advances with s plus a
+    // per-thread offset fixed for the whole kernel, and nothing is clamped or zeroed -- rows m >= M and columns j >= J read
+    // a clamped address and produce accumulator rows / columns the epilogue never stores.  VALU work of the same wave
+    // does NOT hide behind its MFMAs (tools/micro/mfma_valu_mix.hip: one VALU group per MFMA costs 14 % with one wave per
+    // SIMD), so the bounds logic below is kept out of the common path.
+    unsigned aoff[4], boff[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i) {
+        long m = m0 + arow + 64 * i;
+        m = m < M ? m : M - 1;
+        aoff[i] = (unsigned)(((m - m0) * V + 4 * av4) * sizeof(float));          // < 256 * V * 4 bytes
+        boff[i] = (unsigned)(((long)(br4 + 4 * i) * J + (b_in ? j0 + 4 * bc4 : 0)) * sizeof(float));
+    }
+    const char *__restrict__ abase = reinterpret_cast<const char *>(gout + (size_t)m0 * V);
+    const char *__restrict__ bbase = reinterpret_cast<const char *>(w);
+    auto gload_part = [&](int s, Regs &z, int i, int piece = -1, bool fast = false) {
+        if (fast) {                                                              // compile-time constant at the call sites
+            if (piece < 0 || piece == 0)
+                z.a[i] = *reinterpret_cast<const f32x4 *>(abase + (size_t)s * 16 * sizeof(float) + aoff[i]);
+            if (piece < 0 || piece == 1)
+                z.b[i] = *reinterpret_cast<const f32x4 *>(bbase + (size_t)s * 16 * J * sizeof(float) + boff[i]);
+            return;
+        }
+        const int ss = s < steps ? s : steps - 1;
+        if (piece < 0 || piece == 0) {
+            const int v = 16 * ss + 4 * av4;
+            const int vc = v < V ? v : V - 4;               // V % 4 == 0
             long m = m0 + arow + 64 * i;
             m = m < M ? m : M - 1;
             z.a[i] = *reinterpret_cast<const f32x4 *>(gout + (size_t)m * V + vc);
+        }
+        if (piece < 0 || piece == 1) {
             int vr = 16 * ss + br4 + 4 * i;
             vr = vr < V ? vr : V - 1;
             z.b[i] = *reinterpret_cast<const f32x4 *>(gb + (size_t)vr * J);
         }
     };
-    auto lwrite = [&](int s, const Regs &z) {
+    auto lwrite_part = [&](int s, const Regs &z, int i, int piece = -1, bool fast = false) {
         float *sa = zstage + (size_t)(s % kWStages) * kStageFloats;
         float *sb = sa + 16 * kZApad;
-        const bool a_in = 16 * s + 4 * av4 < V;
-        const f32x4 zero = (f32x4){0, 0, 0, 0};
+        const int r = arow + 64 * i;
+        if (fast) {                                                              // plain stores
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = arow + 64 * i;
+            for (int e = 0; e < 4; ++e)
+                if (piece < 0 || (e >> 1) == piece) sa[(4 * av4 + e) * kZApad + r] = z.a[i][e];
+            if (piece < 0 || piece == 2) *reinterpret_cast<f32x4 *>(sb + (br4 + 4 * i) * kZB + 4 * bc4) = z.b[i];
+            return;
+        }
+        const f32x4 zero = (f32x4){0, 0, 0, 0};
+        if (piece < 0 || piece == 0 || piece == 1) {
+            const bool a_in = 16 * s + 4 * av4 < V;
             const f32x4 av = (a_in && m0 + r < M) ? z.a[i] : zero;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sa[(4 * av4 + e) * kZApad + r] = av[e];
+            for (int e = 0; e < 4; ++e)
+                if (piece < 0 || (e >> 1) == piece) sa[(4 * av4 + e) * kZApad + r] = av[e];
+        }
+        if (piece < 0 || piece == 2) {
             const bool bon = b_in && 16 * s + br4 + 4 * i < V;
             *reinterpret_cast<f32x4 *>(sb + (br4 + 4 * i) * kZB + 4 * bc4) = bon ? z.b[i] : zero;
         }
+    };
+    auto gload = [&](int s, Regs &z) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gload_part(s, z, i);
+    };
+    auto lwrite = [&](int s, const Regs &z) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lwrite_part(s, z, i);
     };
 
     f32x16 acc[4][4];
@@ -971,17 +1017,41 @@ __global__ __launch_bounds__(256) void joint_bwd_dz_block_kernel(
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x16){0};
 
-    auto compute = [&](int s) {
-        const float *sa = zstage + (size_t)(s % kWStages) * kStageFloats + half * kZApad + 128 * mh + 4 * l31;
-        const float *sb = zstage + (size_t)(s % kWStages) * kStageFloats + 16 * kZApad + half * kZB + 128 * jh + 4 * l31;
-#pragma unroll 2
-        for (int kp = 0; kp < 8; ++kp) {                              // v = 2 kp + half
-            const f32x4 pa = *reinterpret_cast<const f32x4 *>(sa + 2 * kp * kZApad);
-            const f32x4 pb = *reinterpret_cast<const f32x4 *>(sb + 2 * kp * kZB);
+    // Step s: 8 pairs of v; per pair a lane reads one float4 of each operand and issues 16 MFMAs.  The fragments of pair
+    // kp + 1 are requested before the MFMAs of pair kp (the compiler does not pipeline this itself: it left the LDS latency
+    // open every second pair), and the staging of step s + 2 (LDS writes from z, pairs 0-3) and the global loads of step
+    // s + 4 (into z, pairs 4-7) ride between the MFMA groups instead of standing in front of them after the barrier:
+    // 119.8 -> 126.4 (fragment pipelining) -> see DESIGN.md for the final figure.  sched_barrier pins the pair boundaries.
+    const int frag_a = half * kZApad + 128 * mh + 4 * l31, frag_b = 16 * kZApad + half * kZB + 128 * jh + 4 * l31;
+    // pa / pb: the fragments of the step's first pair, already requested by the previous step (step s + 1 became visible at
+    // the barrier in front of step s, so its first fragments need not wait for the next barrier and its LDS latency)
+    auto compute = [&](int s, Regs &z, f32x4 &pa, f32x4 &pb, auto fast_tag) {
+        constexpr bool fast = decltype(fast_tag)::value;
+        const float *sa = zstage + (size_t)(s % kWStages) * kStageFloats + frag_a;
+        const float *sb = zstage + (size_t)(s % kWStages) * kStageFloats + frag_b;
+        const float *sn = zstage + (size_t)((s + 1) % kWStages) * kStageFloats;
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+        for (int kp = 0; kp < 8; ++kp) {                              // v = 2 kp + half
+            f32x4 na, nb;
+            if (kp < 7) {
+                na = *reinterpret_cast<const f32x4 *>(sa + 2 * (kp + 1) * kZApad);
+                nb = *reinterpret_cast<const f32x4 *>(sb + 2 * (kp + 1) * kZB);
+            } else {
+                na = *reinterpret_cast<const f32x4 *>(sn + frag_a);
+                nb = *reinterpret_cast<const f32x4 *>(sn + frag_b);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u < 3) {
+                    if (kp < 4) lwrite_part(s + 2, z, kp, u, fast);
+                    else if (u < 2) gload_part(s + 4, z, kp - 4, u, fast);
+                }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[t], pb[u], acc[t][u], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            pa = na;
+            pb = nb;
         }
     };
 
@@ -994,19 +1064,25 @@ __global__ __launch_bounds__(256) void joint_bwd_dz_block_kernel(
         lwrite(1, r0);
         gload(2, r0);
         gload(3, r1);
-        for (int s = 0; s < steps2; s += 2) {
+        __syncthreads();                                             // steps 0 and 1 visible
+        f32x4 pa = *reinterpret_cast<const f32x4 *>(zstage + frag_a);
+        f32x4 pb = *reinterpret_cast<const f32x4 *>(zstage + frag_b);
+        // main loop: every step staged (s + 2, s + 3) or loaded (s + 4, s + 5) during the two computes lies wholly inside V
+        // -> the branch-free staging path; the last few steps (V tail, the ghost step of an odd count) run the general one.
+        // Two loops in sequence, not a branch inside one: duplicated bodies inside one loop made the allocator shuffle the
+        // 256 accumulators between the copies.
+        int s = 0;
+        for (; s < steps2 && 16 * (s + 5) + 16 <= V; s += 2) {
+            __syncthreads();                                         // step s + 1 visible; the buffer of step s + 2 is free
+            compute(s, r0, pa, pb, std::true_type{});
             __syncthreads();
-            lwrite(s + 2, r0);
-            gload(s + 4, r0);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(s);
-            __builtin_amdgcn_sched_barrier(0);
+            compute(s + 1, r1, pa, pb, std::true_type{});
+        }
+        for (; s < steps2; s += 2) {
             __syncthreads();
-            lwrite(s + 3, r1);
-            gload(s + 5, r1);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(s + 1);
-            __builtin_amdgcn_sched_barrier(0);
+            compute(s, r0, pa, pb, std::false_type{});
+            __syncthreads();
+            compute(s + 1, r1, pa, pb, std::false_type{});
         }
     }
 
