@@ -740,6 +740,9 @@ __global__ __launch_bounds__(512) void joint_bwd_dw_split_kernel(
 // fp32 ([16][256] each, three LDS stages, global loads two steps ahead); per pair of cells a lane reads one float4
 // of each operand (its 4 interleaved tiles) and issues 16 MFMAs -- 128 MFMAs of 64 cycles per step against 16
 // ds_read_b128, so the k-loop is matrix-core bound.  Padded cells are excluded through the lengths.
+// MASKED = false (no length arrays: the fused joiner + loss node, whose gradient is zero in padded cells): the main loop
+// runs the branch-free staging path; MASKED = true keeps the per-row validity arithmetic of the general path throughout.
+template <bool MASKED>
 __global__ __launch_bounds__(256) void joint_bwd_dw_block_kernel(
     const float *__restrict__ gout /* [M, V] */, const float *__restrict__ h /* [M, J] */,
     const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens, int T, int U1, long M, int V, int J, int n_vs,
@@ -764,6 +767,22 @@ __global__ __launch_bounds__(256) void joint_bwd_dw_block_kernel(
     const float *__restrict__ ga = gout + (a_in ? v0 + 4 * c4 : 0);
     const float *__restrict__ gb = h + (b_in ? j0 + 4 * c4 : 0);
     struct Regs { f32x4 a[4], b[4]; int on; };
+    // Fast path (no lengths, all 16 cells of the step inside the part's range): a wave-uniform base that advances with s
+    // plus a per-thread offset fixed for the whole kernel, no masks -- VALU work of the same wave does not hide behind its
+    // MFMAs (tools/micro/mfma_valu_mix.hip), so the general path's validity arithmetic and selects stay out of the main
+    // loop.  Columns v >= V / j >= J read a clamped address and produce rows / columns of dW that are never stored.
+    unsigned aoff[4], boff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        aoff[i] = (unsigned)(((long)(r4 + 4 * i) * V + (a_in ? v0 + 4 * c4 : 0)) * sizeof(float));
+        boff[i] = (unsigned)(((long)(r4 + 4 * i) * J + (b_in ? j0 + 4 * c4 : 0)) * sizeof(float));
+    }
+    const char *__restrict__ abase = reinterpret_cast<const char *>(gout + (size_t)mb * V);
+    const char *__restrict__ bbase = reinterpret_cast<const char *>(h + (size_t)mb * J);
+    auto gload_fast = [&](int s, Regs &z, int i) {
+        z.a[i] = *reinterpret_cast<const f32x4 *>(abase + (size_t)s * 16 * V * sizeof(float) + aoff[i]);
+        z.b[i] = *reinterpret_cast<const f32x4 *>(bbase + (size_t)s * 16 * J * sizeof(float) + boff[i]);
+    };
     auto gload = [&](int s, Regs &z) {
         z.on = 0;
 #pragma unroll
@@ -772,7 +791,7 @@ __global__ __launch_bounds__(256) void joint_bwd_dw_block_kernel(
             // validity of the row, evaluated here -- two steps ahead of its use -- so that the length loads travel with
             // the operand loads
             bool on = m < me;
-            if (on && llens != nullptr) {                             // M < 2^31 (checked by the caller): 32-bit divisions
+            if (MASKED && on) {                                       // M < 2^31 (checked by the caller): 32-bit divisions
                 const unsigned mu = (unsigned)m, bt = mu / (unsigned)U1, u = mu - bt * (unsigned)U1;
                 const unsigned b = bt / (unsigned)T, t = bt - b * (unsigned)T;
                 on = ((int)t < llens[b]) && ((int)u <= tlens[b]);
@@ -784,6 +803,13 @@ __global__ __launch_bounds__(256) void joint_bwd_dw_block_kernel(
         }
     };
     f32x4 dbacc = (f32x4){0, 0, 0, 0};
+    auto lwrite_fast = [&](int s, const Regs &z, int i) {
+        float *sa = fstage + (size_t)(s % kWStages) * 2 * 16 * kWB;
+        float *sb = sa + 16 * kWB;
+        dbacc += z.a[i];
+        *reinterpret_cast<f32x4 *>(sa + (r4 + 4 * i) * kWB + 4 * c4) = z.a[i];
+        *reinterpret_cast<f32x4 *>(sb + (r4 + 4 * i) * kWB + 4 * c4) = z.b[i];
+    };
     auto lwrite = [&](int s, const Regs &z) {
         float *sa = fstage + (size_t)(s % kWStages) * 2 * 16 * kWB;
         float *sb = sa + 16 * kWB;
@@ -805,17 +831,43 @@ __global__ __launch_bounds__(256) void joint_bwd_dw_block_kernel(
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x16){0};
 
-    auto compute = [&](int s) {
-        const float *sa = fstage + (size_t)(s % kWStages) * 2 * 16 * kWB + half * kWB + 128 * vh + 4 * l31;
-        const float *sb = fstage + (size_t)(s % kWStages) * 2 * 16 * kWB + 16 * kWB + half * kWB + 128 * jh + 4 * l31;
-#pragma unroll 2
-        for (int kp = 0; kp < 8; ++kp) {                              // cells 2 kp + half
-            const f32x4 pa = *reinterpret_cast<const f32x4 *>(sa + 2 * kp * kWB);
-            const f32x4 pb = *reinterpret_cast<const f32x4 *>(sb + 2 * kp * kWB);
+    // Step s: 8 pairs of cells; per pair a lane reads one float4 of each operand and issues 16 MFMAs.  As in the dZ block
+    // kernel below: the fragments of the next pair (and, at the end of a step, of the next step, which became visible at the
+    // barrier in front of this one) are requested before the current pair's MFMAs, and in the fast path the staging of step
+    // s + 2 (pairs 0-3) and the loads of step s + 4 (pairs 4-7) ride between the MFMA groups.
+    const int frag_a = half * kWB + 128 * vh + 4 * l31, frag_b = 16 * kWB + half * kWB + 128 * jh + 4 * l31;
+    auto compute = [&](int s, Regs &z, f32x4 &pa, f32x4 &pb, auto fast_tag) {
+        constexpr bool fast = decltype(fast_tag)::value;
+        const float *sa = fstage + (size_t)(s % kWStages) * 2 * 16 * kWB + frag_a;
+        const float *sb = fstage + (size_t)(s % kWStages) * 2 * 16 * kWB + frag_b;
+        const float *sn = fstage + (size_t)((s + 1) % kWStages) * 2 * 16 * kWB;
+        if (!fast) {
+            lwrite(s + 2, z);
+            gload(s + 4, z);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+        for (int kp = 0; kp < 8; ++kp) {                              // cells 2 kp + half
+            f32x4 na, nb;
+            if (kp < 7) {
+                na = *reinterpret_cast<const f32x4 *>(sa + 2 * (kp + 1) * kWB);
+                nb = *reinterpret_cast<const f32x4 *>(sb + 2 * (kp + 1) * kWB);
+            } else {
+                na = *reinterpret_cast<const f32x4 *>(sn + frag_a);
+                nb = *reinterpret_cast<const f32x4 *>(sn + frag_b);
+            }
+            if (fast) {
+                if (kp < 4) lwrite_fast(s + 2, z, kp);
+                else gload_fast(s + 4, z, kp - 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[t], pb[u], acc[t][u], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            pa = na;
+            pb = nb;
         }
     };
 
@@ -828,19 +880,25 @@ __global__ __launch_bounds__(256) void joint_bwd_dw_block_kernel(
         lwrite(1, r0);
         gload(2, r0);
         gload(3, r1);
-        for (int s = 0; s < steps2; s += 2) {
+        __syncthreads();                                             // steps 0 and 1 visible
+        f32x4 pa = *reinterpret_cast<const f32x4 *>(fstage + frag_a);
+        f32x4 pb = *reinterpret_cast<const f32x4 *>(fstage + frag_b);
+        // main loop: no lengths, and the steps staged / loaded during the two computes (s + 2 .. s + 5) lie wholly inside the
+        // part's range; then the general loop for the tail (two loops in sequence: duplicated bodies inside one loop made the
+        // allocator shuffle the 256 accumulators between the copies)
+        int s = 0;
+        if (!MASKED)
+            for (; s < steps2 && mb + 16L * (s + 5) + 16 <= me; s += 2) {
+                __syncthreads();
+                compute(s, r0, pa, pb, std::true_type{});
+                __syncthreads();
+                compute(s + 1, r1, pa, pb, std::true_type{});
+            }
+        for (; s < steps2; s += 2) {
             __syncthreads();
-            lwrite(s + 2, r0);
-            gload(s + 4, r0);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(s);
-            __builtin_amdgcn_sched_barrier(0);
+            compute(s, r0, pa, pb, std::false_type{});
             __syncthreads();
-            lwrite(s + 3, r1);
-            gload(s + 5, r1);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(s + 1);
-            __builtin_amdgcn_sched_barrier(0);
+            compute(s + 1, r1, pa, pb, std::false_type{});
         }
     }
 
@@ -1197,10 +1255,17 @@ int joint_bwd_dw_block(const float *gout_d, const float *h_d, const int32_t *lle
     long rows_per_part = (M + parts - 1) / parts;
     rows_per_part = (rows_per_part + 15) / 16 * 16;
     const size_t lds = (size_t)kWStages * 2 * 16 * kWB * sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_bwd_dw_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    hipLaunchKernelGGL(joint_bwd_dw_block_kernel, dim3(n_vs * n_js * parts), dim3(256), lds, st, gout_d, h_d, llens_d, tlens_d, T,
-                       U1, M, V, J, n_vs, n_js, rows_per_part, part_dw, part_db);
+    if (llens_d != nullptr && tlens_d != nullptr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_bwd_dw_block_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(joint_bwd_dw_block_kernel<true>, dim3(n_vs * n_js * parts), dim3(256), lds, st, gout_d, h_d, llens_d,
+                           tlens_d, T, U1, M, V, J, n_vs, n_js, rows_per_part, part_dw, part_db);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_bwd_dw_block_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(joint_bwd_dw_block_kernel<false>, dim3(n_vs * n_js * parts), dim3(256), lds, st, gout_d, h_d, llens_d,
+                           tlens_d, T, U1, M, V, J, n_vs, n_js, rows_per_part, part_dw, part_db);
+    }
     WR_CHECK_LAUNCH("joint_bwd_dw_block_kernel");
     hipLaunchKernelGGL(split_dw_reduce_kernel, dim3(1024), dim3(256), 0, st, part_dw, part_db, parts, (long)V * J, V, dw_d, db_d);
     WR_CHECK_LAUNCH("split_dw_reduce_kernel");
