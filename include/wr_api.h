@@ -57,7 +57,7 @@ const char *wr_last_error(void);
  * logits per wave in the gradient pass; n > 0: a persistent grid of n workgroups per CU as in round 1), key 2: non-temporal bits (1: gradient-pass loads, 2: gradient-pass
  * stores, 4: row-lse loads; default 7), key 3 / key 4: 16-byte vectors in flight per lane in the gradient (4, 8 or 16;
  * default 16) / row-lse pass (4, 8 or 16; default 16),
- * key 5: retired (the superseded joiner forward variants were removed), key 6: decoder GEMM lane
+ * key 5: exact-fp32 joiner forward (default: fragment-layout operands; 1: the first forward kernel, bit-identical), key 6: decoder GEMM lane
  * tile (0: by occupancy, 1: 32 lanes, 2: 64 lanes), key 7: column parts of the split joiner forward (0: automatic),
  * key 8: retired (the 64-cell split dZ tiling was removed), key 9 / key 10: exact dW / dZ tiling (0: 256 x 256 blocks,
  * 1: the first tilings of joint.hip), key 11: greedy / beam micro-step with an LSTM predictor (0: projection folded

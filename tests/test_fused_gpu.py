@@ -13,6 +13,14 @@ import oracle
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
+
+@pytest.fixture(autouse=True, params=["epilogue", "row-pass"])
+def lse_mode(request, monkeypatch):
+    """Every test of this file runs with the loss's row statistics coming from the joiner forward's epilogue and from the
+    loss's own row pass (the node picks per precision; WR_FUSED_LSE_EPILOGUE forces one)."""
+    monkeypatch.setenv("WR_FUSED_LSE_EPILOGUE", "1" if request.param == "epilogue" else "0")
+    return request.param
+
 CASES = [  # B, T, U, J, V, ragged
     (2, 9, 4, 16, 50, False),
     (3, 70, 11, 32, 257, True),      # several 64-cell tiles, odd V (scalar tails, column padding)

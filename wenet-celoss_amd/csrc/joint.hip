@@ -36,7 +36,7 @@ constexpr int kBN = 256;       // output columns per chunk (4 waves x 64)
 constexpr int kBK = 8;         // k-slice depth of the streamed operand (forward)
 constexpr int kHPad = kBM + 1; // k-major activation tile row stride (floats)
 
-inline int joint_vpad(int V) { return (V + kBN - 1) / kBN * kBN; }
+inline int joint_vpad(int V) { return (V + 2 * kBN - 1) / (2 * kBN) * (2 * kBN); }   // whole 512-column chunks (8 waves x 2 tiles)
 inline int joint_jpad(int J) { return (J + 31) / 32 * 32; }   // forward k-depth, zero padded (multiple of 2*PFK)
 
 // W [V, J] row-major (nn.Linear weight)  ->  Wt [J, Vp] (k-major, zero padded to a multiple of 256 columns)
@@ -85,8 +85,8 @@ __device__ __forceinline__ void fill_h_tile(float *__restrict__ Ht, const float 
 // and no LDS write at all -- only the read-only activation tile lives in LDS.
 // LSE = true: the epilogue also produces the RNN-T loss's row statistics (joint_lse.hpp) -- the workgroup owns
 // every column of its 64 cells, so pass 1 of the loss never has to read the logits back.
-template <int PFK, int CT /* 32-column tiles per wave: 1 -> 8 waves */, bool LSE>
-__global__ __launch_bounds__(CT == 2 ? 256 : 512) void joint_fwd_direct_kernel(
+template <int PFK, int CT /* 32-column tiles per wave */, bool LSE, int NW = (CT == 2 ? 4 : 8) /* waves */>
+__global__ __launch_bounds__(64 * NW) void joint_fwd_direct_kernel(
     const float *__restrict__ ep, const float *__restrict__ pp, const float *__restrict__ wt /* [Jp, Vp] */,
     const float *__restrict__ bias, const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens,
     int B, int T, int U1, int J, int Jp, int V, int Vp, int act, float *__restrict__ out, JointLse lse)
@@ -116,13 +116,14 @@ __global__ __launch_bounds__(CT == 2 ? 256 : 512) void joint_fwd_direct_kernel(
     fill_h_tile(Ht, ep, pp, m0, M, T, U1, J, Jp, act);
     __syncthreads();
 
-    const int nchunks = Vp / kBN;
+    constexpr int kChunk = NW * 32 * CT;                // output columns per chunk
+    const int nchunks = Vp / kChunk;
     const int half = lane >> 5, l31 = lane & 31;
     const int wcol = wave * (32 * CT);
     const float *__restrict__ Ah = Ht + half * kHPad + l31;       // + k * kHPad (+32 for the second row tile)
 
     for (int nc = 0; nc < nchunks; ++nc) {
-        const int v0 = nc * kBN;
+        const int v0 = nc * kChunk;
         f32x16 acc[2][CT];
 #pragma unroll
         for (int r = 0; r < 2; ++r)
@@ -180,7 +181,156 @@ __global__ __launch_bounds__(CT == 2 ? 256 : 512) void joint_fwd_direct_kernel(
     }
     if (LSE) {
         __syncthreads();                               // every wave is done with the activation tile: reuse its storage
-        joint_lse_finish<CT == 2 ? 4 : 8>(lse, lds, rm, rs, llens, tlens, out, m0, M, T, U1, V);
+        joint_lse_finish<NW>(lse, lds, rm, rs, llens, tlens, out, m0, M, T, U1, V);
+    }
+}
+
+// ---- forward, fragment layout ------------------------------------------------------------------------------------
+// Same ownership (64 cells x all V columns per workgroup, 8 waves, one 32-column tile per wave and chunk), but both MFMA
+// operands arrive 16 bytes per lane and instruction: VALU / VMEM instructions of a wave do not hide behind its own MFMAs
+// (tools/micro/mfma_valu_mix.hip), and the kernel above issues 1.5 four-byte loads per MFMA.  Here
+//   W is re-laid once per call as  wf[(ct * KG + kg) * 64 + lane] = float4{ W[32 ct + l31][8 kg + 2 i + half], i = 0..3 }
+//     (ct: 32-column tile, kg: group of 8 k, lane = 32 half + l31): one global_load_dwordx4 feeds 4 MFMAs per row tile;
+//   H lives in LDS as  Ht[row][half][k >> 1]  (row stride Jp + 4 floats: conflict-free ds_read_b128): one read = the A
+//     operands of 4 MFMAs.
+// 0.375 load instructions per MFMA instead of 1.5.
+constexpr int kFPF = 2;                                // k-groups (of 8 k) in flight per register set
+
+__global__ void joint_frag_w_kernel(const float *__restrict__ w, int V, int J, int Jp, int Vp, float4 *__restrict__ wf)
+{
+    const int KG = Jp / 8;
+    const long n = (long)(Vp / 32) * KG * 64;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const long g = idx >> 6;
+        const int kg = (int)(g % KG), ct = (int)(g / KG);
+        const int v = 32 * ct + (lane & 31), half = lane >> 5;
+        float x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = 8 * kg + 2 * i + half;
+            x[i] = (v < V && k < J) ? w[(size_t)v * J + k] : 0.f;
+        }
+        wf[idx] = make_float4(x[0], x[1], x[2], x[3]);
+    }
+}
+
+template <bool LSE, int CT>
+__global__ __launch_bounds__(512) void joint_fwd_frag_kernel(
+    const float *__restrict__ ep, const float *__restrict__ pp, const float4 *__restrict__ wf, const float *__restrict__ bias,
+    const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens, int B, int T, int U1, int J, int Jp, int V, int Vp,
+    int act, float *__restrict__ out, JointLse lse)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int AS = Jp + 4;                            // row stride of the activation tile (floats)
+    float *Ht = lds;                                  // [64][AS]
+    const long M = (long)B * T * U1;
+    const long m0 = (long)blockIdx.x * kBM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    float rm[32], rs[32];
+    if (LSE) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { rm[i] = -3.0e38f; rs[i] = 0.f; }
+    }
+    if (llens != nullptr && tlens != nullptr) {
+        int valid = 0;
+        const long m = m0 + tid;
+        if (tid < kBM && m < M) {
+            const long bt = m / U1;
+            const int u = (int)(m - bt * U1);
+            const int b = (int)(bt / T), t = (int)(bt - (long)b * T);
+            valid = (t < llens[b]) && (u <= tlens[b]);
+        }
+        if (!__syncthreads_or(valid)) return;
+    }
+    // activation tile: Ht[row][k & 1][k >> 1]
+    for (int row = wave; row < kBM; row += 8) {
+        const long m = m0 + row;
+        float *hr = Ht + (size_t)row * AS;
+        if (m < M) {
+            const long bt = m / U1;
+            const int u = (int)(m - bt * U1);
+            const long b = bt / T;
+            const float *__restrict__ e = ep + (size_t)bt * J;
+            const float *__restrict__ p = pp + ((size_t)b * U1 + u) * J;
+            for (int k = lane; k < Jp; k += 64) hr[(k & 1) * (Jp / 2) + (k >> 1)] = (k < J) ? act_value(act, e[k] + p[k]) : 0.f;
+        } else {
+            for (int k = lane; k < Jp; k += 64) hr[k] = 0.f;
+        }
+    }
+    __syncthreads();
+
+    const int KG = Jp / 8;                            // Jp is a multiple of 32: KG a multiple of kFPF
+    constexpr int kChunk = 8 * 32 * CT;
+    const int nchunks = Vp / kChunk;
+    const f32x4 *__restrict__ A0 = reinterpret_cast<const f32x4 *>(Ht + (size_t)l31 * AS + half * (Jp / 2));
+    const f32x4 *__restrict__ A1 = reinterpret_cast<const f32x4 *>(Ht + (size_t)(l31 + 32) * AS + half * (Jp / 2));
+    // register set P is loaded one block ahead ACROSS chunk boundaries: the last block of a chunk requests the first
+    // block of the next chunk's W tile, so a chunk does not start by waiting out an L2 round trip (one per 32 768 MFMA
+    // cycles otherwise)
+    f32x4 pb[CT][kFPF], pa0[kFPF], pa1[kFPF], qb[CT][kFPF], qa0[kFPF], qa1[kFPF];
+#define WR_LOADF(B_, b_, a0_, a1_, g_)                                                 \
+        _Pragma("unroll") for (int i = 0; i < kFPF; ++i) {                             \
+            _Pragma("unroll") for (int c = 0; c < CT; ++c) b_[c][i] = B_[((size_t)c * KG + (g_) + i) * 64]; \
+            a0_[i] = A0[(g_) + i];                                                     \
+            a1_[i] = A1[(g_) + i];                                                     \
+        }
+    {
+        const f32x4 *__restrict__ Bfirst = reinterpret_cast<const f32x4 *>(wf) + (size_t)(wave * CT) * KG * 64 + lane;
+        WR_LOADF(Bfirst, pb, pa0, pa1, 0)
+    }
+    for (int nc = 0; nc < nchunks; ++nc) {
+        const int v0 = nc * kChunk;
+        const int ct = (v0 >> 5) + wave * CT;
+        f32x16 acc[2][CT];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[r][c] = (f32x16){0};
+        const f32x4 *__restrict__ Bf = reinterpret_cast<const f32x4 *>(wf) + (size_t)ct * KG * 64 + lane;
+        const f32x4 *__restrict__ Bnext = nc + 1 < nchunks ? Bf + (size_t)8 * CT * KG * 64 : Bf;
+#define WR_MFMAF(b_, a0_, a1_)                                                          \
+        _Pragma("unroll") for (int i = 0; i < kFPF; ++i)                               \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q)                              \
+                _Pragma("unroll") for (int c = 0; c < CT; ++c) {                       \
+                    acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_[i][q], b_[c][i][q], acc[0][c], 0, 0, 0); \
+                    acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_[i][q], b_[c][i][q], acc[1][c], 0, 0, 0); \
+                }
+        for (int g = 0; g < KG; g += 2 * kFPF) {
+            WR_LOADF(Bf, qb, qa0, qa1, g + kFPF)
+            __builtin_amdgcn_sched_barrier(0);
+            WR_MFMAF(pb, pa0, pa1)
+            __builtin_amdgcn_sched_barrier(0);
+            const bool wrap = g + 2 * kFPF >= KG;
+            const int g2 = wrap ? 0 : g + 2 * kFPF;
+            const f32x4 *__restrict__ B2 = wrap ? Bnext : Bf;
+            WR_LOADF(B2, pb, pa0, pa1, g2)
+            __builtin_amdgcn_sched_barrier(0);
+            WR_MFMAF(qb, qa0, qa1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef WR_MFMAF
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int col = v0 + 32 * (wave * CT + c) + l31;
+            const float bv = (col < V) ? bias[col] : 0.f;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const long m = m0 + row;
+                    const float x = acc[rt][c][r] + bv;
+                    if (m < M && col < V) out[(size_t)m * V + col] = x;
+                    if (LSE) joint_lse_add(rm[rt * 16 + r], rs[rt * 16 + r], x, col < V, nc == 0 && c == 0);
+                }
+        }
+    }
+#undef WR_LOADF
+    if (LSE) {
+        __syncthreads();
+        joint_lse_finish<8>(lse, lds, rm, rs, llens, tlens, out, m0, M, T, U1, V);
     }
 }
 
@@ -507,12 +657,35 @@ int joint_fwd_launch(const float *ep_d, const float *pp_d, const float *w_out_d,
     const int Vp = joint_vpad(V), Jp = joint_jpad(J);
     WR_REQUIRE(workspace_bytes >= (size_t)Jp * Vp * sizeof(float), WR_EWORKSPACE, "joint_fwd: workspace too small");
     float *wt = static_cast<float *>(workspace_d);
-    hipLaunchKernelGGL(joint_transpose_w_kernel, dim3(Vp / 32, (Jp + 31) / 32), dim3(256), 0, st, w_out_d, V, J, Jp, Vp,
-                       wt);
-    WR_CHECK_LAUNCH("joint_transpose_w_kernel");
     const long M = (long)B * T * U1;
     const dim3 grid((unsigned)((M + kBM - 1) / kBM));
     const size_t tile = (size_t)Jp * kHPad * sizeof(float);
+    // default: the fragment-layout kernel; wr_tune_set(5, 1) selects the first forward kernel (kept for the equivalence test)
+    if (tune_get(kTuneJointFwdVariant) != 1) {
+        float4 *wf = static_cast<float4 *>(workspace_d);
+        hipLaunchKernelGGL(joint_frag_w_kernel, dim3(1024), dim3(256), 0, st, w_out_d, V, J, Jp, Vp, wf);
+        const size_t tile2 = (size_t)kBM * (Jp + 4) * sizeof(float);
+        if (lse == nullptr) {
+#define WR_LAUNCH_FRAG(LSE_, CT_, lds_, lse_)                                                                          \
+            do {                                                                                                      \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_fwd_frag_kernel<LSE_, CT_>),             \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_));                    \
+                hipLaunchKernelGGL((joint_fwd_frag_kernel<LSE_, CT_>), grid, dim3(512), lds_, st, ep_d, pp_d, wf, b_out_d, \
+                                   logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, act, out_d, lse_);       \
+            } while (0)
+            WR_LAUNCH_FRAG(false, 1, tile2, JointLse{});
+        } else {
+            const size_t lds2 = tile2 > joint_lse_exchange_bytes(8) ? tile2 : joint_lse_exchange_bytes(8);
+            (void)hipMemsetAsync(lse->repair, 0, sizeof(int32_t), st);
+            WR_LAUNCH_FRAG(true, 1, lds2, *lse);
+#undef WR_LAUNCH_FRAG
+        }
+        WR_CHECK_LAUNCH("joint_fwd_frag_kernel");
+        return WR_OK;
+    }
+    hipLaunchKernelGGL(joint_transpose_w_kernel, dim3(Vp / 32, (Jp + 31) / 32), dim3(256), 0, st, w_out_d, V, J, Jp, Vp,
+                       wt);
+    WR_CHECK_LAUNCH("joint_transpose_w_kernel");
     if (lse == nullptr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_fwd_direct_kernel<8, 1, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile);

@@ -3,9 +3,11 @@
 
 Why one node.  The unfused pair moves the (B, T, U+1, V) logits tensor through HBM five times (joiner write, loss
 pass 1 read, gradient pass read + write, joiner backward read).  A joiner forward workgroup owns every column of
-its 64 lattice cells, so it produces the loss's row statistics (denom, skip / emit log-probabilities) in its
-epilogue (`wr_joint_fwd_lse`); the loss then only runs its lattice sweeps (`wr_rnnt_loss_fwd_from_lse`) -- pass 1,
-one full read of the logits (16.6 ms of the 50 ms loss step at B=32, T=1000, U=150, V=5000), is gone.  And because
+its 64 lattice cells, so it can produce the loss's row statistics (denom, skip / emit log-probabilities) in its
+epilogue (`wr_joint_fwd_lse`); the loss then only runs its lattice sweeps (`wr_rnnt_loss_fwd_from_lse`) and pass 1,
+one full read of the logits, is gone.  Whether that pays is a measurement (see `forward` below): the split-precision
+forward takes the epilogue, the exact-fp32 forward runs the loss's own row pass (14 ms per 32 utterances at the BASELINE
+shape since the round-2 launch-shape change).  And because
 the logits are internal to the node, the gradient pass writes over them: one logits-sized tensor instead of two.
 
 Results: costs and every gradient agree with the unfused path to fp32 rounding of the row log-sum-exp (the
@@ -41,7 +43,27 @@ class _JointRnntFn(torch.autograd.Function):
         costs = torch.empty(B, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             st = _lib.current_stream(dev)
-            if terms == 0:
+            # Row statistics of the loss: as the joiner forward's epilogue (wr_joint_fwd*_lse) or as the loss's own row pass.
+            # Round 2 measured both ways per 8 utterances at the BASELINE shape: the split-precision forward pays 1.7 ms for
+            # the epilogue against 3.5 ms for the row pass (epilogue wins); the exact-fp32 forward, since its fragment-layout
+            # rewrite, pays 5.6 ms (54.8 against 49.2 ms: the epilogue's vector work does not hide behind the wave's own
+            # MFMAs) against the same 3.5 ms (the row pass wins).  WR_FUSED_LSE_EPILOGUE=1 / 0 forces either.
+            epi = os.environ.get("WR_FUSED_LSE_EPILOGUE")
+            epilogue = (terms != 0) if epi is None else (epi == "1")
+            if terms == 0 and not epilogue:
+                ws_bytes = lib.wr_joint_workspace_bytes(J, V)
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                rc = lib.wr_joint_fwd(_lib.ptr(ep), _lib.ptr(pp), _lib.ptr(w), _lib.ptr(b), _lib.ptr(llens), _lib.ptr(tlens),
+                                      B, T, U1, J, V, act, _lib.ptr(logits), _lib.ptr(ws), ws_bytes, st)
+                _lib.check(rc, "wr_joint_fwd")
+            elif not epilogue:
+                ws_bytes = lib.wr_joint_split_workspace_bytes(J, V)
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                rc = lib.wr_joint_fwd_split(_lib.ptr(ep), _lib.ptr(pp), _lib.ptr(w), _lib.ptr(b), _lib.ptr(llens),
+                                            _lib.ptr(tlens), B, T, U1, J, V, act, terms, _lib.ptr(logits), _lib.WR_F32,
+                                            _lib.ptr(ws), ws_bytes, st)
+                _lib.check(rc, "wr_joint_fwd_split")
+            elif terms == 0:
                 ws_bytes = lib.wr_joint_workspace_bytes(J, V)
                 ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
                 rc = lib.wr_joint_fwd_lse(_lib.ptr(ep), _lib.ptr(pp), _lib.ptr(w), _lib.ptr(b), _lib.ptr(llens),
@@ -55,9 +77,14 @@ class _JointRnntFn(torch.autograd.Function):
                                                 _lib.ptr(tlens), _lib.ptr(targets), B, T, U1, J, V, act, blank, terms,
                                                 _lib.ptr(logits), _lib.ptr(ws), ws_bytes, _lib.ptr(rws), rws_bytes, st)
                 _lib.check(rc, "wr_joint_fwd_split_lse")
-            rc = lib.wr_rnnt_loss_fwd_from_lse(_lib.ptr(logits), _lib.ptr(targets), _lib.ptr(llens), _lib.ptr(tlens), B, T, U1,
-                                               V, blank, _lib.ptr(costs), _lib.ptr(rws), rws_bytes, st)
-            _lib.check(rc, "wr_rnnt_loss_fwd_from_lse")
+            if epilogue:
+                rc = lib.wr_rnnt_loss_fwd_from_lse(_lib.ptr(logits), _lib.ptr(targets), _lib.ptr(llens), _lib.ptr(tlens), B, T,
+                                                   U1, V, blank, _lib.ptr(costs), _lib.ptr(rws), rws_bytes, st)
+                _lib.check(rc, "wr_rnnt_loss_fwd_from_lse")
+            else:
+                rc = lib.wr_rnnt_loss_fwd(_lib.ptr(logits), _lib.WR_F32, _lib.ptr(targets), _lib.ptr(llens), _lib.ptr(tlens), B,
+                                          T, U1, V, blank, _lib.ptr(costs), _lib.ptr(rws), rws_bytes, st)
+                _lib.check(rc, "wr_rnnt_loss_fwd")
         ctx.save_for_backward(ep, pp, w, targets, llens, tlens, logits, rws)
         ctx.blank, ctx.clamp, ctx.terms, ctx.act = blank, clamp, terms, act
         return costs
