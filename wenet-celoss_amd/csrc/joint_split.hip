@@ -386,7 +386,8 @@ __device__ __forceinline__ void split8(const f32x4 &a, const f32x4 &b, bf16x8 &h
 constexpr int kZM2 = 128;        // cells per workgroup
 constexpr int kZStages = 3;
 
-template <int TERMS>
+// FULL: all 16 column tiles are in use (J = 512, the shipped join_dim): no per-tile guards in the k-loop
+template <int TERMS, bool FULL>
 __global__ __launch_bounds__(256) void joint_bwd_dz_split128_kernel(
     const float *__restrict__ gout /* [M, V] */, const float *__restrict__ ep, const float *__restrict__ pp,
     const u32x4 *__restrict__ wh, const u32x4 *__restrict__ wl, const int32_t *__restrict__ llens,
@@ -459,6 +460,19 @@ __global__ __launch_bounds__(256) void joint_bwd_dz_split128_kernel(
 #pragma unroll
         for (int q = 0; q < 8; ++q) st[tid + 256 * q] = z.v[q];
     };
+    // the same, one fragment chunk at a time and without clamps (every step < steps: the fragment index is linear in the
+    // step, ((jt * D + d) * 2 + t) = jt * 2D + s), for the main loop, which spreads a step's 8 LDS writes and 8 global loads
+    // over the 16 column tiles of the step being computed
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto wload_fast = [&](int s, WRegs &z, int q) {
+        int jt = (wave_u + 4 * q) & 15;
+        jt = (FULL || jt < n_jt) ? jt : n_jt - 1;
+        const u32x4 *img = (q < 4 || TERMS != 3) ? wh : wl;
+        z.v[q] = img[((size_t)jt * 2 * D + s) * 64 + lane];
+    };
+    auto wwrite_fast = [&](int s, const WRegs &z, int q) {
+        stage[(size_t)(s % kZStages) * 2 * 16 * 64 + tid + 256 * q] = z.v[q];
+    };
     // dY of this lane's row: 16 floats per double step (elements 0-7 feed the even step, 8-15 the odd one)
     struct ARegs { f32x4 a[4]; };
     auto aload = [&](int d, ARegs &z) {
@@ -475,22 +489,44 @@ __global__ __launch_bounds__(256) void joint_bwd_dz_split128_kernel(
                 z.a[i][e] = v < V ? arow[32 * Dfull + 4 * i + e] : 0.f;
             }
     };
-    auto compute = [&](int s, const ARegs &z) {
+    auto compute = [&](int s, const ARegs &z, WRegs &zw, auto fast_tag) {
+        constexpr bool fast = decltype(fast_tag)::value;
         const int t = s & 1;
+        if (!fast) {
+            wwrite(s + 2, zw);
+            wload(s + 4, zw);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         bf16x8 ah, al;
         split8(z.a[2 * t], z.a[2 * t + 1], ah, al, TERMS == 3);
         const u32x4 *st = stage + (size_t)(s % kZStages) * 2 * 16 * 64 + lane;
+        // the fragments of column tile c + 2 are requested before the MFMAs of tile c (the compiler issued each tile's two
+        // reads directly in front of its three MFMAs: an LDS round trip per 96 matrix-core cycles, the reason these kernels
+        // ran the matrix cores 40 % busy); tiles past n_jt read a valid stage address and feed nothing
+        u32x4 rh[3], rl[3];
+        rh[0] = st[0];
+        rh[1] = st[64];
+        if (TERMS == 3) { rl[0] = st[16 * 64]; rl[1] = st[17 * 64]; }
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-            if (c < n_jt) {
-                const bf16x8 bhv = __builtin_bit_cast(bf16x8, st[c * 64]);
+            if (c + 2 < 16) {
+                rh[(c + 2) % 3] = st[(c + 2) * 64];
+                if (TERMS == 3) rl[(c + 2) % 3] = st[(16 + c + 2) * 64];
+            }
+            if (fast) {                                      // staging of step s + 2 (tiles 0-7), loads of step s + 4 (tiles 8-15)
+                if (c < 8) wwrite_fast(s + 2, zw, c);
+                else wload_fast(s + 4, zw, c - 8);
+            }
+            if (FULL || c < n_jt) {
+                const bf16x8 bhv = __builtin_bit_cast(bf16x8, rh[c % 3]);
                 if (TERMS == 3) {
-                    const bf16x8 blv = __builtin_bit_cast(bf16x8, st[(16 + c) * 64]);
+                    const bf16x8 blv = __builtin_bit_cast(bf16x8, rl[c % 3]);
                     acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bhv, acc[c], 0, 0, 0);
                     acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blv, acc[c], 0, 0, 0);
                 }
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhv, acc[c], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -504,34 +540,36 @@ __global__ __launch_bounds__(256) void joint_bwd_dz_split128_kernel(
     if (1 < Dfull) aload(1, a1); else if (1 < D) atail(a1);
     // the loop handles two double steps (four 16-deep steps) per trip; D is padded to even below by repeating the
     // last double step with zero fragments (W is zero past V, and the A tail is zero there too)
-    for (int d = 0; d < D; d += 2) {
+    // main loop: all four steps of a trip and everything they stage / load (up to step 2d + 7) lie inside the step range
+    // and inside V: staging rides between the MFMAs, nothing is clamped; then the general loop for the last trips (two loops
+    // in sequence: a branch inside one loop would duplicate the MFMA body and unsettle the accumulator allocation)
+    int d = 0;
+    for (; d + 3 < Dfull && 2 * d + 7 < steps; d += 2) {
+        __syncthreads();
+        compute(2 * d, a0, w0, std::true_type{});
+        __syncthreads();
+        compute(2 * d + 1, a0, w1, std::true_type{});
+        aload(d + 2, a0);
+        __syncthreads();
+        compute(2 * d + 2, a1, w0, std::true_type{});
+        __syncthreads();
+        compute(2 * d + 3, a1, w1, std::true_type{});
+        aload(d + 3, a1);
+    }
+    for (; d < D; d += 2) {
         // ---- double step d (registers a0) ----
         __syncthreads();
-        wwrite(2 * d + 2, w0);
-        wload(2 * d + 4, w0);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(2 * d, a0);
-        __builtin_amdgcn_sched_barrier(0);
+        compute(2 * d, a0, w0, std::false_type{});
         __syncthreads();
-        wwrite(2 * d + 3, w1);
-        wload(2 * d + 5, w1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(2 * d + 1, a0);
-        __builtin_amdgcn_sched_barrier(0);
+        compute(2 * d + 1, a0, w1, std::false_type{});
         if (d + 2 < Dfull) aload(d + 2, a0); else if (d + 2 < D) atail(a0);
         // ---- double step d + 1 (registers a1) ----
         __syncthreads();
-        wwrite(2 * d + 4, w0);
-        wload(2 * d + 6, w0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (d + 1 < D) compute(2 * d + 2, a1);
-        __builtin_amdgcn_sched_barrier(0);
+        if (d + 1 < D) compute(2 * d + 2, a1, w0, std::false_type{});
+        else { wwrite(2 * d + 4, w0); wload(2 * d + 6, w0); }
         __syncthreads();
-        wwrite(2 * d + 5, w1);
-        wload(2 * d + 7, w1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (d + 1 < D) compute(2 * d + 3, a1);
-        __builtin_amdgcn_sched_barrier(0);
+        if (d + 1 < D) compute(2 * d + 3, a1, w1, std::false_type{});
+        else { wwrite(2 * d + 5, w1); wload(2 * d + 7, w1); }
         if (d + 3 < Dfull) aload(d + 3, a1); else if (d + 3 < D) atail(a1);
     }
 
@@ -1418,15 +1456,16 @@ extern "C" int wr_joint_bwd_dz_split(const float *gout_d, const float *ep_d, con
     {                                                       // 128-cell tiling, W fragments staged in LDS
         const size_t lds = (size_t)kZStages * 2 * 16 * 64 * 16 + (size_t)kZM2 * (2 * sizeof(long) + sizeof(int));
         const dim3 grid2((unsigned)((M + kZM2 - 1) / kZM2));
-#define WR_LAUNCH_DZ2(TERMS)                                                                                           \
+#define WR_LAUNCH_DZ2(TERMS, FULL_)                                                                                    \
         do {                                                                                                          \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_bwd_dz_split128_kernel<TERMS>),              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_bwd_dz_split128_kernel<TERMS, FULL_>),       \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
-            hipLaunchKernelGGL(joint_bwd_dz_split128_kernel<TERMS>, grid2, dim3(256), lds, st, gout_d, ep_d, pp_d,      \
+            hipLaunchKernelGGL((joint_bwd_dz_split128_kernel<TERMS, FULL_>), grid2, dim3(256), lds, st, gout_d, ep_d, pp_d, \
                                reinterpret_cast<const u32x4 *>(wh), reinterpret_cast<const u32x4 *>(wl),               \
                                logit_lengths_d, target_lengths_d, B, T, U1, J, V, D, n_jt, activation, dz_d, h_d);     \
         } while (0)
-        if (terms == 3) WR_LAUNCH_DZ2(3); else WR_LAUNCH_DZ2(1);
+        if (n_jt == 16) { if (terms == 3) WR_LAUNCH_DZ2(3, true); else WR_LAUNCH_DZ2(1, true); }
+        else { if (terms == 3) WR_LAUNCH_DZ2(3, false); else WR_LAUNCH_DZ2(1, false); }
 #undef WR_LAUNCH_DZ2
         WR_CHECK_LAUNCH("joint_bwd_dz_split128_kernel");
     }
