@@ -976,8 +976,10 @@ __global__ __launch_bounds__(256) void joint_bwd_dw_block_kernel(
 constexpr int kZB = 256;         // block edge (cells and join columns)
 constexpr int kZApad = kZB + 4;  // transposed dY stage row stride (floats)
 
-// ANY_ACT = false: tanh only (the shipped joiner) -- the generic activation switch in this epilogue costs the 256-register
-// accumulator kernel its register allocation (121 -> 42 TFLOP/s measured), so it is compiled separately.
+// ANY_ACT = false: tanh (the shipped joiner) in the epilogue.  ANY_ACT = true: the epilogue stores the raw product dH and
+// joint_dz_act_kernel applies the activation's derivative afterwards (one more pass over the 2.5 GB / 8 utterances of dZ):
+// a generic activation switch inside this epilogue cost the 256-accumulator kernel its register allocation -- scratch
+// spills in the k-loop, 9.5 instead of 132 TFLOP/s measured.
 template <bool ANY_ACT>
 __global__ __launch_bounds__(256) void joint_bwd_dz_block_kernel(
     const float *__restrict__ gout /* [M, V] */, const float *__restrict__ ep, const float *__restrict__ pp,
@@ -1200,10 +1202,8 @@ __global__ __launch_bounds__(256) void joint_bwd_dz_block_kernel(
                 f32x4 h4, g4;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    float hh, dh;
-                    if (ANY_ACT) {
-                        act_value_grad(act, e4[u] + p4[u], hh, dh);
-                    } else {
+                    float hh = 0.f, dh = 1.f;
+                    if (!ANY_ACT) {
                         hh = tanhf(e4[u] + p4[u]);
                         dh = 1.f - hh * hh;
                     }
@@ -1211,7 +1211,7 @@ __global__ __launch_bounds__(256) void joint_bwd_dz_block_kernel(
                     g4[u] = ok ? acc[t][u][q] * dh : 0.f;
                 }
                 *reinterpret_cast<f32x4 *>(dz + (size_t)m * J + jcol) = g4;
-                if (hout) *reinterpret_cast<f32x4 *>(hout + (size_t)m * J + jcol) = h4;
+                if (!ANY_ACT && hout) *reinterpret_cast<f32x4 *>(hout + (size_t)m * J + jcol) = h4;
             }
     }
 }
@@ -1255,6 +1255,36 @@ int split_check(int B, int T, int U1, int J, int V, int terms, int out_dtype, in
 
 }  // namespace
 
+// dz[m, j] *= act'(ep[bt, j] + pp[bu, j]),  h[m, j] = act(...)   (zero in padded cells: dz already is): the second pass
+// of the generic-activation path of joint_bwd_dz_block_kernel<true>
+__global__ void joint_dz_act_kernel(const float *__restrict__ ep, const float *__restrict__ pp, const int32_t *__restrict__ llens,
+                                    const int32_t *__restrict__ tlens, int T, int U1, int J, long M, int act,
+                                    float *__restrict__ dz, float *__restrict__ hout)
+{
+    const long n4 = M * (J / 4);                                      // J % 4 == 0
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / (J / 4);
+        const int j = (int)(i - m * (J / 4)) * 4;
+        const long bt = m / U1;
+        const int u = (int)(m - bt * U1);
+        const long b = bt / T;
+        bool ok = true;
+        if (llens != nullptr && tlens != nullptr) ok = ((int)(bt - b * T) < llens[b]) && (u <= tlens[b]);
+        const f32x4 e4 = *reinterpret_cast<const f32x4 *>(ep + bt * J + j);
+        const f32x4 p4 = *reinterpret_cast<const f32x4 *>(pp + (b * U1 + u) * J + j);
+        f32x4 g4 = *reinterpret_cast<const f32x4 *>(dz + m * J + j), h4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float hh, dh;
+            act_value_grad(act, e4[q] + p4[q], hh, dh);
+            g4[q] = ok ? g4[q] * dh : 0.f;
+            h4[q] = ok ? hh : 0.f;
+        }
+        *reinterpret_cast<f32x4 *>(dz + m * J + j) = g4;
+        if (hout) *reinterpret_cast<f32x4 *>(hout + m * J + j) = h4;
+    }
+}
+
 // Exact-fp32 activation gradient with the block tiling (called by wr_joint_bwd_dz in joint.hip).
 int joint_bwd_dz_block(const float *gout_d, const float *ep_d, const float *pp_d, const float *w_d, const int32_t *llens_d,
                        const int32_t *tlens_d, int B, int T, int U1, int J, int V, int act, float *dz_d, float *h_d, hipStream_t st)
@@ -1274,6 +1304,8 @@ int joint_bwd_dz_block(const float *gout_d, const float *ep_d, const float *pp_d
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(joint_bwd_dz_block_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, st, gout_d, ep_d, pp_d, w_d,
                            llens_d, tlens_d, B, T, U1, J, V, n_js, act, dz_d, h_d);
+        hipLaunchKernelGGL(joint_dz_act_kernel, dim3(256 * 16), dim3(256), 0, st, ep_d, pp_d, llens_d, tlens_d, T, U1, J, M, act,
+                           dz_d, h_d);
     }
     WR_CHECK_LAUNCH("joint_bwd_dz_block_kernel");
     return WR_OK;
