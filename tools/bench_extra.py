@@ -109,10 +109,15 @@ def bench_joint(args):
                           "max_err_over_rms": float((dwt - dw_ref).abs().max()) / rms,
                           "db_max_err_over_rms": float((dbt - db_ref).abs().max() / db_ref.pow(2).mean().sqrt())}), flush=True)
     if args.dw:
-        g2 = out.view(-1, V)
-        k = lambda: g2.t().mm(h.view(-1, J))
-        ms = timeit(k, max(1, args.steps // 2))
-        print(json.dumps({"what": "joint_dW_rocblas", "ms": round(ms, 3), "TFLOPs": round(flops / ms / 1e9, 2)}), flush=True)
+        # yardstick, not product: the library's fp32 GEMM (hipBLASLt / rocBLAS through torch) on the three contractions
+        g2, h2 = out.view(-1, V), h.view(-1, J)
+        dz2 = dz.view(-1, J)
+        for name, k in (("forward  H @ W^T + b", lambda: torch.addmm(b, h2, w.t(), out=g2)),
+                        ("dZ       dY @ W", lambda: torch.mm(g2, w, out=dz2)),
+                        ("dW       dY^T @ H", lambda: g2.t().mm(h2))):
+            ms = timeit(k, max(1, args.steps // 2))
+            print(json.dumps({"what": "library fp32 GEMM (yardstick)", "contraction": name, "ms": round(ms, 3),
+                              "TFLOPs": round(flops / ms / 1e9, 2), "frac": round(flops / ms / 1e9 / 157.3, 4)}), flush=True)
 
 
 def bench_ctc(args):
@@ -408,7 +413,7 @@ if __name__ == "__main__":
     ap.add_argument("--U", type=int, default=150)
     ap.add_argument("--V", type=int, default=5000)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--dw", action="store_true")
+    ap.add_argument("--dw", action="store_true", help="joint: also time the library fp32 GEMM on the three contractions (yardstick)")
     ap.add_argument("--fwd-only", action="store_true", help="joint: stop after the exact forward sweep")
     ap.add_argument("--ragged", action="store_true", help="step: frames in [0.8 T, T] sorted, labels in [U/3, U]")
     ap.add_argument("--buckets", type=int, default=4, help="step: label-length groups of the fused node (1 = off)")
