@@ -65,7 +65,7 @@ void run(int waves_per_simd, const char *name)
 
 int main()
 {
-    run<0, 4>(1, "32x32x2"); run<0, 8>(1, "32x32x2"); run<0, 16>(1, "32x32x2"); run<0, 4>(2, "32x32x2");
+    run<0, 2>(1, "32x32x2"); run<0, 2>(2, "32x32x2"); run<0, 4>(1, "32x32x2"); run<0, 8>(1, "32x32x2"); run<0, 16>(1, "32x32x2"); run<0, 4>(2, "32x32x2");
     run<1, 8>(1, "16x16x4"); run<1, 16>(1, "16x16x4"); run<1, 32>(1, "16x16x4"); run<1, 16>(2, "16x16x4");
     run<2, 8>(1, "16x16x1 x4 blocks"); run<2, 16>(1, "16x16x1 x4 blocks");
     run<3, 4>(1, "32x32x1 x2 blocks"); run<3, 8>(1, "32x32x1 x2 blocks");
