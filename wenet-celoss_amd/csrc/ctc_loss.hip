@@ -54,7 +54,7 @@ inline CtcWs ctc_ws_layout(int B, int Tmax, int Smax)
 }
 
 // ------------------------------------------------------------------ pass 1 --
-// Row log-sum-exp: wave_row_lse of row_stream.hpp (16-byte vectors, 8 in flight per lane), with default-policy loads --
+// Row log-sum-exp: wave_row_lse of row_stream.hpp (16-byte vectors, 16 in flight per lane: 153 -> 137 us against 8), with default-policy loads --
 // the CTC logits (B*T*V) are re-read by the gather below and by pass 3.
 __global__ __launch_bounds__(256) void ctc_lse_kernel(
     const float *__restrict__ logits, const int32_t *__restrict__ targets,
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void ctc_lse_kernel(
             xl[q] = row[lab];
         }
         const float xb = row[blank];
-        const float d = normalized ? 0.f : wave_row_lse<float, false, 8>(row, V, lane);
+        const float d = normalized ? 0.f : wave_row_lse<float, false, 16>(row, V, lane);
         if (lane == 0) {
             denom[r] = d;
             lp_blank[r] = xb - d;
