@@ -61,7 +61,10 @@ def parse():
     ap.add_argument("--launch-timeout", type=float, default=3000.0,
                     help="self-launch only: seconds after which ranks that are still running are stopped (exit code 3)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="utterances timed on the CPU (-1: auto, 0: skip)")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time budget for the baseline")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="target CPU time budget for the baseline")
+    ap.add_argument("--extra-seconds", type=float, default=90.0,
+                    help="N=1 only: time budget of the secondary measurements appended as \"extra\" (tools/secondary.py: "
+                         "joiner TFLOP/s, loss-block step, CTC, greedy, beam, hot-word); 0 skips them")
     return ap.parse_args()
 
 
@@ -317,6 +320,17 @@ def main():
         out["rehearsal"] = "ranks share one device (development run, not a scaling measurement)"
     if rank == 0 and world == 1 and args.cpu_sample != 0:
         out["cpu_baseline"] = cpu_baseline(args, logits if not inplace else None, targets, llens, tlens, costs, gen, dev)
+    if rank == 0 and world == 1 and args.extra_seconds > 0:
+        # secondary metrics (SURVEY.md 8d "Secondary"), after the timed region and the CPU baseline, every leg guarded
+        # on its own; the 193 GB of headline buffers are released first
+        fwd = bwd = None
+        del logits, grads, ws
+        torch.cuda.empty_cache()
+        try:
+            from tools import secondary
+            out["extra"] = secondary.collect(dev, budget_s=args.extra_seconds)
+        except Exception as e:                  # never lose the headline line
+            out["extra"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -357,34 +371,52 @@ def cpu_baseline(args, logits, targets, llens, tlens, gpu_costs, gen, dev):
     cores = host_cores()
     per_utt_gb = T * (U + 1) * V * 4 / 1e9
     bs = args.cpu_sample
+    try:
+        avail = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 1e9
+    except (ValueError, OSError):
+        avail = 32.0
+    avail = min(avail, 200.0)                  # gpurun caps one command at ~270 GiB of host memory
+    # SURVEY.md 8d protocol: B' = min(B, floor(0.4 * RAM / (2 * 3.02 GB))) utterances of the same (T,U,V), 3 warm-ups,
+    # >= 5 timed repetitions, median.  Work is exactly linear in B' (utterances are independent), so when 3 + 5 runs of
+    # the RAM-sized sample would not fit --cpu-seconds (bench.py has to finish within minutes) B' is cut down to what
+    # does, never below 1; the sample actually used and every count are reported in "sample".
+    ram_bs = int(max(1, min(B, avail * 0.4 // (2 * per_utt_gb))))
     if bs < 0:
-        try:
-            avail = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 1e9
-        except (ValueError, OSError):
-            avail = 32.0
-        bs = int(max(1, min(B, min(avail, 200.0) * 0.4 // (2 * per_utt_gb), 4)))
+        bs = ram_bs
+    bs = int(max(1, min(bs, B)))
     if logits is None:      # in-place run destroyed the logits: regenerate the sample
         logits = torch.empty(bs, T, U + 1, V, dtype=torch.float32, device=dev)
         logits.normal_(generator=gen)
-    x = logits[:bs].cpu().numpy()
     y = targets[:bs].cpu().numpy()
+    # probe: one utterance, to size the sample to the time budget
+    x1 = logits[:1].cpu().numpy()
+    g1 = np.empty_like(x1)
+    t0 = time.perf_counter()
+    oracle.rnnt_loss_f32(x1, y[:1], np.array([T], np.int32), np.array([U], np.int32), nthreads=cores, out_grad=g1)
+    oracle.rnnt_loss_f32(x1, y[:1], np.array([T], np.int32), np.array([U], np.int32), nthreads=cores, out_grad=g1)
+    per_utt_s = (time.perf_counter() - t0) / 2
+    del x1, g1
+    WARM, REPS = 3, 5
+    if args.cpu_sample < 0:
+        bs = int(max(1, min(bs, args.cpu_seconds // ((WARM + REPS) * per_utt_s))))
+    x = logits[:bs].cpu().numpy()
+    y = y[:bs]
     ll = llens[:bs].cpu().numpy().copy()
     tl = tlens[:bs].cpu().numpy().copy()
     ll[0], tl[0] = T, U               # keep the maxima pinned for the sliced batch
     g = np.empty_like(x)
-    t0 = time.perf_counter()
-    c, _ = oracle.rnnt_loss_f32(x, y, ll, tl, nthreads=cores, out_grad=g)     # warm-up (page faults, thread pool)
-    warm = time.perf_counter() - t0
-    reps = int(max(1, min(5, args.cpu_seconds // max(warm, 1e-3))))
+    for _ in range(WARM):             # page faults, thread pool, caches
+        c, _ = oracle.rnnt_loss_f32(x, y, ll, tl, nthreads=cores, out_grad=g)
     times = []
-    for _ in range(reps):
+    for _ in range(REPS):
         t0 = time.perf_counter()
         c, _ = oracle.rnnt_loss_f32(x, y, ll, tl, nthreads=cores, out_grad=g)
         times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
     res = {"value": round(bs / med, 3), "unit": "utterances/s", "cores": cores, "kind": "port",
            "sample": f"{bs} of {B} utterances at the same (T={T},U={U},V={V}), fp32, loss+grad, "
-                     f"median of {reps} runs after 1 warm-up; oracle/rnnt_baseline.c with {cores} OpenMP threads "
+                     f"median of {REPS} runs after {WARM} warm-ups (SURVEY 8d protocol; RAM-sized sample would be {ram_bs}, "
+                     f"cut to fit {args.cpu_seconds:.0f} s of CPU time); oracle/rnnt_baseline.c with {cores} OpenMP threads "
                      f"(torchaudio is not installed on this image)"}
     try:
         gc = gpu_costs[:bs].cpu().numpy()

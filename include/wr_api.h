@@ -33,7 +33,10 @@
 extern "C" {
 #endif
 
-#define WR_API_VERSION 1
+/* Bumped whenever an existing signature or struct layout changes (callers built against another version must not
+ * bind): 1 = round 1; 2 = round 2 (an `activation` argument inside wr_joint_fwd / wr_joint_bwd_dz / *_split,
+ * wr_transducer_weights grew the predictor-variant fields); 3 = this header. */
+#define WR_API_VERSION 3
 
 enum wr_dtype { WR_F32 = 0, WR_F16 = 1, WR_BF16 = 2 };
 /* joiner activation (TransducerJoint(activation=...), wenet/transducer/joint.py:25 -> wenet/utils/common.py:228-242);

@@ -50,6 +50,8 @@ static double ctc_one(const float *logits, const int32_t *y, int T, int S,
     double *alpha = (double *)malloc(sizeof(double) * (size_t)T * SP);
     double *beta  = (double *)malloc(sizeof(double) * (size_t)T * SP);
     (void)Tmax;
+    /* frames are independent in the log-softmax: the pragma only spreads them over the host cores */
+#pragma omp parallel for schedule(static)
     for (int t = 0; t < T; ++t) {
         const float *row = logits + (size_t)t * V;
         double mx = row[0];
@@ -126,6 +128,8 @@ int wr_oracle_ctc_f64(const float *logits, const int32_t *targets,
 {
     const size_t per_b = (size_t)Tmax * V;
     if (grad) memset(grad, 0, sizeof(float) * per_b * (size_t)B);
+    /* utterances are independent */
+#pragma omp parallel for schedule(dynamic, 1)
     for (int b = 0; b < B; ++b)
         nll[b] = ctc_one(logits + per_b * b, targets + (size_t)b * Smax,
                          input_lengths[b], target_lengths[b], Tmax, V, blank,

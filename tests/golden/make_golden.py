@@ -27,6 +27,8 @@ for modules that are absent from the image -- `typeguard`, used only for
   wenet/transducer/transducer.py      Transducer.forward / beam_search / transducer_attention_rescoring / greedy_search
                                       through the reference's own class (torchaudio.functional.rnnt_loss stubbed with
                                       this repo's float64 oracle)    -> transducer_wrappers.npz
+  wenet/transformer/asr_model.py      ASRModel.recognize / attention_rescoring / ctc_* / the jit exports, as inherited by
+                                      the reference Transducer class  -> asr_surface.npz
   wenet/transformer/context_bias.py   ContextBias (the real module) driven by
   wenet/transducer/search/greedy_search.py  basic_greedy_search_both -> greedy_both_real_*.npz
 torchaudio.functional.rnnt_loss cannot be imported (torchaudio is absent), so no
@@ -764,6 +766,14 @@ def gen_transducer_wrappers():
     so the RNN-T numbers inside these fixtures are the oracle's (that leg stays "parity unpinned"); everything around
     them -- label preparation, the loss dictionary and its weights, hot-word loss, n-best padding, score combination,
     arg-max -- is the reference's own code."""
+    env = _reference_transducer_env()
+    for variant in ("", "_emb"):
+        _gen_transducer_wrappers_variant(variant, env)
+
+
+def _reference_transducer_env():
+    """Import the reference's Transducer class (see gen_transducer_wrappers for the torchaudio stub) and the stand-in
+    encoder / attention decoder; returns the names the generators need."""
     root = os.path.dirname(os.path.dirname(HERE))
     sys.path.insert(0, root)
     sys.path.insert(0, os.path.dirname(HERE))
@@ -795,8 +805,74 @@ def gen_transducer_wrappers():
     from wenet.transducer.predictor import EmbeddingPredictor, RNNPredictor
     from wenet.transformer.context_bias import ContextBias
     from wenet.transformer.ctc import CTC
-    for variant in ("", "_emb"):
-        _gen_transducer_wrappers_variant(variant, locals())
+    return dict(locals())
+
+
+def gen_asr_surface():
+    """The entry points the reference's Transducer INHERITS from ASRModel (wenet/transformer/asr_model.py) and that
+    wenet/bin/recognize.py / the C++ runtime call on it: `recognize` (:175-279, --mode attention), `attention_rescoring`
+    (:443-540, --mode attention_rescoring), `ctc_greedy_search` (:281-324), `ctc_prefix_beam_search` (:411-440) and the
+    exports `subsampling_rate`, `right_context`, `sos_symbol`, `eos_symbol`, `ctc_activation`,
+    `is_bidirectional_decoder`, `forward_attention_decoder` (:542-720) -- run on the reference's own class built around
+    the stand-in encoder / attention decoder of tests/test_transducer_gpu.py -> asr_surface.npz."""
+    env = _reference_transducer_env()
+    Transducer, TransducerJoint, RNNPredictor, CTC = (env[k] for k in ("Transducer", "TransducerJoint", "RNNPredictor", "CTC"))
+    TinyEncoder, TinyAttnDecoder = env["TinyEncoder"], env["TinyAttnDecoder"]
+    V, D, J, H = 23, 12, 16, 14
+    torch.manual_seed(51)
+    m = Transducer(V, 0, TinyEncoder(8, D), RNNPredictor(V, D, D, 0.0, H, 2, dropout=0.0), TransducerJoint(V, D, D, J),
+                   attention_decoder=TinyAttnDecoder(V, D), ctc=CTC(V, D), context_bias=None, ctc_weight=0.1,
+                   transducer_weight=0.75, attention_weight=0.15, reverse_weight=0.3, hw_weight=0.0).eval()
+    with torch.no_grad():
+        m.ctc.ctc_lo.weight *= 5
+        m.ctc.ctc_lo.bias[0] += 1.0
+        m.decoder.out.weight *= 4
+        m.decoder.out.bias[V - 1] += 1.0            # <eos> likely enough that some beams finish early
+    g = torch.Generator().manual_seed(52)
+    out = {}
+    with torch.no_grad():
+        # recognize: batch of 3 with ragged lengths, two beam sizes
+        sp = torch.randn(3, 14, 8, generator=g)
+        sl = torch.tensor([14, 9, 12], dtype=torch.int32)
+        out.update(rec_speech=sp.numpy(), rec_slen=sl.numpy())
+        for k, beam in enumerate((1, 4)):
+            hyps, scores = m.recognize(sp, sl, beam_size=beam)
+            out[f"rec_{k}_beam"] = np.array(beam); out[f"rec_{k}_hyps"] = hyps.numpy(); out[f"rec_{k}_scores"] = scores.numpy()
+            print(f"  recognize beam {beam}:", hyps.tolist(), scores.tolist())
+        out["n_rec"] = np.array(2)
+        # ctc_greedy_search (batched) / ctc_prefix_beam_search / attention_rescoring (batch 1)
+        gh, gs = m.ctc_greedy_search(sp, sl)
+        out["ctcg_len"] = np.array([len(h) for h in gh]); out["ctcg_hyps"] = np.array([h + [-1] * (14 - len(h)) for h in gh])
+        out["ctcg_scores"] = gs.values.numpy() if hasattr(gs, "values") else np.asarray(gs[0])
+        sp1 = torch.randn(1, 21, 8, generator=g)
+        sl1 = torch.tensor([21], dtype=torch.int32)
+        out.update(one_speech=sp1.numpy())
+        ph, ps = m.ctc_prefix_beam_search(sp1, sl1, 4)
+        out.update(cpb_hyp=np.array(list(ph), np.int64), cpb_score=np.array(float(ps)))
+        print("  ctc_prefix_beam_search:", list(ph), float(ps))
+        k = 0
+        for rw in (0.0, 0.3):
+            for cw in (0.0, 0.5):
+                h, s = m.attention_rescoring(sp1, sl1, 4, ctc_weight=cw, reverse_weight=rw)
+                out[f"ar_{k}_rw"] = np.array(rw); out[f"ar_{k}_cw"] = np.array(cw)
+                out[f"ar_{k}_hyp"] = np.array(list(h), np.int64); out[f"ar_{k}_score"] = np.array(float(s))
+                print(f"  attention_rescoring rw={rw} ctc_weight={cw}:", list(h), float(s))
+                k += 1
+        out["n_ar"] = np.array(k)
+        # exports
+        out.update(subsampling_rate=np.array(m.subsampling_rate()), right_context=np.array(m.right_context()),
+                   sos=np.array(m.sos_symbol()), eos=np.array(m.eos_symbol()),
+                   bidirectional=np.array(m.is_bidirectional_decoder()))
+        xs = torch.randn(2, 5, D, generator=g)
+        out.update(act_in=xs.numpy(), act_out=m.ctc_activation(xs).numpy())
+        hy = torch.tensor([[V - 1, 3, 4, 5, 9], [V - 1, 7, 2, V - 1, V - 1], [V - 1, 6, V - 1, V - 1, V - 1]])
+        hl = torch.tensor([5, 3, 2])
+        eo = torch.randn(1, 6, D, generator=g)
+        for k, rw in enumerate((0.0, 0.3)):
+            a, b = m.forward_attention_decoder(hy, hl, eo, rw)
+            out[f"fad_{k}_rw"] = np.array(rw); out[f"fad_{k}_out"] = a.numpy(); out[f"fad_{k}_rout"] = b.numpy()
+        out.update(fad_hyps=hy.numpy(), fad_lens=hl.numpy(), fad_enc=eo.numpy())
+    save("asr_surface", **out, **{"m_" + k: v for k, v in sd(m).items()})
 
 
 def _gen_transducer_wrappers_variant(variant, env):
@@ -916,3 +992,4 @@ if __name__ == "__main__":
     gen_greedy_stream()
     gen_greedy_both_real()
     gen_transducer_wrappers()
+    gen_asr_surface()

@@ -16,6 +16,11 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(wr_[a-z0-9_]+)\s*\(", text)))
 
 
+def header_api_version():
+    text = open(os.path.join(ROOT, "include", "wr_api.h")).read()
+    return int(re.search(r"#define\s+WR_API_VERSION\s+(\d+)", text).group(1))
+
+
 @pytest.fixture(scope="module")
 def lib():
     from wenet_celoss_amd import _lib
@@ -34,7 +39,8 @@ def test_header_symbols_all_exported_and_bound(lib):
 
 
 def test_version_and_workspace(lib):
-    assert lib.wr_api_version() == 1
+    from wenet_celoss_amd import _lib
+    assert lib.wr_api_version() == _lib.API_VERSION == header_api_version()
     assert lib.wr_rnnt_workspace_bytes(0, 10, 10) == 0
     small = lib.wr_rnnt_workspace_bytes(2, 10, 5)
     big = lib.wr_rnnt_workspace_bytes(32, 1000, 151)

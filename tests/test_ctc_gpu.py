@@ -139,8 +139,10 @@ def test_module_matches_reference_fixture(path):
 
 
 def test_full_size_properties():
-    """BASELINE CTC shape (T=1000,B=32,S=150,V=5000): every gradient row sums to ~0,
-    padding frames are zero, nll agrees with torch.nn.CTCLoss on the CPU."""
+    """BASELINE CTC shape (T=1000,B=32,S=150,V=5000): nll AND the whole gradient of every utterance against the
+    float64 oracle at the north-star tolerance (nll rtol 1e-5; gradient rtol 1e-4 / atol 1e-5 -- T = 1000
+    dependent steps, lattice values ~1e4); nll also against torch.nn.CTCLoss on the CPU (the reference's own call,
+    ctc.py:60-61); every gradient row sums to ~0, padding frames are zero."""
     import wenet_celoss_amd as w
     torch.manual_seed(0)
     B, T, S, V = 32, 1000, 150, 5000
@@ -157,3 +159,7 @@ def test_full_size_properties():
     lp = x.detach().cpu().transpose(0, 1).log_softmax(2)
     ref = torch.nn.CTCLoss(reduction="none")(lp, y.cpu(), il.cpu().long(), tl.cpu().long())
     np.testing.assert_allclose(nll.detach().cpu().numpy(), ref.numpy(), rtol=2e-5)
+    onll, og = oracle.ctc_loss_f64(x.detach().cpu().numpy(), y.cpu().numpy().astype(np.int32),
+                                   il.cpu().numpy(), tl.cpu().numpy())
+    np.testing.assert_allclose(nll.detach().cpu().numpy(), onll, rtol=1e-5)
+    np.testing.assert_allclose(g.cpu().numpy(), og, rtol=1e-4, atol=1e-5)

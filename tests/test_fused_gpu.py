@@ -248,3 +248,24 @@ def test_full_baseline_shape_loss_block():
         bi = int(rs.integers(B)); t = int(rs.integers(int(tl[bi]))); u = int(rs.integers(int(ul[bi]) + 1))
         ref = torch.tanh(ep[bi, t].double().cpu() + pp[bi, u].double().cpu()) @ wd.T + bd
         np.testing.assert_allclose(logits[bi, t, u].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_second_backward_through_a_retained_graph(precision):
+    """The node writes the gradient over its saved logits through a raw pointer (invisible to autograd's version
+    counter).  A second backward through a retained graph -- retain_graph=True, or per-loss torch.autograd.grad --
+    must not differentiate gradients-as-logits: the node rebuilds the logits first.  Both passes give the gradients
+    of a fresh node, bit for bit (the kernels are deterministic)."""
+    import wenet_celoss_amd as w_
+    args = make(3, 70, 11, 32, 257, True)
+    leaves = [t.clone().requires_grad_(True) for t in args[:4]]
+    costs = w_.joint_rnnt_loss(*leaves, *args[4:], blank=0, reduction="none", precision=precision, buckets=1)
+    g1 = torch.autograd.grad(costs.sum(), leaves, retain_graph=True)
+    g2 = torch.autograd.grad(costs.sum(), leaves, retain_graph=True)
+    g3 = torch.autograd.grad((costs * torch.tensor([2.0, 0.0, -1.0], device=DEV)).sum(), leaves)
+    fresh = [t.clone().requires_grad_(True) for t in args[:4]]
+    c2 = w_.joint_rnnt_loss(*fresh, *args[4:], blank=0, reduction="none", precision=precision, buckets=1)
+    r3 = torch.autograd.grad((c2 * torch.tensor([2.0, 0.0, -1.0], device=DEV)).sum(), fresh)
+    for a, b_, c, d in zip(g1, g2, g3, r3):
+        assert torch.equal(a, b_)
+        assert torch.equal(c, d)

@@ -187,3 +187,70 @@ def test_config1_ctc_only_batch2_runs_on_cpu():
     # the functional fused op and the RNN-T / joiner paths still refuse CPU tensors
     with pytest.raises(RuntimeError, match="HIP device"):
         w.ctc_loss(torch.zeros(1, 4, 5), torch.ones(1, 1, dtype=torch.long), torch.tensor([4]), torch.tensor([1]))
+
+
+# wenet/bin/recognize.py:259-362: args.mode -> (method called on the model, keyword arguments it passes besides
+# (feats, feats_lengths)).  Restated as data; checked against the reference file's text when the tree is present.
+_RECOGNIZE_MODES = {
+    "attention": ("recognize", dict(beam_size=4, decoding_chunk_size=-1, num_decoding_left_chunks=-1, simulate_streaming=False)),
+    "ctc_greedy_search": ("ctc_greedy_search", dict(decoding_chunk_size=-1, num_decoding_left_chunks=-1, simulate_streaming=False)),
+    "rnnt_greedy_search": ("greedy_search", dict(decoding_chunk_size=-1, num_decoding_left_chunks=-1, simulate_streaming=False,
+                                                 context_list=torch.IntTensor([[0]]), context_lengths=torch.IntTensor([1]),
+                                                 context_filter_state="on",
+                                                 context_decoder_labels_padded=torch.IntTensor([[0]]))),
+    "rnnt_beam_search": ("beam_search", dict(decoding_chunk_size=-1, beam_size=4, num_decoding_left_chunks=-1,
+                                             simulate_streaming=False, ctc_weight=0.3, transducer_weight=0.7,
+                                             context_list=torch.IntTensor([[0]]), context_lengths=torch.IntTensor([1]))),
+    "rnnt_beam_attn_rescoring": ("transducer_attention_rescoring",
+                                 dict(decoding_chunk_size=-1, beam_size=4, num_decoding_left_chunks=-1, simulate_streaming=False,
+                                      ctc_weight=0.2, transducer_weight=0.5, attn_weight=0.3, reverse_weight=0.3,
+                                      search_ctc_weight=0.3, search_transducer_weight=0.7)),
+    "ctc_beam_td_attn_rescoring": ("transducer_attention_rescoring",
+                                   dict(decoding_chunk_size=-1, beam_size=4, num_decoding_left_chunks=-1, simulate_streaming=False,
+                                        ctc_weight=0.2, transducer_weight=0.5, attn_weight=0.3, reverse_weight=0.3,
+                                        search_ctc_weight=0.3, search_transducer_weight=0.7, beam_search_type="ctc")),
+    "ctc_prefix_beam_search": ("ctc_prefix_beam_search", dict(beam_size=4, decoding_chunk_size=-1, num_decoding_left_chunks=-1,
+                                                              simulate_streaming=False)),
+    "attention_rescoring": ("attention_rescoring", dict(beam_size=4, decoding_chunk_size=-1, num_decoding_left_chunks=-1,
+                                                        ctc_weight=0.5, simulate_streaming=False, reverse_weight=0.3)),
+}
+
+
+def test_every_recognize_mode_reaches_a_method_of_the_replacement_class():
+    """north_star: bin/recognize.py runs unchanged.  Its eight `args.mode` branches (recognize.py:259-362) call eight
+    methods on the model with fixed keyword sets; two of them (`recognize`, `attention_rescoring`) the reference's
+    Transducer only inherits from ASRModel.  Each must exist on wenet_celoss_amd.Transducer, accept exactly that call,
+    and -- run on CPU tensors here -- either complete (the pure host-logic mode 'attention') or stop at the product's
+    "tensors must live on a HIP device" check: never AttributeError / TypeError."""
+    import inspect
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_transducer_gpu import TinyAttnDecoder, TinyEncoder
+    import wenet_celoss_amd as w
+    torch.manual_seed(0)
+    V, D = 23, 12
+    m = w.Transducer(V, 0, TinyEncoder(8, D), w.RNNPredictor(V, D, D, 0.0, 14, 2, dropout=0.0), w.TransducerJoint(V, D, D, 16),
+                     attention_decoder=TinyAttnDecoder(V, D), ctc=w.CTC(V, D), context_bias=None, ctc_weight=0.1,
+                     transducer_weight=0.75, attention_weight=0.15, reverse_weight=0.3, hw_weight=0.0).eval()
+    feats, lens = torch.randn(1, 17, 8), torch.tensor([17], dtype=torch.int32)
+    completed = []
+    for mode, (name, kwargs) in _RECOGNIZE_MODES.items():
+        fn = getattr(m, name, None)
+        assert callable(fn), f"--mode {mode}: Transducer has no method {name}"
+        inspect.signature(fn).bind(feats, feats_lengths := lens, **kwargs)          # the call recognize.py makes binds
+        try:
+            with torch.no_grad():
+                fn(feats, feats_lengths, **kwargs)
+            completed.append(mode)
+        except RuntimeError as e:                                                     # the HIP path refusing CPU tensors
+            assert "HIP" in str(e) or "hip" in str(e), (mode, e)
+    assert "attention" in completed
+    # the exports torch_asr_model.cc reads at load time
+    assert (m.subsampling_rate(), m.right_context(), m.sos_symbol(), m.eos_symbol()) == (4, 6, V - 1, V - 1)
+    assert m.is_bidirectional_decoder() is True
+    if os.path.isfile(os.path.join(REF, "wenet/bin/recognize.py")):
+        import re
+        text = open(os.path.join(REF, "wenet/bin/recognize.py")).read()
+        called = set(re.findall(r"model\.([a-z_]+)\(", text)) - {"eval", "to", "load_state_dict"}
+        assert called == {name for name, _ in _RECOGNIZE_MODES.values()}, called
+        for mode in _RECOGNIZE_MODES:
+            assert f"'{mode}'" in text, mode

@@ -14,12 +14,23 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+class TinySubsampling(torch.nn.Module):
+    """Carries the two integers the ASRModel exports read from `encoder.embed` (asr_model.py:542-554); no parameters,
+    so the state dict of TinyEncoder -- and every fixture built on it -- is unchanged."""
+
+    def __init__(self):
+        super().__init__()
+        self.subsampling_rate: int = 4
+        self.right_context: int = 6
+
+
 class TinyEncoder(torch.nn.Module):
     """Linear + frame mask; returns (encoder_out, mask) like wenet encoders (encoder.py forward)."""
 
     def __init__(self, idim, odim):
         super().__init__()
         self.proj = torch.nn.Linear(idim, odim)
+        self.embed = TinySubsampling()
 
     def forward(self, xs, xs_lens, decoding_chunk_size=0, num_decoding_left_chunks=-1):
         T = xs.size(1)
@@ -198,6 +209,15 @@ class TinyAttnDecoder(torch.nn.Module):
         ctx = memory.mean(1, keepdim=True)
         return (self.out(torch.tanh(self.embed(ys_in_pad) + ctx)),
                 self.right_decoder(torch.tanh(self.embed(r_ys_in_pad) + ctx)), ys_in_lens)
+
+    @torch.jit.unused
+    def forward_one_step(self, memory, memory_mask, tgt, tgt_mask, cache=None):
+        """decoder.py forward_one_step: (memory, memory_mask, tgt (N, i), tgt_mask (N, i, i), cache) ->
+        (log-probs of the next token (N, V), cache).  Depends on the last TWO tokens so that beams differ."""
+        ctx = memory.mean(1)
+        prev = self.embed(tgt[:, -2]) if tgt.size(1) > 1 else torch.zeros_like(ctx)
+        h = torch.tanh(self.embed(tgt[:, -1]) + 0.5 * prev + ctx)
+        return torch.log_softmax(self.out(h), dim=-1), cache
 
 
 def _float64_joint_logits(m, enc_out, ys_in):
@@ -511,3 +531,49 @@ def test_wrappers_match_the_reference_class(fixture):
                                  context_lengths=torch.tensor(d["fwd_ctx_len"]), context_filter_state="on",
                                  context_decoder_labels_padded=torch.tensor(d["greedy_labels"]))
     assert gh == [d["greedy_hyp"].tolist()] and gd == float(d["greedy_dist"])
+
+
+def test_asr_model_surface_matches_the_reference_class():
+    """The reference's Transducer IS an ASRModel (transducer.py:20): wenet/bin/recognize.py calls `recognize`
+    (--mode attention, recognize.py:259) and `attention_rescoring` (--mode attention_rescoring, :351) on it and the C++
+    runtime calls the jit exports.  tests/golden/asr_surface.npz holds what the reference's own class returned for all
+    of them (make_golden.py::gen_asr_surface); ours, with the same weights, reproduces it: token sequences exactly,
+    scores to 1e-5 relative (the n-best of attention_rescoring comes from the HIP CTC prefix beam search)."""
+    from conftest import GOLDEN
+    import wenet_celoss_amd as w
+    d = np.load(os.path.join(GOLDEN, "asr_surface.npz"))
+    sd = {k[2:]: torch.tensor(d[k]) for k in d.files if k.startswith("m_")}
+    V, D = sd["predictor.embed.weight"].shape
+    m = w.Transducer(V, 0, TinyEncoder(8, D), w.RNNPredictor(V, D, D, 0.0, sd["predictor.rnn.weight_hh_l0"].shape[1], 2, dropout=0.0),
+                     w.TransducerJoint(V, D, D, sd["joint.enc_ffn.weight"].shape[0]), attention_decoder=TinyAttnDecoder(V, D),
+                     ctc=w.CTC(V, D), context_bias=None, ctc_weight=0.1, transducer_weight=0.75, attention_weight=0.15,
+                     reverse_weight=0.3, hw_weight=0.0)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    T = lambda k: torch.tensor(d[k]).to(DEV)
+    with torch.no_grad():
+        sp, sl = T("rec_speech"), T("rec_slen")
+        for k in range(int(d["n_rec"])):
+            hyps, scores = m.recognize(sp, sl, beam_size=int(d[f"rec_{k}_beam"]))
+            assert hyps.cpu().tolist() == d[f"rec_{k}_hyps"].tolist(), k
+            np.testing.assert_allclose(scores.cpu().numpy(), d[f"rec_{k}_scores"], rtol=1e-5)
+        gh, gs = m.ctc_greedy_search(sp, sl)
+        assert gh == [row[:n].tolist() for row, n in zip(d["ctcg_hyps"], d["ctcg_len"])]
+        np.testing.assert_allclose(torch.as_tensor(gs[0] if isinstance(gs, tuple) else gs).cpu().numpy().reshape(-1),
+                                   d["ctcg_scores"].reshape(-1), rtol=1e-5)
+        sp1 = T("one_speech")
+        sl1 = torch.tensor([sp1.shape[1]], dtype=torch.int32, device=DEV)
+        ph, ps = m.ctc_prefix_beam_search(sp1, sl1, 4)
+        assert list(ph) == d["cpb_hyp"].tolist() and float(ps) == pytest.approx(float(d["cpb_score"]), rel=1e-5)
+        for k in range(int(d["n_ar"])):
+            h, s = m.attention_rescoring(sp1, sl1, 4, ctc_weight=float(d[f"ar_{k}_cw"]), reverse_weight=float(d[f"ar_{k}_rw"]))
+            assert list(h) == d[f"ar_{k}_hyp"].tolist(), k
+            assert float(s) == pytest.approx(float(d[f"ar_{k}_score"]), rel=1e-5), k
+        assert m.subsampling_rate() == int(d["subsampling_rate"]) and m.right_context() == int(d["right_context"])
+        assert m.sos_symbol() == int(d["sos"]) and m.eos_symbol() == int(d["eos"])
+        assert m.is_bidirectional_decoder() == bool(d["bidirectional"])
+        np.testing.assert_allclose(m.ctc_activation(T("act_in")).cpu().numpy(), d["act_out"], rtol=1e-5, atol=1e-6)
+        for k in range(2):
+            a, b = m.forward_attention_decoder(T("fad_hyps"), T("fad_lens"), T("fad_enc"), float(d[f"fad_{k}_rw"]))
+            np.testing.assert_allclose(a.cpu().numpy(), d[f"fad_{k}_out"], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(b.cpu().numpy(), d[f"fad_{k}_rout"], rtol=1e-5, atol=1e-6)

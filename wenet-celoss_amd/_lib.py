@@ -21,6 +21,7 @@ LIB_NAME = "libwr_mi355x.so"
 LIB_PATH = os.path.join(_PKG, LIB_NAME)
 _HASH_PATH = LIB_PATH + ".srchash"
 
+API_VERSION = 3              # include/wr_api.h WR_API_VERSION this binding was written against
 WR_F32, WR_F16, WR_BF16 = 0, 1, 2
 # wr_activation codes (include/wr_api.h), keyed by the names of wenet/utils/common.py:228-242 get_activation
 ACTIVATIONS = {"tanh": 0, "relu": 1, "hardtanh": 2, "selu": 3, "swish": 4, "gelu": 5}
@@ -191,8 +192,9 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.wr_api_version() != 1:
-            raise RuntimeError("wenet_celoss_amd: libwr_mi355x.so API version mismatch")
+        if lib.wr_api_version() != API_VERSION:
+            raise RuntimeError(f"wenet_celoss_amd: libwr_mi355x.so API version {lib.wr_api_version()} != {API_VERSION} "
+                               "(stale library or stale binding)")
         _lib = lib
     return _lib
 

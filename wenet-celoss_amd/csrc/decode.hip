@@ -2090,6 +2090,10 @@ int greedy_run(wr_decoder *h, const float *enc_out_d, const int32_t *enc_lens_d,
         }
     }
     WR_CHECK_LAUNCH("greedy_search");
+    // every micro-step emits (at most n_steps per frame) or advances the frame, so the budget cannot run out; if it ever
+    // does, say so instead of returning truncated hypotheses as WR_OK
+    WR_REQUIRE(h->h_active[0] <= 0, WR_ELAUNCH, "greedy_search: %d streams still active after %ld micro-steps",
+               h->h_active[0], max_micro);
     scope.ok();
     return WR_OK;
 }
@@ -2401,6 +2405,8 @@ extern "C" int wr_greedy_search_hotword(wr_decoder *h, const float *enc_hot_d, c
         if (h->h_active[0] <= 0) break;
     }
     WR_CHECK_LAUNCH("greedy_search_hotword");
+    WR_REQUIRE(h->h_active[0] <= 0, WR_ELAUNCH, "greedy_search_hotword: %d streams still active after %ld micro-steps "
+               "(go-backs exceeded the budget); hypotheses are incomplete", h->h_active[0], max_micro);
     scope.ok();
     return WR_OK;
 }

@@ -18,6 +18,7 @@ from __future__ import annotations
 import os
 from typing import Optional
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -85,18 +86,49 @@ class _JointRnntFn(torch.autograd.Function):
                 rc = lib.wr_rnnt_loss_fwd(_lib.ptr(logits), _lib.WR_F32, _lib.ptr(targets), _lib.ptr(llens), _lib.ptr(tlens), B,
                                           T, U1, V, blank, _lib.ptr(costs), _lib.ptr(rws), rws_bytes, st)
                 _lib.check(rc, "wr_rnnt_loss_fwd")
-        ctx.save_for_backward(ep, pp, w, targets, llens, tlens, logits, rws)
+        ctx.save_for_backward(ep, pp, w, b, targets, llens, tlens, logits, rws)
         ctx.blank, ctx.clamp, ctx.terms, ctx.act = blank, clamp, terms, act
+        ctx.logits_hold_gradient = False
         return costs
+
+    @staticmethod
+    def _recompute_logits(ctx, lib, ep, pp, w, b, llens, tlens, logits):
+        """A second backward through a retained graph (retain_graph=True, per-loss torch.autograd.grad) finds the
+        gradient of the first one where the logits were: the write went through a raw pointer, which autograd's
+        version counter never sees.  The joiner forward is deterministic and its plain / epilogue variants give
+        bit-identical logits, so the node rebuilds them in the same buffer (one forward's time) instead of failing
+        or -- what it did before -- differentiating gradients-as-logits.  The lattice in `rws` is still the first
+        forward's (the gradient pass only reads it)."""
+        B, T, U1, V = logits.shape
+        J = ep.shape[2]
+        dev = logits.device
+        st = _lib.current_stream(dev)
+        if ctx.terms == 0:
+            ws_bytes = lib.wr_joint_workspace_bytes(J, V)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            rc = lib.wr_joint_fwd(_lib.ptr(ep), _lib.ptr(pp), _lib.ptr(w), _lib.ptr(b), _lib.ptr(llens), _lib.ptr(tlens),
+                                  B, T, U1, J, V, ctx.act, _lib.ptr(logits), _lib.ptr(ws), ws_bytes, st)
+            _lib.check(rc, "wr_joint_fwd")
+        else:
+            ws_bytes = lib.wr_joint_split_workspace_bytes(J, V)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            rc = lib.wr_joint_fwd_split(_lib.ptr(ep), _lib.ptr(pp), _lib.ptr(w), _lib.ptr(b), _lib.ptr(llens),
+                                        _lib.ptr(tlens), B, T, U1, J, V, ctx.act, ctx.terms, _lib.ptr(logits), _lib.WR_F32,
+                                        _lib.ptr(ws), ws_bytes, st)
+            _lib.check(rc, "wr_joint_fwd_split")
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_costs):
-        ep, pp, w, targets, llens, tlens, logits, rws = ctx.saved_tensors
+        ep, pp, w, b, targets, llens, tlens, logits, rws = ctx.saved_tensors
         lib = _lib.load()
         B, T, U1, V = logits.shape
         dev = logits.device
         gc = grad_costs.to(torch.float32).contiguous()
+        if ctx.logits_hold_gradient:
+            with torch.cuda.device(dev):
+                _JointRnntFn._recompute_logits(ctx, lib, ep, pp, w, b, llens, tlens, logits)
+            ctx.logits_hold_gradient = False
         # Nothing else holds the logits, so the gradient overwrites them (one logits-sized tensor instead of two).  With
         # round 1's plain loads that cost the gradient pass ~11 % (a line rewritten microseconds after it was read); with
         # the non-temporal loads of round 2 it costs nothing measurable (46.97 / 46.94 against 47.03 / 47.40 ms per
@@ -108,6 +140,7 @@ class _JointRnntFn(torch.autograd.Function):
                                       B, T, U1, V, ctx.blank, float(ctx.clamp), _lib.ptr(gc), _lib.ptr(grads),
                                       _lib.ptr(rws), rws.numel(), _lib.current_stream(dev))
         _lib.check(rc, "wr_rnnt_loss_bwd")
+        ctx.logits_hold_gradient = inplace
         d_ep, d_pp, d_w, d_b = joint_backward(grads, ep, pp, w, llens, tlens, ctx.terms, ctx.needs_input_grad[2],
                                               ctx.needs_input_grad[3], gout_zero_in_padding=True, act=ctx.act)
         return d_ep, d_pp, d_w, d_b, None, None, None, None, None, None, None
@@ -132,29 +165,30 @@ def plan_buckets(t_lens, u_lens, max_buckets: int = 4, min_gain: float = 0.08, m
     whole = n * max(t_lens) * (max(u_lens) + 1)
     if n < 2 or whole < max(min_cells, 1):
         return None
-    us = [u_lens[i] for i in order]
-    ts = [t_lens[i] for i in order]
-
-    def cost(a, b):                      # group of sorted positions [a, b)
-        return (b - a) * max(ts[a:b]) * (us[b - 1] + 1)
-    INF = float("inf")
-    best = [[INF] * (n + 1) for _ in range(max_buckets + 1)]
-    cut = [[0] * (n + 1) for _ in range(max_buckets + 1)]
-    best[0][0] = 0
+    us = np.asarray([u_lens[i] for i in order], dtype=np.int64)
+    ts = np.asarray([t_lens[i] for i in order], dtype=np.int64)
+    # cost[a, b] of the group of sorted positions [a, b) = (b - a) * max(ts[a:b]) * (us[b - 1] + 1): the running
+    # maximum per start index makes it one vector operation per row (the host runs this every training step; the
+    # first version recomputed max(ts[a:b]) inside a triple Python loop, 1 s at 512 utterances).
+    INF = np.iinfo(np.int64).max // 4
+    cost = np.full((n + 1, n + 1), INF, dtype=np.int64)
+    width = us + 1
+    for a in range(n):
+        cnt = np.arange(1, n - a + 1, dtype=np.int64)
+        cost[a, a + 1:] = cnt * np.maximum.accumulate(ts[a:]) * width[a:]
+    best = np.full((max_buckets + 1, n + 1), INF, dtype=np.int64)
+    cut = np.zeros((max_buckets + 1, n + 1), dtype=np.int64)
+    best[0, 0] = 0
     for g in range(1, max_buckets + 1):
-        for b in range(1, n + 1):
-            for a in range(g - 1, b):
-                if best[g - 1][a] == INF:
-                    continue
-                c = best[g - 1][a] + cost(a, b)
-                if c < best[g][b]:
-                    best[g][b], cut[g][b] = c, a
-    g_best = min(range(1, max_buckets + 1), key=lambda g: best[g][n])
+        cand = np.minimum(best[g - 1][:, None] + cost, INF)       # [a, b]; INF rows / entries stay INF
+        cut[g] = cand.argmin(axis=0)                                # first minimum = smallest a, as the scalar loop did
+        best[g] = cand[cut[g], np.arange(n + 1)]
+    g_best = min(range(1, max_buckets + 1), key=lambda g: int(best[g][n]))
     if g_best == 1 or best[g_best][n] > (1.0 - min_gain) * whole:
         return None
     groups, b = [], n
     for g in range(g_best, 0, -1):
-        a = cut[g][b]
+        a = int(cut[g][b])
         groups.append(order[a:b])
         b = a
     return groups[::-1]

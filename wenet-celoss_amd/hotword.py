@@ -47,6 +47,14 @@ def device_capable(cb) -> bool:
         return False
 
 
+def list_fits(cb, n_ctx: int) -> bool:
+    """The bias kernel keeps its vectors and one score per (head, list entry) in LDS: hw_check in csrc/decode.hip admits
+    (21 * dim + heads * max_ctx) * 4 bytes <= 60 KB, i.e. about 2 400 entries at dim 256 with 4 heads, 1 000 at dim 512.
+    Longer hot-word lists take the host-driven loop (search/greedy_search.py) instead of failing in the attach call."""
+    D = cb.predictor_bias.linear_q.weight.shape[0]
+    return (21 * D + int(cb.predictor_bias.h) * max(int(n_ctx), 8)) * 4 <= 60 * 1024
+
+
 class HotwordDecoder(DeviceDecoder):
     """A decoder handle with the hot-word module attached."""
 

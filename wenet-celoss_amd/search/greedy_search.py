@@ -149,8 +149,10 @@ def basic_greedy_search_both(model, encoder_out, encoder_out_lens, context_list=
     on the device (hotword.py: gate table, fused predictor biasing, gate / go-back state machine in the update kernel,
     hipGraph replay); WR_HOTWORD_HOST=1 forces the host-driven loop."""
     import os
-    from ..hotword import device_capable, greedy_search_both_device
-    if device_capable(model.context_bias) and os.environ.get("WR_HOTWORD_HOST", "0") != "1":
+    from ..hotword import device_capable, greedy_search_both_device, list_fits
+    n_ctx = int(context_list.shape[0]) if torch.is_tensor(context_list) and context_list.dim() == 2 else 1
+    if (device_capable(model.context_bias) and list_fits(model.context_bias, n_ctx)
+            and os.environ.get("WR_HOTWORD_HOST", "0") != "1"):
         hyps, traces = greedy_search_both_device(model, encoder_out, encoder_out_lens, context_list, context_lengths,
                                                  n_steps=n_steps, filter_on=context_filter_state == "on")
         lab = context_decoder_labels_padded

@@ -86,6 +86,11 @@ class Transducer(nn.Module):
         if attention_decoder is not None:
             self.criterion_att = LabelSmoothingLoss(size=vocab_size, padding_idx=ignore_id, smoothing=lsm_weight,
                                                     normalize_length=length_normalized_loss)
+        # encoder.embed.{subsampling_rate, right_context} as the exports below report them (asr_model.py:542-554); -1 when
+        # the encoder module has no `embed` (the reference would fail to script such a model)
+        embed = getattr(encoder, "embed", None)
+        self._subsampling_rate: int = int(getattr(embed, "subsampling_rate", -1))
+        self._right_context: int = int(getattr(embed, "right_context", -1))
         self._decoder_cache = DecoderCache()
         # joiner + RNN-T loss as one autograd node (fused.py): pass 1 of the loss rides on the joiner's epilogue and the
         # logits never leave the node (half the footprint).  WR_FUSED_LOSS=0 (or this attribute) selects the two separate ops.
@@ -238,18 +243,41 @@ class Transducer(nn.Module):
                             blank=self.blank, reduction="none")
         return loss_td * -1
 
-    def _cal_attn_score(self, encoder_out, encoder_mask, hyps_pad, hyps_lens):
-        """transducer.py:304-330"""
+    def _cal_attn_score(self, encoder_out, encoder_mask, hyps_pad, hyps_lens, reverse_weight: Optional[float] = None):
+        """transducer.py:304-330 (decoder called with self.reverse_weight) and the same block inside
+        asr_model.py:485-502 (called with the rescoring call's reverse_weight)."""
+        if reverse_weight is None:
+            reverse_weight = self.reverse_weight
         ori_hyps_pad = hyps_pad
         hyps_pad, _ = add_sos_eos(hyps_pad, self.sos, self.eos, self.ignore_id)
         hyps_lens = hyps_lens + 1
         r_hyps_pad = reverse_pad_list(ori_hyps_pad, hyps_lens, self.ignore_id)
         r_hyps_pad, _ = add_sos_eos(r_hyps_pad, self.sos, self.eos, self.ignore_id)
         decoder_out, r_decoder_out, _ = self.decoder(encoder_out, encoder_mask, hyps_pad, hyps_lens, r_hyps_pad,
-                                                     self.reverse_weight)
+                                                     reverse_weight)
         decoder_out = torch.nn.functional.log_softmax(decoder_out, dim=-1).cpu().numpy()
         r_decoder_out = torch.nn.functional.log_softmax(r_decoder_out, dim=-1).cpu().numpy()
         return decoder_out, r_decoder_out
+
+    def _attention_scores(self, hyps, decoder_out, r_decoder_out, reverse_weight: float):
+        """Per hypothesis: sum of the attention decoder's log-probabilities of its tokens plus <eos>, mixed with the
+        right-to-left decoder's when reverse_weight > 0 (the inner loop shared by asr_model.py:511-525 and
+        transducer.py:485-503; numpy fp32 rows summed left to right as there)."""
+        out = []
+        for i, hyp in enumerate(hyps):
+            n = len(hyp)
+            score = 0.0
+            for j, w in enumerate(hyp):
+                score += decoder_out[i][j][w]
+            score += decoder_out[i][n][self.eos]
+            if reverse_weight > 0:
+                r_score = 0.0
+                for j, w in enumerate(hyp):
+                    r_score += r_decoder_out[i][n - j - 1][w]
+                r_score += r_decoder_out[i][n][self.eos]
+                score = score * (1 - reverse_weight) + r_score * reverse_weight
+            out.append(score)
+        return out
 
     # CTC decode modes inherited from ASRModel in the reference (asr_model.py:281-440)
     def _forward_encoder(self, speech, speech_lengths, decoding_chunk_size: int = -1, num_decoding_left_chunks: int = -1,
@@ -294,6 +322,81 @@ class Transducer(nn.Module):
         hyps, _ = self._ctc_prefix_beam_search(speech, speech_lengths, beam_size, decoding_chunk_size,
                                                num_decoding_left_chunks, simulate_streaming)
         return hyps[0]
+
+    # ------------------------------------------- ASRModel surface the reference class inherits (asr_model.py) --
+    # The reference's Transducer IS an ASRModel (transducer.py:20), so wenet/bin/recognize.py may call `recognize`
+    # (--mode attention, recognize.py:259) and `attention_rescoring` (--mode attention_rescoring, :351) on it, and
+    # the C++ runtime calls the exported helpers below.  Plain host logic over the caller's attention decoder; the
+    # n-best list of attention_rescoring comes from the HIP CTC prefix beam search.
+    def recognize(self, speech: torch.Tensor, speech_lengths: torch.Tensor, beam_size: int = 10,
+                  decoding_chunk_size: int = -1, num_decoding_left_chunks: int = -1, simulate_streaming: bool = False):
+        """Beam search on the attention decoder, batched (asr_model.py:175-279) -> (best_hyps (B, L), best_scores (B,)).
+        Every step keeps `beam_size` prefixes per utterance: per-prefix top-k, finished prefixes carry one zero-cost
+        <eos> branch, top-k again over the beam_size^2 candidates; no length normalisation."""
+        assert speech.shape[0] == speech_lengths.shape[0]
+        assert decoding_chunk_size != 0
+        dev = speech.device
+        B, N = speech.shape[0], beam_size
+        memory, memory_mask = self._forward_encoder(speech, speech_lengths, decoding_chunk_size, num_decoding_left_chunks,
+                                                    simulate_streaming)
+        L = memory.size(1)
+        memory = memory.repeat_interleave(N, dim=0)                              # utterance-major, beam-minor rows
+        memory_mask = memory_mask.repeat_interleave(N, dim=0)
+        hyps = torch.full((B * N, 1), self.sos, dtype=torch.long, device=dev)
+        scores = torch.full((B, N), -float("inf"), device=dev)
+        scores[:, 0] = 0.0                                                       # one live prefix per utterance at start
+        scores = scores.view(-1, 1)
+        done = torch.zeros(B * N, 1, dtype=torch.bool, device=dev)
+        cache: Optional[List[torch.Tensor]] = None
+        first_of_utt = torch.arange(B, device=dev).unsqueeze(1) * N            # (B, 1)
+        for i in range(1, L + 1):
+            if bool(done.all()):
+                break
+            causal = torch.ones(i, i, dtype=torch.bool, device=dev).tril().unsqueeze(0).expand(B * N, i, i)
+            logp, cache = self.decoder.forward_one_step(memory, memory_mask, hyps, causal, cache)
+            cand_logp, cand_tok = logp.topk(N)                                   # (B*N, N)
+            # a finished prefix keeps exactly one continuation: <eos> at no cost
+            cand_logp = cand_logp.masked_fill(done, -float("inf"))
+            cand_logp[:, 0] = torch.where(done.squeeze(1), torch.zeros_like(cand_logp[:, 0]), cand_logp[:, 0])
+            cand_tok = cand_tok.masked_fill(done, self.eos)
+            scores, pick = (scores + cand_logp).view(B, N * N).topk(N)           # (B, N) each
+            scores = scores.view(-1, 1)
+            parent = (first_of_utt + pick // N).view(-1)                         # row of the prefix each survivor extends
+            tok = cand_tok.view(B, N * N).gather(1, pick).view(-1, 1)
+            hyps = torch.cat([hyps.index_select(0, parent), tok], dim=1)
+            done = tok == self.eos
+        best_scores, best = scores.view(B, N).max(dim=-1)
+        rows = best + torch.arange(B, device=dev) * N
+        return hyps.index_select(0, rows)[:, 1:], best_scores
+
+    def attention_rescoring(self, speech: torch.Tensor, speech_lengths: torch.Tensor, beam_size: int,
+                            decoding_chunk_size: int = -1, num_decoding_left_chunks: int = -1, ctc_weight: float = 0.0,
+                            simulate_streaming: bool = False, reverse_weight: float = 0.0):
+        """CTC prefix beam search n-best rescored by the attention decoder (asr_model.py:443-540) ->
+        (best prefix tuple, score)."""
+        assert speech.shape[0] == speech_lengths.shape[0]
+        assert decoding_chunk_size != 0
+        if reverse_weight > 0.0:
+            assert hasattr(self.decoder, "right_decoder")
+        device = speech.device
+        assert speech.shape[0] == 1
+        hyps, encoder_out = self._ctc_prefix_beam_search(speech, speech_lengths, beam_size, decoding_chunk_size,
+                                                         num_decoding_left_chunks, simulate_streaming)
+        assert len(hyps) == beam_size
+        prefixes = [h[0] for h in hyps]
+        hyps_pad = pad_sequence([torch.tensor(h, device=device, dtype=torch.long) for h in prefixes], True, self.ignore_id)
+        hyps_lens = torch.tensor([len(h) for h in prefixes], device=device, dtype=torch.long)
+        encoder_out = encoder_out.repeat(beam_size, 1, 1)
+        encoder_mask = torch.ones(beam_size, 1, encoder_out.size(1), dtype=torch.bool, device=device)
+        decoder_out, r_decoder_out = self._cal_attn_score(encoder_out, encoder_mask, hyps_pad, hyps_lens,
+                                                          reverse_weight=reverse_weight)
+        att = self._attention_scores(prefixes, decoder_out, r_decoder_out, reverse_weight)
+        best_score, best_index = -float("inf"), 0
+        for i in range(len(hyps)):
+            score = att[i] + hyps[i][1] * ctc_weight
+            if score > best_score:
+                best_score, best_index = score, i
+        return hyps[best_index][0], best_score
 
     def beam_search(self, speech: torch.Tensor, speech_lengths: torch.Tensor, decoding_chunk_size: int = -1,
                     beam_size: int = 5, num_decoding_left_chunks: int = -1, simulate_streaming: bool = False,
@@ -344,20 +447,10 @@ class Transducer(nn.Module):
         encoder_mask = torch.ones(beam_size, 1, encoder_out.size(1), dtype=torch.bool, device=device)
         td_score = self._cal_transducer_score(encoder_out, encoder_mask, hyps_lens, hyps_pad)
         decoder_out, r_decoder_out = self._cal_attn_score(encoder_out, encoder_mask, hyps_pad, hyps_lens)
+        att = self._attention_scores(hyps, decoder_out, r_decoder_out, reverse_weight)
         best_score, best_index = -float("inf"), 0
-        for i, hyp in enumerate(hyps):
-            score = 0.0
-            for j, w in enumerate(hyp):
-                score += decoder_out[i][j][w]
-            score += decoder_out[i][len(hyp)][self.eos]
-            td_s = td_score[i]
-            if reverse_weight > 0:
-                r_score = 0.0
-                for j, w in enumerate(hyp):
-                    r_score += r_decoder_out[i][len(hyp) - j - 1][w]
-                r_score += r_decoder_out[i][len(hyp)][self.eos]
-                score = score * (1 - reverse_weight) + r_score * reverse_weight
-            score = score * attn_weight + beam_score[i] * ctc_weight + td_s * transducer_weight
+        for i in range(len(hyps)):
+            score = att[i] * attn_weight + beam_score[i] * ctc_weight + td_score[i] * transducer_weight
             if score > best_score:
                 best_score, best_index = score, i
         return hyps[best_index], best_score
@@ -434,6 +527,75 @@ class Transducer(nn.Module):
                               cnn_cache: torch.Tensor = torch.zeros(0, 0, 0, 0)
                               ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         return self.encoder.forward_chunk(xs, offset, required_cache_size, att_cache, cnn_cache)
+
+    # The ASRModel exports the C++ runtime calls on every model (asr_model.py:542-634; torch_asr_model.cc reads
+    # subsampling_rate / right_context / sos_symbol / eos_symbol / is_bidirectional_decoder at load time).
+    @torch.jit.export
+    def subsampling_rate(self) -> int:
+        if torch.jit.is_scripting():
+            return self._subsampling_rate        # captured at construction: a scripted body cannot probe for `embed`
+        else:
+            return self.encoder.embed.subsampling_rate
+
+    @torch.jit.export
+    def right_context(self) -> int:
+        if torch.jit.is_scripting():
+            return self._right_context
+        else:
+            return self.encoder.embed.right_context
+
+    @torch.jit.export
+    def sos_symbol(self) -> int:
+        return self.sos
+
+    @torch.jit.export
+    def eos_symbol(self) -> int:
+        return self.eos
+
+    @torch.jit.export
+    def ctc_activation(self, xs: torch.Tensor) -> torch.Tensor:
+        """Linear + log-softmax in front of the CTC search (asr_model.py:597-607)."""
+        if self.ctc is not None:
+            return self.ctc.log_softmax(xs)
+        else:
+            raise RuntimeError("ctc_activation: the model was built without a CTC head")
+
+    @torch.jit.export
+    def is_bidirectional_decoder(self) -> bool:
+        if self.decoder is not None:
+            if hasattr(self.decoder, "right_decoder"):
+                return True
+            else:
+                return False
+        else:
+            return False
+
+    @torch.jit.export
+    def forward_attention_decoder(self, hyps: torch.Tensor, hyps_lens: torch.Tensor, encoder_out: torch.Tensor,
+                                  reverse_weight: float = 0.0) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Score an n-best list (sos-prefixed `hyps` (N, L), lengths counting the sos) on the attention decoder against
+        ONE encoder output (asr_model.py:620-710) -> (log-probs (N, L, V), right-to-left log-probs or a zero tensor).
+        The right-to-left input is built without pad_sequence (ONNX-friendly in the reference): the label part of every
+        row reversed in place, positions beyond its length filled with eos, the sos column kept."""
+        if self.decoder is not None:
+            assert encoder_out.size(0) == 1
+            n = hyps.size(0)
+            assert hyps_lens.size(0) == n
+            memory = encoder_out.repeat(n, 1, 1)
+            memory_mask = torch.ones(n, 1, memory.size(1), dtype=torch.bool, device=memory.device)
+            lab_lens = (hyps_lens - 1).unsqueeze(1)                                   # without the sos
+            labels = hyps[:, 1:]
+            pos = torch.arange(0, int(torch.max(lab_lens)), 1, device=memory.device)
+            valid = lab_lens > pos                                                    # (N, Lmax)
+            src = (lab_lens - 1 - pos) * valid                                        # mirrored index, 0 where invalid
+            flipped = torch.where(valid, torch.gather(labels, 1, src), self.eos)
+            r_hyps = torch.cat([hyps[:, 0:1], flipped], dim=1)
+            decoder_out, r_decoder_out, _ = self.decoder(memory, memory_mask, hyps, hyps_lens, r_hyps, reverse_weight)
+            decoder_out = torch.nn.functional.log_softmax(decoder_out, dim=-1)
+            r_decoder_out = torch.nn.functional.log_softmax(r_decoder_out, dim=-1)
+            return decoder_out, r_decoder_out
+        else:
+            raise RuntimeError("forward_attention_decoder: the model was built without an attention decoder")
 
     @torch.jit.export
     def forward_predictor_step(self, xs: torch.Tensor, cache: List[torch.Tensor]
