@@ -50,6 +50,31 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// ---- diagnostic build only (-DWR_STAMPS, tools/decode_stamps.py): per-wave s_memtime / s_memrealtime stamps of the
+// micro-step kernels into a device array, to attribute a kernel's microseconds to load latency / MFMA / reduction /
+// epilogue and to measure start skew and inter-kernel gaps.  In the product library none of this exists.
+#ifdef WR_STAMPS
+constexpr int kStampSlots = 12, kStampWgs = 1024, kStampWaves = 8, kStampPts = 10;
+__device__ unsigned long long g_stamps[kStampSlots * kStampWgs * kStampWaves * kStampPts];
+#define WR_STAMP_DECL unsigned long long st_[::wr::kStampPts] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define WR_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); st_[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WR_STAMP_RT(i) do { __builtin_amdgcn_sched_barrier(0); st_[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WR_STAMP_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define WR_STAMP_FLUSH(slot)                                                                                              \
+    do {                                                                                                                  \
+        const int wg_ = blockIdx.y * gridDim.x + blockIdx.x, wv_ = threadIdx.x >> 6;                                      \
+        if ((threadIdx.x & 63) == 0 && (slot) >= 0 && (slot) < ::wr::kStampSlots && wg_ < ::wr::kStampWgs && wv_ < ::wr::kStampWaves) \
+            for (int i_ = 0; i_ < ::wr::kStampPts; ++i_)                                                                  \
+                ::wr::g_stamps[((size_t)((slot) * ::wr::kStampWgs + wg_) * ::wr::kStampWaves + wv_) * ::wr::kStampPts + i_] = st_[i_]; \
+    } while (0)
+#else
+#define WR_STAMP_DECL
+#define WR_STAMP(i)
+#define WR_STAMP_RT(i)
+#define WR_STAMP_DRAIN()
+#define WR_STAMP_FLUSH(slot)
+#endif
+
 constexpr int kMaxLayers = WR_MAX_LSTM_LAYERS;
 enum PredictorType { kPredLstm = 0, kPredEmbedding = 1, kPredConv = 2 };
 constexpr int kMaxLanes = 1024;      // streams (greedy) or utterances x beam decoded together
@@ -153,6 +178,9 @@ struct GemmArgs {
     int row_part_ld;              // blocks per row
     const int32_t *ep_gate;       // hot-word mode: per-lane selector of the encoder stream (ep_all + gate * ep_gate_stride)
     size_t ep_gate_stride;
+#ifdef WR_STAMPS
+    int dbg_slot;
+#endif
 };
 
 enum GemmEpilogue { kEpiKMajor = 0, kEpiRowMajor = 1, kEpiLstmCell = 2, kEpiJointAct = 3, kEpiRowStats = 4 };
@@ -246,6 +274,9 @@ template <int MT, int EPI>
 __global__ __launch_bounds__(64 * kGemmWaves) void lane_gemm_kernel(GemmArgs g)
 {
     __shared__ float red[kGemmWaves][MT][32 * 32];
+    WR_STAMP_DECL;
+    WR_STAMP_RT(7);
+    WR_STAMP(0);
     const int n0 = blockIdx.x * 32;
     const int lane0 = blockIdx.y * (32 * MT);                          // first decode lane of this workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -343,10 +374,18 @@ __global__ __launch_bounds__(64 * kGemmWaves) void lane_gemm_kernel(GemmArgs g)
             }
     }
     __builtin_amdgcn_sched_barrier(0);
+    WR_STAMP(1);                                   // every load of the launch issued
+#if defined(WR_STAMPS) && WR_STAMPS >= 2
+    WR_STAMP_DRAIN();                              // level 2: wait for them, so that point 2 is the pure load latency
+    WR_STAMP(2);
+#endif
 
     for (int ci = 0;; ci += 2) {
         mfma_chunk(pb, pa);
         __builtin_amdgcn_sched_barrier(0);
+#if defined(WR_STAMPS) && WR_STAMPS < 2
+        if (ci == 0) WR_STAMP(2);                  // first chunk's operands arrived and its MFMAs issued
+#endif
         if (ci + 1 >= nch) break;
         load_chunk(ci + 2 < nch ? ci + 2 : ci + 1, pb, pa);
         __builtin_amdgcn_sched_barrier(0);
@@ -363,7 +402,9 @@ __global__ __launch_bounds__(64 * kGemmWaves) void lane_gemm_kernel(GemmArgs g)
             const int row = (r & 3) + 8 * (r >> 2) + 4 * half;       // C/D layout of the 32x32 MFMA
             red[wave][m][row * 32 + (l31 ^ row)] = acc[m][r];      // XOR swizzle: both epilogue orders are conflict-free
         }
+    WR_STAMP(3);                                   // MFMAs retired (accumulators read), partial tiles on their way to LDS
     __syncthreads();
+    WR_STAMP(4);
     auto total = [&](int m, int ln, int col) {
         const int rc = ln * 32 + (col ^ ln);
         return ((red[0][m][rc] + red[1][m][rc]) + (red[2][m][rc] + red[3][m][rc])) +
@@ -436,6 +477,11 @@ __global__ __launch_bounds__(64 * kGemmWaves) void lane_gemm_kernel(GemmArgs g)
                 if (f < g.look) g.C[(size_t)v * g.ldc + f * g.lane_stride + n] = act_on[it] ? act_value(g.act, act_ep[f][it] + pp) : 0.f;
         }
     }
+    WR_STAMP(5);                                   // epilogue stores issued
+    WR_STAMP_DRAIN();
+    WR_STAMP(6);
+    WR_STAMP_RT(8);
+    WR_STAMP_FLUSH(g.dbg_slot);
 }
 
 // xT[:, n] = embed[tok] for one lane (called by the kernels that decide a lane's next token)
@@ -666,6 +712,9 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(DevState *sp)
 {
     __shared__ float sv[4];
     __shared__ int si[4];
+    WR_STAMP_DECL;
+    WR_STAMP_RT(7);
+    WR_STAMP(0);
     const DevState S = *sp;                         // by value: no reloads of the pointers after the stores below
     const Dims &d = S.d;
     const int n = blockIdx.x, tid = threadIdx.x;
@@ -706,6 +755,7 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(DevState *sp)
 #pragma unroll
     for (int i = 0; i < PP; ++i) m = fmaxf(m, (tid + i * 256 < ncb) ? rec[i].x : -3.0e38f);
     m = block_max(m, sv);
+    WR_STAMP(1);                                   // state and records arrived, first reduction done
     if (!act) return;
     float sum = 0.f;
 #pragma unroll
@@ -732,6 +782,7 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(DevState *sp)
         if (idx < bi) { best = 1.f; bi = idx; }
     }
     block_argmax(best, bi, sv, si);
+    WR_STAMP(2);                                   // token decided
     const int k = bi;
     const bool emit = (k != S.blank);
     if (need) nic = 0;                             // the predictor stepped in this micro-step
@@ -811,6 +862,11 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(DevState *sp)
             S.cache_cT[o] = S.new_cT[o];
         }
     }
+    WR_STAMP(5);
+    WR_STAMP_DRAIN();
+    WR_STAMP(6);
+    WR_STAMP_RT(8);
+    WR_STAMP_FLUSH(HW ? 5 : 4);
 }
 
 // ---- look-ahead greedy: `look` encoder frames per micro-step against one predictor state -------------------
@@ -1242,6 +1298,9 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(DevState *sp)
 {
     __shared__ float sv[4];
     __shared__ int si[4];
+    WR_STAMP_DECL;
+    WR_STAMP_RT(7);
+    WR_STAMP(0);
     const DevState S = *sp;
     const Dims &d = S.d;
     const int n = blockIdx.x, tid = threadIdx.x;
@@ -1265,12 +1324,14 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(DevState *sp)
 #pragma unroll
     for (int i = 0; i < NV; ++i) m = fmaxf(m, (tid + i * 256 < d.V) ? xv[i] : -3.0e38f);
     m = block_max(m, sv);
+    WR_STAMP(1);                                   // rows arrived, first reduction done
     if (!act) return;
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) sum += (tid + i * 256 < d.V) ? expf(xv[i] - m) : 0.f;
     sum = block_sum(sum, sv);
     const float ls = logf(sum);
+    WR_STAMP(2);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const float l = (xv[i] - m) - ls;
@@ -1302,7 +1363,9 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(DevState *sp)
         const float touch = cp[(size_t)d.V + tid * 32];
         asm volatile("" ::"v"(touch));
     }
+    WR_STAMP(3);                                   // per-wave selection rounds done
     __syncthreads();
+    WR_STAMP(4);
     if (wave == 0) {
         const bool in = lane < 4 * S.beam;
         float cv0 = in ? wv[lane] : ninf;
@@ -1318,6 +1381,11 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(DevState *sp)
             if (ci == bi) cv0 = ninf;
         }
     }
+    WR_STAMP(5);
+    WR_STAMP_DRAIN();
+    WR_STAMP(6);
+    WR_STAMP_RT(8);
+    WR_STAMP_FLUSH(6);
 }
 
 __device__ __forceinline__ double log_add2(double a, double b)
@@ -1343,6 +1411,9 @@ __global__ __launch_bounds__(256) void beam_update_kernel(DevState *sp)
     __shared__ int e_src[kMaxBeam], e_blank[kMaxBeam], e_tok[kMaxBeam], e_last[kMaxBeam], e_lb[kMaxBeam];
     __shared__ double c_score[MC], f_score[MC];
     __shared__ int s_keep;
+    WR_STAMP_DECL;
+    WR_STAMP_RT(7);
+    WR_STAMP(0);
     const DevState S = *sp;
     const Dims &d = S.d;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -1381,6 +1452,7 @@ __global__ __launch_bounds__(256) void beam_update_kernel(DevState *sp)
         c_rank[tid] = 0;
     }
     __syncthreads();
+    WR_STAMP(1);                                   // candidates built
     // phase 2: class representative = the first candidate with the same token sequence (:130-142)
     for (int p = tid; p < C * C; p += 256) {
         const int i = p / C, f = p - i * C;
@@ -1406,6 +1478,7 @@ __global__ __launch_bounds__(256) void beam_update_kernel(DevState *sp)
         if (same) atomicMin(&c_rep[i], f);
     }
     __syncthreads();
+    WR_STAMP(2);                                   // classes known
     // phase 3: a representative accumulates its duplicates' scores in candidate order with float64 log_add
     if (tid < C) {
         double sc = c_score[tid];
@@ -1443,6 +1516,7 @@ __global__ __launch_bounds__(256) void beam_update_kernel(DevState *sp)
         S.token[b * beam + tid] = c_last[f];       // next frame's predictor input: last token of the hypothesis (:78-80)
     }
     __syncthreads();
+    WR_STAMP(3);                                   // fused, ranked, pruned
     // phase 5: the pruned beam -- hypotheses into the other buffer, (survivor, position) pairs in flight together
     {
         int maxlb = 0;
@@ -1489,6 +1563,7 @@ __global__ __launch_bounds__(256) void beam_update_kernel(DevState *sp)
             }
         }
     }
+    WR_STAMP(4);                                   // hypotheses and next inputs moved
     // predictor caches: a blank extension keeps the base hypothesis' cache, a label takes the predictor's new
     // cache (:111-124).  Rows i of [L*Hp][NLp]; a thread owns (row, survivor) pairs, `beam` survivors per row.
     {
@@ -1533,6 +1608,11 @@ __global__ __launch_bounds__(256) void beam_update_kernel(DevState *sp)
             S.hyp_sel[b] = 1 - sel;
         }
     }
+    WR_STAMP(5);
+    WR_STAMP_DRAIN();
+    WR_STAMP(6);
+    WR_STAMP_RT(8);
+    WR_STAMP_FLUSH(7);
 }
 
 __global__ void beam_export_kernel(DevState *s, int32_t *hyps_out, int32_t *lens_out, double *scores_out, int32_t *n_out)
@@ -1754,6 +1834,9 @@ void launch_predictor(wr_decoder *h, int n_lanes, hipStream_t st, bool with_proj
         GemmArgs g{};
         g.A0 = s.combT; g.B0 = s.pffn_wt; g.K0 = d.Dp;
         g.lda = d.NLp; g.ldb = up(d.D, 32); g.bias = s.pffn_b; g.C = s.ffnT; g.ldc = d.NLp; g.N = d.D; g.n_lanes = n_lanes;
+#ifdef WR_STAMPS
+        g.dbg_slot = -1;
+#endif
         launch_gemm<kEpiKMajor>(g, up(d.D, 32), n_lanes, st);
         hipLaunchKernelGGL(ctx_predictor_kernel<1>, dim3(n_lanes), dim3(kCtxThreads), 0, st, h->dev);
         return;
@@ -1769,12 +1852,18 @@ void launch_predictor(wr_decoder *h, int n_lanes, hipStream_t st, bool with_proj
         g.lda = d.NLp; g.ldb = d.G4p; g.bias = s.bsum[l]; g.C = nullptr; g.ldc = d.NLp; g.N = d.G4p; g.n_lanes = n_lanes;
         g.lane_active = s.lane_active; g.need_pred = s.need_pred; g.H = d.H;
         g.cache_cT = s.cache_cT + (size_t)l * ls; g.new_cT = s.new_cT + (size_t)l * ls; g.new_hT = s.new_hT + (size_t)l * ls;
+#ifdef WR_STAMPS
+        g.dbg_slot = l < 2 ? l : -1;
+#endif
         launch_gemm<kEpiLstmCell>(g, d.G4p, n_lanes, st);
     }
     if (!with_projection) return;                 // the caller applies the composed projection + pred_ffn
     GemmArgs g{};
     g.A0 = s.new_hT + (size_t)(d.L - 1) * ls; g.B0 = s.proj_wt; g.K0 = d.Hp;
     g.lda = d.NLp; g.ldb = up(d.P, 32); g.bias = s.proj_b; g.C = s.outT; g.ldc = d.NLp; g.N = d.P; g.n_lanes = n_lanes;
+#ifdef WR_STAMPS
+    g.dbg_slot = 8;
+#endif
     launch_gemm<kEpiKMajor>(g, up(d.P, 32), n_lanes, st);
 }
 
@@ -1797,9 +1886,15 @@ void launch_predictor_and_joint(wr_decoder *h, int n_lanes, hipStream_t st, int 
         g.lda = d.NLp; g.ldb = up(d.J, 32); g.C = s.ht; g.ldc = kMaxLook * d.NLp; g.N = d.J; g.n_lanes = n_lanes;
         g.st = h->dev; g.lane_active = s.lane_active; g.lane_t = s.lane_t; g.ep_all = s.ep_all; g.J = d.J;
         g.look = look; g.lane_stride = d.NLp; g.act = d.act;
+#ifdef WR_STAMPS
+        g.dbg_slot = 2;
+#endif
         launch_gemm<kEpiJointAct>(g, up(d.J, 32), n_lanes, st);
     }
     GemmArgs g{};
+#ifdef WR_STAMPS
+    g.dbg_slot = 3;
+#endif
     // the joiner output for every (frame, lane) column of ht: rows f * NLp + n of the logits
     const int rows = (look - 1) * d.NLp + n_lanes;
     g.A0 = s.ht; g.B0 = s.out_wt; g.K0 = d.Jp;
@@ -2283,9 +2378,15 @@ void hw_micro_step(wr_decoder *h, int n_lanes, hipStream_t st)
         g.st = h->dev; g.lane_active = s.lane_active; g.lane_t = s.lane_t; g.ep_all = h->hw_ep2; g.J = d.J;
         g.look = 1; g.lane_stride = d.NLp; g.act = d.act;
         g.ep_gate = h->hw_state; g.ep_gate_stride = (size_t)h->max_utt * h->Tmax * d.J;
+#ifdef WR_STAMPS
+        g.dbg_slot = 2;
+#endif
         launch_gemm<kEpiJointAct>(g, up(d.J, 32), n_lanes, st);
     }
     GemmArgs g{};
+#ifdef WR_STAMPS
+    g.dbg_slot = 3;
+#endif
     g.A0 = s.ht; g.B0 = s.out_wt; g.K0 = d.Jp;
     g.lda = kMaxLook * d.NLp; g.ldb = d.Vp; g.bias = s.out_b; g.C = s.logits; g.ldc = d.V; g.N = d.V; g.n_lanes = n_lanes;
     g.row_part = s.row_part; g.row_part_ld = s.n_cb;
@@ -2410,3 +2511,17 @@ extern "C" int wr_greedy_search_hotword(wr_decoder *h, const float *enc_hot_d, c
     scope.ok();
     return WR_OK;
 }
+
+#ifdef WR_STAMPS
+// diagnostic build only: copy the stamp array to the host and clear it
+extern "C" int wr_debug_read_stamps(unsigned long long *host, size_t n_words)
+{
+    const size_t total = (size_t)wr::kStampSlots * wr::kStampWgs * wr::kStampWaves * wr::kStampPts;
+    if (!host || n_words < total) return (int)total;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(wr::g_stamps), total * sizeof(unsigned long long)) != hipSuccess) return -1;
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(wr::g_stamps)) == hipSuccess) (void)hipMemset(p, 0, total * sizeof(unsigned long long));
+    return 0;
+}
+#endif
