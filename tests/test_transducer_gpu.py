@@ -432,6 +432,60 @@ def test_two_rank_ddp_training_step_on_the_product_path(tmp_path):
     assert "extra" not in got[1]
 
 
+def test_two_rank_ddp_at_librispeech_shapes(tmp_path):
+    """BASELINE config 4 rehearsed at shape (tests/ddp_shape_worker.py): two fresh ranks, a 57 M-parameter model (stand-in
+    encoder with the real parameter budget + the product's predictor / joiner / CTC head at V = 5000, J = 512), LibriSpeech
+    dynamic batches (4 utterances of <= 1500 fbank frames per rank and step), DistributedDataParallel(
+    find_unused_parameters=True) inside join(), accum_grad 4 (three no_sync steps + one synchronising step), RCCL when each
+    rank has a device of its own, gloo otherwise.  Every parameter's gradient after the synchronising step must equal the
+    mean over ranks of the per-rank accumulated gradients computed in this process; the step breakdown is printed."""
+    import json
+    import subprocess
+    import sys
+    import ddp_shape_worker as sw
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40e9:
+        pytest.skip("needs ~40 GB of free HBM (two ranks + the reference on one device)")
+    port = 29200 + os.getpid() % 500
+    out = str(tmp_path / "shape")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "ddp_shape_worker.py"),
+                                       out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        logs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
+    got = [torch.load(f"{out}.rank{r}", weights_only=True) for r in range(2)]
+    infos = [json.loads(g["info"]) for g in got]
+    for info in infos:
+        print("config-4 rehearsal:", json.dumps(info))
+    assert infos[0]["parameters"] > 55e6
+    # single-process reference: each rank's accumulated gradient, then the mean over ranks
+    dev = torch.device(DEV)
+    m = sw.build_model(dev)
+    params = list(m.named_parameters())
+    per_rank = []
+    for r in range(2):
+        m.zero_grad()
+        per_rank.append(sw.accumulate(m, params, r, dev))
+    top = max(float(v.abs().max()) for v in per_rank[0].values())
+    checked = 0
+    for n in per_rank[0]:
+        want = (per_rank[0][n] + per_rank[1][n]) / 2
+        tol = 2e-5 * float(want.abs().max()) + 1e-7 * top
+        for r in range(2):
+            assert float((got[r]["grads"][n] - want).abs().max()) <= tol, (n, r)
+        checked += 1
+    assert checked >= 100
+
+
 def test_amp_two_op_path_buckets_ragged_batches(monkeypatch):
     """The --use_amp configuration (joiner precision "bf16" under autocast: 16-bit logits, two ops) cuts a ragged batch
     into label-length groups as the fused node does; loss and gradients equal the one-call path to summation order."""

@@ -286,6 +286,10 @@ __global__ __launch_bounds__(64 * kGemmWaves) void lane_gemm_kernel(GemmArgs g)
     f32x16 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = (f32x16){0};
+#ifdef WR_STAMPS
+    asm volatile("" ::"s"(g.K0), "s"(g.ldb));      // the kernel-argument segment has arrived
+    WR_STAMP(9);
+#endif
     const int kq0 = g.K0 / kGemmWaves, kq1 = (g.A1 != nullptr) ? g.K1 / kGemmWaves : 0;
     const int nch0 = (kq0 + 2 * CH - 1) / (2 * CH), nch1 = (kq1 + 2 * CH - 1) / (2 * CH);
     const int nch = nch0 + nch1;
