@@ -294,7 +294,7 @@ typedef struct wr_transducer_weights {
     int32_t n_layers;     /* L */
     int32_t join_dim;     /* J */
     int32_t activation;   /* wr_activation of the joiner (0 = tanh) */
-    const float *embed;                        /* predictor.embed.weight       [V, D] */
+    const float *embed;                        /* predictor.embed.weight       [V, D] ([embed_rows, D] if embed_rows > 0) */
     const float *w_ih[WR_MAX_LSTM_LAYERS];     /* predictor.rnn.weight_ih_l{k} [4H, D or H], gate order i,f,g,o */
     const float *w_hh[WR_MAX_LSTM_LAYERS];     /* predictor.rnn.weight_hh_l{k} [4H, H] */
     const float *b_ih[WR_MAX_LSTM_LAYERS];     /* predictor.rnn.bias_ih_l{k}   [4H] */
@@ -312,7 +312,9 @@ typedef struct wr_transducer_weights {
     int32_t n_head;            /* type 1: heads of the positional weighting; n_head * context_size <= 64 */
     int32_t pred_activation;   /* wr_activation applied after the LayerNorm */
     float ln_eps;              /* LayerNorm epsilon */
-    int32_t reserved;
+    int32_t embed_rows;        /* rows of predictor.embed.weight when that differs from V (a predictor stepped on its own
+                                * through wr_predictor_step has no joiner vocabulary); 0 = vocab_size.  The LSTM path keeps a
+                                * table of W_ih(layer 0) . embed[v] with that many rows. */
     const float *pos_w;                        /* type 1: pos_embed.weight     [n_head, D * context_size] (bias unused) */
     const float *ffn_w, *ffn_b;                /* type 1: ffn                  [D, D], [D] */
     const float *norm_w, *norm_b;              /* types 1, 2: norm             [D], [D] */

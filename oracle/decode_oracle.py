@@ -143,8 +143,9 @@ class StreamingGreedy:
     chunk (:571) drops the predictor state that was computed but not yet committed in the previous chunk;
     False keeps it, which makes a chunked decode equal the offline decode of the concatenated frames."""
 
-    def __init__(self, pred: Predictor, joint: Joint, blank=0):
+    def __init__(self, pred: Predictor, joint: Joint, blank=0, clear_margin=1e-4):
         self.pred, self.joint, self.blank = pred, joint, blank
+        self.clear_margin = clear_margin
         self.reset_cache()
 
     def reset_cache(self):
@@ -155,6 +156,8 @@ class StreamingGreedy:
         self.per_frame = 0
         self.prev_nblk = True
         self.min_margin = float("inf")      # smallest top-1 / top-2 log-prob gap over all decisions so far
+        self.n_tokens = 0                   # tokens emitted since reset_cache
+        self.clear_tokens = None            # tokens emitted before the first decision whose gap was < clear_margin
 
     def forward_greedy_search(self, enc, T, n_steps=64, reference_new_cache=True):
         padding = np.zeros((1, 1), F)
@@ -167,7 +170,10 @@ class StreamingGreedy:
             k = int(lp.argmax())
             top2 = np.partition(lp, -2)[-2:]
             self.min_margin = min(self.min_margin, float(top2[1] - top2[0]))
+            if self.clear_tokens is None and float(top2[1] - top2[0]) < self.clear_margin:
+                self.clear_tokens = self.n_tokens
             if k != self.blank:
+                self.n_tokens += 1
                 hyps.append(k)
                 self.prev_nblk = True
                 self.per_frame += 1
@@ -320,12 +326,15 @@ def ctc_log_softmax(w, enc):
 
 
 def prefix_beam_search(pred: Predictor, joint: Joint, ctc_w, enc, T, beam_size=5, ctc_weight=0.3,
-                       transducer_weight=0.7, blank=0, return_margin=False):
+                       transducer_weight=0.7, blank=0, return_margin=False, stop_below=None):
     """prefix_beam_search.py:42-148 for one utterance.  Returns the pruned beam as a
     list of dicts {hyp (with the seed blank), score (float64), cache}.
     return_margin: also return the smallest score gap that decided anything visible in the result -- between
     neighbours of the sorted fused candidates down to the first pruned one, over all frames.  An implementation
-    whose per-frame log-probs differ in the last fp32 bits can only produce a different beam when this is tiny."""
+    whose per-frame log-probs differ in the last fp32 bits can only produce a different beam when this is tiny.
+    stop_below: stop in front of the first frame whose own margin is below this value and return
+    (beam after the clear prefix, smallest margin inside the prefix, number of frames decoded) -- the long-utterance
+    comparison of BASELINE config 5: everything up to the first ambiguous decision must agree."""
     ctc_probs = ctc_log_softmax(ctc_w, enc[:T])
     beam = [dict(hyp=[blank], score=0.0, cache=pred.init_state(1))]
     min_margin = float("inf")
@@ -360,12 +369,18 @@ def prefix_beam_search(pred: Predictor, joint: Joint, ctc_w, enc, T, beam_size=5
             else:
                 fusion.append(s1)
         fusion.sort(key=lambda s: s["score"], reverse=True)                 # stable, like list.sort
-        if return_margin:
+        if return_margin or stop_below is not None:
             sc = [s["score"] for s in fusion[:beam_size + 1]]
+            frame_margin = float("inf")
             for a, b in zip(sc[:-1], sc[1:]):
                 if math.isfinite(a) and math.isfinite(b):
-                    min_margin = min(min_margin, a - b)
+                    frame_margin = min(frame_margin, a - b)
+            if stop_below is not None and frame_margin < stop_below:
+                return beam, min_margin, i
+            min_margin = min(min_margin, frame_margin)
         beam = fusion[:beam_size]
+    if stop_below is not None:
+        return beam, min_margin, T
     return (beam, min_margin) if return_margin else beam
 
 

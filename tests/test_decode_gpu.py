@@ -328,7 +328,8 @@ def test_config3_shape_streams_match_oracle():
 def test_config5_full_shape_prefix_beam_matches_oracle():
     """BASELINE config 5 at full shape: one call with B=16 utterances, T=1500 encoder frames, V=5000, E=P=256,
     J=512, LSTM 2x256, beam 8, ctc/transducer weights (0.3, 0.7) -- prefix_beam_search.py:42-148 for every
-    utterance.  The ten utterances of at most 150 frames are re-decoded by the numpy oracle; n-best hypotheses and
+    utterance.  The ten utterances of at most 150 frames are re-decoded whole by the numpy oracle, the five long ones
+    (400 .. 1500 frames) over their clear prefix (below); n-best hypotheses and
     their order must be identical and scores agree to 1e-5 relative for every one whose decisions were clear:
     random weights give near-degenerate beams (hypotheses whose scores differ by less than an fp32 ulp of the
     score), so an utterance is compared only if the smallest gap between neighbouring candidates around the prune
@@ -369,6 +370,21 @@ def test_config5_full_shape_prefix_beam_matches_oracle():
             np.testing.assert_allclose([s.score for s in res[i]], [s["score"] for s in ref], rtol=1e-5)
             compared += 1
     assert compared >= 4, margins
+    # The long utterances (T = 1500, 1500, 1000, 700, 400 -- the config's defining length).  Random weights give beams
+    # whose entries sit within 1e-2 of each other, so a decision with a gap below 1e-4 turns up every ~100 frames and
+    # from there on two fp32 implementations may legitimately keep different tails.  Up to that frame everything must
+    # agree: the oracle stops in front of the first frame whose prune margin is < 1e-4 (`stop_below`), the HIP search
+    # decodes the same frames, and n-best, order and scores are compared as above.
+    clear = []
+    for i in range(5):
+        ref, margin, f = do.prefix_beam_search(p, j, cw, enc[i].numpy(), lens[i], beam_size=beam, ctc_weight=0.3,
+                                               transducer_weight=0.7, stop_below=1e-4)
+        clear.append(f)
+        assert f >= 30, (i, f)
+        got = bs.search_encoded(enc_d[i:i + 1, :f].contiguous(), torch.tensor([f]), beam, 0.3, 0.7)[0]
+        assert [s["hyp"] for s in ref] == [s.hyp for s in got], (i, f, margin)
+        np.testing.assert_allclose([s.score for s in got], [s["score"] for s in ref], rtol=1e-5)
+    assert sum(clear) >= 500, clear                   # 42 + 60 + 67 + 277 + 149 frames for this seed on the CPU
     # a full-length utterance decoded alone gives what it gave inside the batch
     single = bs.search_encoded(enc_d[1:2].contiguous(), torch.tensor([lens[1]]), beam, 0.3, 0.7)[0]
     assert [s.hyp for s in single] == [s.hyp for s in res[1]]
@@ -420,6 +436,47 @@ def test_config3_chunked_streams_match_reference_loop():
                 assert [t for ch in got[i] for t in ch] == off, i
         assert compared >= 48, compared                # at most a quarter of the streams may be ambiguous
         assert emitted > compared                      # the scenario emits tokens
+
+
+def test_config3_chunked_streams_unscaled_weights_prefix_rule():
+    """Config 3 again WITHOUT the engineered weights of the test above (no x10 on ffn_out, no blank bias): plain randomly
+    initialised modules, whose logits are nearly flat (top-1 / top-2 gaps of a few 1e-2), so every decision emits and
+    every frame runs into the n_steps cap.  The rule is the prefix rule: a stream's tokens are compared with the
+    reference loop up to the first decision whose top-1 / top-2 log-prob gap is below 1e-4 (from there on two fp32
+    implementations may differ); at least 24 of the 32 compared streams must be clear for 20 tokens or more, and at least
+    8 to the end."""
+    import wenet_celoss_amd as w
+    torch.manual_seed(17)
+    V, E, P, J, H, L, N, C, n_chunks, n_steps = 5000, 256, 256, 512, 256, 2, 64, 16, 3, 4
+    pred = w.RNNPredictor(V, P, P, 0.1, H, L).to(DEV).eval()
+    joint = w.TransducerJoint(V, E, P, J).to(DEV).eval()
+    m = w.Transducer(V, 0, torch.nn.Identity(), pred, joint, ctc_weight=0.0, transducer_weight=1.0, hw_weight=0.0)
+    enc = torch.randn(N, C * n_chunks, E, device=DEV)
+    chunk_lens = [torch.full((N,), C), torch.randint(5, C + 1, (N,)), torch.full((N,), C)]
+    p = do.Predictor({k: v.detach().cpu().numpy() for k, v in pred.state_dict().items()}, L)
+    j = do.Joint({k: v.detach().cpu().numpy() for k, v in joint.state_dict().items()})
+    enc_np = enc.cpu().numpy()
+    m.reset_cache(N, chunk_frames=C, n_steps=n_steps)
+    got = [[] for _ in range(N)]
+    for c in range(n_chunks):
+        res = m.forward_greedy_search(enc[:, c * C:(c + 1) * C].contiguous(), chunk_lens[c], n_steps=n_steps)
+        for i in range(N):
+            got[i] += res[i]
+    compared_tokens, fully_clear, long_prefix = 0, 0, 0
+    for i in range(0, N, 2):
+        ref = do.StreamingGreedy(p, j)
+        want = []
+        for c in range(n_chunks):
+            want += ref.forward_greedy_search(enc_np[i, c * C:(c + 1) * C], int(chunk_lens[c][i]), n_steps=n_steps)
+        k = len(want) if ref.clear_tokens is None else ref.clear_tokens
+        assert got[i][:k] == want[:k], (i, k, ref.min_margin)
+        compared_tokens += k
+        long_prefix += k >= 20
+        if ref.clear_tokens is None:
+            assert got[i] == want, i
+            fully_clear += 1
+    print('unscaled config 3: tokens compared', compared_tokens, 'streams clear to the end', fully_clear, 'with >= 20 clear tokens', long_prefix)
+    assert compared_tokens >= 32 * 40 and fully_clear >= 8 and long_prefix >= 24, (compared_tokens, fully_clear, long_prefix)
 
 
 def test_streaming_chunks_equal_offline_and_reference_quirk():

@@ -156,7 +156,7 @@ class TransducerWeights(ctypes.Structure):
                 ("pred_ffn_w", ctypes.c_void_p), ("pred_ffn_b", ctypes.c_void_p),
                 ("out_w", ctypes.c_void_p), ("out_b", ctypes.c_void_p),
                 ("predictor_type", ctypes.c_int32), ("context_size", ctypes.c_int32), ("n_head", ctypes.c_int32),
-                ("pred_activation", ctypes.c_int32), ("ln_eps", ctypes.c_float), ("reserved", ctypes.c_int32),
+                ("pred_activation", ctypes.c_int32), ("ln_eps", ctypes.c_float), ("embed_rows", ctypes.c_int32),
                 ("pos_w", ctypes.c_void_p), ("ffn_w", ctypes.c_void_p), ("ffn_b", ctypes.c_void_p),
                 ("norm_w", ctypes.c_void_p), ("norm_b", ctypes.c_void_p),
                 ("conv_w", ctypes.c_void_p), ("conv_b", ctypes.c_void_p)]

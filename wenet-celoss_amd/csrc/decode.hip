@@ -85,6 +85,7 @@ constexpr int kStageSlots = 4;
 
 struct Dims {
     int V, E, P, D, H, L, J;      // vocab, encoder dim, predictor out dim, embed dim, hidden, layers, join dim
+    int Ve;                       // rows of the embedding table (= V unless the caller says otherwise)
     int Dp, Hp, Pp, Jp;           // K dimensions padded to a multiple of 8 (zero rows)
     int G4p, Vp;                  // N dimensions: 4H padded to 32, V padded to 256
     int NL, NLp;                  // lanes, lanes padded to 32
@@ -122,6 +123,11 @@ struct DevState {
     float *xT;                    // [Dp][NLp]     embedding of each lane's token
     float *cache_hT, *cache_cT;   // [L][Hp][NLp]  committed LSTM state
     float *new_hT, *new_cT;       // [L][Hp][NLp]  output of the last predictor step
+    // LSTM predictor in its hoisted form (see "LSTM predictor step" below): state lives in a pool of 2 * NLp slots
+    float *etab;                  // [V][G4p]          W_ih(layer 0) . embed[v], gate columns permuted like the weights
+    float *pool_c;                // [L][2 NLp][Hp]    cell state of a slot
+    float *pool_g;                // [L][2 NLp][G4p]   W_hh . h + b_ih + b_hh of the slot's hidden state
+    int32_t *comm_slot, *new_slot;   // [NLp] slot of a lane's committed state / slot its next predictor step writes
     float *outT;                  // [Pp][NLp]     projected predictor output
     float *ht;                    // [Jp][kMaxLook * NLp]  joiner activation, column f * NLp + n
     float *logits;                // [kMaxLook * NLp, V]   row f * NLp + n: lane n, frame t_n + f
@@ -168,8 +174,7 @@ struct GemmArgs {
     // kernel reads them from its argument segment instead of chasing them through the device-side state
     const DevState *st;           // per-call scalars (T, lanes_per_utt)
     const int32_t *lane_active, *need_pred, *lane_t;
-    const float *cache_cT;        // this layer's committed cell state   [Hp][NLp]
-    float *new_cT, *new_hT;       // this layer's new state
+    float *new_hT;                // this layer's new hidden state [Hp][NLp] (lane-indexed: the next GEMM's A operand)
     const float *ep_all;          // [n_utt, T, J]
     int H, J;
     int act;                      // joiner activation (wr_activation)
@@ -178,12 +183,18 @@ struct GemmArgs {
     int row_part_ld;              // blocks per row
     const int32_t *ep_gate;       // hot-word mode: per-lane selector of the encoder stream (ep_all + gate * ep_gate_stride)
     size_t ep_gate_stride;
+    // LSTM layers >= 1 (kEpiLstmCell) and the recurrent products (kEpiSlotRow): state pool of this layer, row-major per slot
+    float *pool_g;                // [2 NLp][G4p]  W_hh . h + b of the slot's hidden state
+    float *pool_c;                // [2 NLp][Hp]   cell state
+    const int32_t *comm_slot, *new_slot;   // [NLp]
+    const int32_t *slot_idx;      // kEpiSlotRow: the slot each lane's row goes to
+    int Hp, G4p;
 #ifdef WR_STAMPS
     int dbg_slot;
 #endif
 };
 
-enum GemmEpilogue { kEpiKMajor = 0, kEpiRowMajor = 1, kEpiLstmCell = 2, kEpiJointAct = 3, kEpiRowStats = 4 };
+enum GemmEpilogue { kEpiKMajor = 0, kEpiRowMajor = 1, kEpiLstmCell = 2, kEpiJointAct = 3, kEpiRowStats = 4, kEpiSlotRow = 5 };
 
 // ----------------------------------------------------------------- setup --
 // src [R][C] row-major -> dst [C][Rp] (zero padded columns R..Rp-1 and rows C..Cp-1)
@@ -271,13 +282,12 @@ __global__ void lstm_bias_prep_kernel(const float *__restrict__ b_ih, const floa
 // 32-column tile holds i,f,g,o of 8 hidden units), joiner activation tanh(enc_ffn(enc)[t] + pred_ffn(pred)).
 constexpr int kGemmWaves = 8;
 template <int MT, int EPI>
-__global__ __launch_bounds__(64 * kGemmWaves) void lane_gemm_kernel(GemmArgs g)
+__device__ __forceinline__ void lane_gemm_body(const GemmArgs &g, const int bx, float (&red)[kGemmWaves][MT][32 * 32])
 {
-    __shared__ float red[kGemmWaves][MT][32 * 32];
     WR_STAMP_DECL;
     WR_STAMP_RT(7);
     WR_STAMP(0);
-    const int n0 = blockIdx.x * 32;
+    const int n0 = bx * 32;
     const int lane0 = blockIdx.y * (32 * MT);                          // first decode lane of this workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -329,9 +339,9 @@ __global__ __launch_bounds__(64 * kGemmWaves) void lane_gemm_kernel(GemmArgs g)
     constexpr int kItems = MT * 1024 / NT;                                // outputs per thread of the 32 x 32*MT tile
     float bias_v[kItems > 4 ? kItems : 4];
     bool cell_on = false;
-    int cell_j = 0;
-    size_t cell_o = 0;
-    float cell_c = 0.f;
+    int cell_j = 0, cell_n = 0, cell_unit = 0, cell_sn = 0;
+    float cell_c = 0.f, cell_g[4];
+    int slot_v[kItems];
     bool act_on[kItems];
     float act_ep[kMaxLook][kItems];
     if (EPI == kEpiRowMajor || EPI == kEpiRowStats) {
@@ -345,16 +355,30 @@ __global__ __launch_bounds__(64 * kGemmWaves) void lane_gemm_kernel(GemmArgs g)
         }
     }
     if (EPI == kEpiLstmCell) {
+        // gates = (W_ih . h_below: this GEMM) + (W_hh . h + b: pool_g of the lane's committed slot); one (lane, unit) per thread
         const int q = tid & 255;
         cell_j = q >> 5;
+        cell_n = lane0 + ((tid >> 8) % MT) * 32 + l31;
+        cell_unit = (n0 >> 5) * 8 + cell_j;
+        const bool in = tid < MT * 256 && cell_n < g.n_lanes && cell_unit < g.H;
+        const int nn = in ? cell_n : 0;
+        const int la = g.lane_active[nn], np = g.need_pred[nn];
+        const int sc = g.comm_slot[nn];
+        cell_sn = g.new_slot[nn];
+        const float *__restrict__ gp = g.pool_g + (size_t)sc * g.G4p + n0 + cell_j;
 #pragma unroll
-        for (int gt = 0; gt < 4; ++gt) bias_v[gt] = g.bias[n0 + gt * 8 + cell_j];   // bias is padded to 4*Hp
-        const int n = lane0 + ((tid >> 8) % MT) * 32 + l31, unit = (n0 >> 5) * 8 + cell_j;
-        const bool in = tid < MT * 256 && n < g.n_lanes && unit < g.H;
-        cell_o = in ? (size_t)unit * g.lda + n : 0;                     // lda = NLp
-        const int la = g.lane_active[in ? n : 0], np = g.need_pred[in ? n : 0];
-        cell_c = g.cache_cT[cell_o];
+        for (int gt = 0; gt < 4; ++gt) cell_g[gt] = gp[gt * 8];
+        cell_c = g.pool_c[(size_t)sc * g.Hp + (in ? cell_unit : 0)];
         cell_on = in && la && np;
+    } else if (EPI == kEpiSlotRow) {
+        const int v = n0 + l31;
+        bias_v[0] = g.bias ? g.bias[v < g.N ? v : g.N - 1] : 0.f;
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            const int i = tid + it * NT;
+            const int n = lane0 + (i >> 10) * 32 + ((i & 1023) >> 5);
+            slot_v[it] = g.slot_idx[n < g.n_lanes ? n : 0];
+        }
     } else if (EPI == kEpiJointAct) {
         const int T = g.st->T, lpu = g.st->lanes_per_utt;
         int tt[kItems];
@@ -444,7 +468,7 @@ __global__ __launch_bounds__(64 * kGemmWaves) void lane_gemm_kernel(GemmArgs g)
             // each butterfly -- they do (a + b == b + a), so the record does not depend on the lane that stores it
             const float se = half_allreduce_f(in ? expf(x - mx) : 0.f, [](float a, float b) { return a + b; });
             if (col == 0 && n < g.n_lanes)
-                g.row_part[(size_t)n * g.row_part_ld + blockIdx.x] = make_float4(mx, se, second, __builtin_bit_cast(float, n0 + first));
+                g.row_part[(size_t)n * g.row_part_ld + bx] = make_float4(mx, se, second, __builtin_bit_cast(float, n0 + first));
         }
     } else if (EPI == kEpiKMajor) {
 #pragma unroll
@@ -460,13 +484,22 @@ __global__ __launch_bounds__(64 * kGemmWaves) void lane_gemm_kernel(GemmArgs g)
         if (cell_on) {
             const int j = cell_j, ln = l31;
             const int m = (tid >> 8) % MT;
-            const float ig = sigmoidf_(total(m, ln, j) + bias_v[0]);
-            const float fg = sigmoidf_(total(m, ln, 8 + j) + bias_v[1]);
-            const float gg = tanhf(total(m, ln, 16 + j) + bias_v[2]);
-            const float og = sigmoidf_(total(m, ln, 24 + j) + bias_v[3]);
+            const float ig = sigmoidf_(total(m, ln, j) + cell_g[0]);
+            const float fg = sigmoidf_(total(m, ln, 8 + j) + cell_g[1]);
+            const float gg = tanhf(total(m, ln, 16 + j) + cell_g[2]);
+            const float og = sigmoidf_(total(m, ln, 24 + j) + cell_g[3]);
             const float c = fg * cell_c + ig * gg;
-            g.new_cT[cell_o] = c;
-            g.new_hT[cell_o] = og * tanhf(c);
+            g.pool_c[(size_t)cell_sn * g.Hp + cell_unit] = c;
+            g.new_hT[(size_t)cell_unit * g.lda + cell_n] = og * tanhf(c);       // lda = NLp
+        }
+    } else if (EPI == kEpiSlotRow) {
+        // row-major rows addressed through a per-lane slot: pool_g[slot(n)][v] = W_hh[v] . h_n + b[v]
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            const int i = tid + it * NT;
+            const int m = i >> 10, ln = (i & 1023) >> 5, col = i & 31;
+            const int n = lane0 + m * 32 + ln, v = n0 + col;
+            if (n < g.n_lanes && v < g.N) g.C[(size_t)slot_v[it] * g.ldc + v] = total(m, ln, col) + bias_v[0];
         }
     } else {   // kEpiJointAct: ht[j][f * stride + lane] = tanh(ep_all[utt, t_lane + f, j] + pp[j][lane]); zero for idle lanes
 #pragma unroll
@@ -488,11 +521,113 @@ __global__ __launch_bounds__(64 * kGemmWaves) void lane_gemm_kernel(GemmArgs g)
     WR_STAMP_FLUSH(g.dbg_slot);
 }
 
+template <int MT, int EPI>
+__global__ __launch_bounds__(64 * kGemmWaves) void lane_gemm_kernel(GemmArgs g)
+{
+    __shared__ float red[kGemmWaves][MT][32 * 32];
+    lane_gemm_body<MT, EPI>(g, blockIdx.x, red);
+}
+
+// Two independent GEMMs over the same lanes in ONE launch (column tiles [0, ct0) belong to the first): the small
+// predictor GEMMs leave most of the chip idle, so the recurrent product of the layer below rides along for free.
+template <int MT, int EPI0, int EPI1>
+__global__ __launch_bounds__(64 * kGemmWaves) void lane_gemm_pair_kernel(GemmArgs g0, GemmArgs g1, int ct0)
+{
+    __shared__ float red[kGemmWaves][MT][32 * 32];
+    if ((int)blockIdx.x < ct0) lane_gemm_body<MT, EPI0>(g0, blockIdx.x, red);
+    else lane_gemm_body<MT, EPI1>(g1, (int)blockIdx.x - ct0, red);
+}
+
+// ---- LSTM predictor step, hoisted form -------------------------------------------------------------------------
+// gates_l = W_ih_l . in_l + W_hh_l . h_l + b_l.  Two of the three terms do not have to wait for the step:
+//   * layer 0's input is an embedding row, so W_ih_0 . embed[v] is a table (etab, built once per handle);
+//   * W_hh_l . h_l + b_l depends only on the state the step starts from, and that state was itself produced by an
+//     earlier step: it is computed right behind that step (kEpiSlotRow jobs riding in the launches of the next stage,
+//     which leave most of the chip idle) and kept with the state (pool_g).
+// Layer 0 is then elementwise and runs in the tail of the kernel that decides the token (update / resolve / beam
+// update / init): one launch per micro-step less, and the layer >= 1 GEMMs have half the depth.  State lives in a pool
+// of 2 * NLp slots addressed through comm_slot / new_slot: committing a step swaps two integers (greedy) and the beam
+// search's survivors inherit slot numbers instead of copied caches.  Lane-indexed are only the hidden outputs of the
+// last step (new_hT), which the next GEMM reads as its k-major A operand.
+__device__ __forceinline__ void lstm_layer0_cell(const DevState &S, int n, int tok, int sc, int sn)
+{
+    const Dims &d = S.d;
+    const float *__restrict__ e = S.etab + (size_t)tok * d.G4p;
+    const float *__restrict__ g = S.pool_g + (size_t)sc * d.G4p;
+    const float *__restrict__ c0 = S.pool_c + (size_t)sc * d.Hp;
+    float *__restrict__ c1 = S.pool_c + (size_t)sn * d.Hp;
+    for (int u = threadIdx.x; u < d.H; u += blockDim.x) {
+        const int col = (u >> 3) * 32 + (u & 7);              // tile of 32 columns = i,f,g,o of 8 units
+        const float ig = sigmoidf_(e[col] + g[col]);
+        const float fg = sigmoidf_(e[col + 8] + g[col + 8]);
+        const float gg = tanhf(e[col + 16] + g[col + 16]);
+        const float og = sigmoidf_(e[col + 24] + g[col + 24]);
+        const float c = fg * c0[u] + ig * gg;
+        c1[u] = c;
+        S.new_hT[(size_t)u * d.NLp + n] = og * tanhf(c);
+    }
+}
+
+// A lane's two slots hold the zero state (h = 0, so W_hh . h + b = b), comm_slot = n, new_slot = NLp + n.
+__device__ __forceinline__ void lstm_reset_lane(const DevState &S, int n)
+{
+    const Dims &d = S.d;
+    const size_t S2 = 2 * (size_t)d.NLp;
+    for (int l = 0; l < d.L; ++l) {
+        float *pc = S.pool_c + ((size_t)l * S2 + n) * d.Hp;
+        float *pg = S.pool_g + ((size_t)l * S2 + n) * d.G4p;
+        for (int i = threadIdx.x; i < d.Hp; i += blockDim.x) pc[i] = 0.f;
+        for (int i = threadIdx.x; i < d.G4p; i += blockDim.x) pg[i] = S.bsum[l][i];
+    }
+    if (threadIdx.x == 0) { S.comm_slot[n] = n; S.new_slot[n] = d.NLp + n; }
+}
+
+// etab[v][c'] = sum_k w_ih0[gate * H + unit][k] * embed[v][k]  (c' <-> (unit, gate) as in lstm_weight_prep_kernel); float64
+// sums rounded once (setup, once per handle)
+__global__ void lstm_etab_kernel(const float *__restrict__ embed, const float *__restrict__ w_ih, int V, int D, int H, int Hp,
+                                 float *__restrict__ etab)
+{
+    const int G4p = 4 * Hp;
+    const long total = (long)V * G4p;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int v = (int)(i / G4p), c = (int)(i % G4p);
+        const int unit = (c >> 5) * 8 + (c & 7), gate = (c & 31) >> 3;
+        double a = 0.0;
+        if (unit < H) {
+            const float *__restrict__ wr = w_ih + (size_t)(gate * H + unit) * D;
+            const float *__restrict__ er = embed + (size_t)v * D;
+            for (int k = 0; k < D; ++k) a += (double)wr[k] * (double)er[k];
+        }
+        etab[i] = (float)a;
+    }
+}
+
+// step API: layer 0 for every lane as a kernel of its own
+__global__ void lstm_layer0_kernel(DevState *sp)
+{
+    const DevState &S = *sp;
+    const int n = blockIdx.x;
+    if (!(S.lane_active[n] && S.need_pred[n])) return;
+    lstm_layer0_cell(S, n, S.token[n], S.comm_slot[n], S.new_slot[n]);
+}
+
 // xT[:, n] = embed[tok] for one lane (called by the kernels that decide a lane's next token)
 __device__ __forceinline__ void write_embedding_column(DevState *s, int n, int tok)
 {
     const Dims &d = s->d;
     for (int k = threadIdx.x; k < d.D; k += blockDim.x) s->xT[(size_t)k * d.NLp + n] = s->embed[(size_t)tok * d.D + k];
+}
+
+// A lane starts from the zero state with the blank as its first predictor input
+__device__ __forceinline__ void first_predictor_input(DevState *s, int n)
+{
+    if (s->d.ptype == kPredLstm) {
+        lstm_reset_lane(*s, n);
+        __syncthreads();                                      // the slot rows written above are read below
+        lstm_layer0_cell(*s, n, s->blank, n, s->d.NLp + n);
+    } else {
+        write_embedding_column(s, n, s->blank);
+    }
 }
 
 // wt[k][j] = sum_p wf[j][p] * wp[p][k]  (k-major, as lane_gemm reads it),  bias[j] = bf[j] + sum_p wf[j][p] * bp[p];
@@ -654,6 +789,35 @@ __global__ __launch_bounds__(kCtxThreads) void ctx_predictor_kernel(DevState *sp
     }
 }
 
+// Tail of the kernels that decide a lane's token: the commit (greedy_search copy.py:52 `cache = new_cache`) and the
+// next predictor input.  LSTM predictor: a commit swaps the lane's two slot numbers, and layer 0 of the predictor step
+// the emission causes is evaluated here (lstm_layer0_cell) from the committed slot; stateless predictors copy their token
+// history and leave the new token's embedding column for ctx_predictor_kernel.  `sc` / `sn`: the lane's slots as
+// loaded at the top of the kernel.
+__device__ __forceinline__ void commit_and_feed(const DevState &S, int n, bool feed, bool commit, int tok, int sc, int sn)
+{
+    const Dims &d = S.d;
+    const int tid = threadIdx.x;
+    if (d.ptype == kPredLstm) {
+        if (commit) {
+            const int t = sc; sc = sn; sn = t;
+            if (tid == 0) { S.comm_slot[n] = sc; S.new_slot[n] = sn; }
+        }
+        if (feed) lstm_layer0_cell(S, n, tok, sc, sn);
+        return;
+    }
+    if (feed) {
+        for (int q = tid; q < d.D; q += blockDim.x) S.xT[(size_t)q * d.NLp + n] = S.embed[(size_t)tok * d.D + q];
+    }
+    if (commit) {
+        for (int i = tid; i < d.L * d.Hp; i += blockDim.x) {
+            const size_t o = (size_t)i * d.NLp + n;
+            S.cache_hT[o] = S.new_hT[o];
+            S.cache_cT[o] = S.new_cT[o];
+        }
+    }
+}
+
 // ---------------------------------------------------------------- greedy --
 __global__ void greedy_init_kernel(DevState *s)
 {
@@ -676,7 +840,7 @@ __global__ void greedy_init_kernel(DevState *s)
         s->lane_active[n] = act;
         if (act) atomicAdd(s->active_count, 1);
     }
-    write_embedding_column(s, n, s->blank);
+    first_predictor_input(s, n);
 }
 
 // Streaming: start the next chunk of every stream with the state the previous chunk left behind
@@ -730,6 +894,7 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(DevState *sp)
     int nic = S.new_is_cache[n];
     const int len = S.hyp_lens[n];
     const int enc_len = S.enc_lens[n];
+    const int sc = S.comm_slot[n], sn = S.new_slot[n];     // LSTM predictor: state slots (unused otherwise)
     int gate_cur = 1, gb_flag = 0, gb_end = 0, last_t = 0, tlen = 0, gate_t0 = 1, gate_t1 = 1, last_gate = 1;
     if (HW) {
         gate_cur = S.cur_gate[n]; gb_flag = S.gb_flag[n]; gb_end = S.gb_end[n]; last_t = S.last_t[n];
@@ -856,16 +1021,7 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(DevState *sp)
             atomicSub(S.active_count, 1);
         }
     }
-    if (emit && !withdraw) {                       // next predictor input
-        for (int q = tid; q < d.D; q += 256) S.xT[(size_t)q * d.NLp + n] = S.embed[(size_t)k * d.D + q];
-    }
-    if (commit) {                                  // cache = new_cache (greedy_search copy.py:52)
-        for (int i = tid; i < d.L * d.Hp; i += 256) {
-            const size_t o = (size_t)i * d.NLp + n;
-            S.cache_hT[o] = S.new_hT[o];
-            S.cache_cT[o] = S.new_cT[o];
-        }
-    }
+    commit_and_feed(S, n, emit && !withdraw, commit, k, sc, sn);
     WR_STAMP(5);
     WR_STAMP_DRAIN();
     WR_STAMP(6);
@@ -931,6 +1087,7 @@ __global__ __launch_bounds__(256) void greedy_resolve_kernel(DevState *sp, int l
     int nic = S.new_is_cache[n];
     int len = S.hyp_lens[n];
     const int enc_len = S.enc_lens[n];
+    const int sc = S.comm_slot[n], sn = S.new_slot[n];
     int toks[kMaxLook];
 #pragma unroll
     for (int f = 0; f < kMaxLook; ++f) toks[f] = S.row_tok[(size_t)(f < look ? f : 0) * d.NLp + n];
@@ -974,16 +1131,7 @@ __global__ __launch_bounds__(256) void greedy_resolve_kernel(DevState *sp, int l
             atomicSub(S.active_count, 1);
         }
     }
-    if (emitted >= 0) {                            // next predictor input
-        for (int q = tid; q < d.D; q += 256) S.xT[(size_t)q * d.NLp + n] = S.embed[(size_t)emitted * d.D + q];
-    }
-    if (commit) {                                  // cache = new_cache (greedy_search copy.py:52)
-        for (int i = tid; i < d.L * d.Hp; i += 256) {
-            const size_t o = (size_t)i * d.NLp + n;
-            S.cache_hT[o] = S.new_hT[o];
-            S.cache_cT[o] = S.new_cT[o];
-        }
-    }
+    commit_and_feed(S, n, emitted >= 0, commit, emitted, sc, sn);
 }
 
 // ------------------------------------------------------- hot-word greedy --
@@ -1255,7 +1403,7 @@ __global__ void greedy_hw_init_kernel(DevState *s)
         if (act && s->trace_cap > 0) s->trace[(size_t)n * s->trace_cap] = gate;
         s->trace_len[n] = act ? 1 : 0;
     }
-    write_embedding_column(s, n, s->blank);
+    first_predictor_input(s, n);
 }
 
 // ------------------------------------------------------------------ beam --
@@ -1291,7 +1439,7 @@ __global__ void beam_init_kernel(DevState *s)
             s->bscores[(size_t)b * s->beam] = 0.0;
         }
     }
-    write_embedding_column(s, n, s->blank);
+    first_predictor_input(s, n);
 }
 
 // per lane: log-softmax, mixture with the CTC posterior of this frame, top-`beam`.  The row lives in registers
@@ -1547,6 +1695,34 @@ __global__ __launch_bounds__(256) void beam_update_kernel(DevState *sp)
             if (!e_blank[tid] && lb < S.Lmax) hy2[(size_t)tid * S.Lmax + lb] = e_tok[tid];
         }
     }
+    if (d.ptype == kPredLstm) {
+        // LSTM predictor: a survivor inherits a slot NUMBER -- its base hypothesis' committed slot for a blank extension,
+        // the slot of the base's new state for a label (:111-124; several survivors may share one) -- and gets a free slot
+        // of the utterance's 2 * beam for its own next step; then layer 0 of that step (lstm_layer0_cell).  Nothing is
+        // copied.  Slots of utterance b: lanes' numbers b * beam + j and NLp + b * beam + j.
+        __shared__ int s_comm[kMaxBeam], s_new[kMaxBeam];
+        if (tid == 0) {
+            unsigned used = 0;                                   // bit j: slot b*beam + j, bit beam + j: slot NLp + b*beam + j
+            for (int e = 0; e < keep; ++e) {
+                const int src = b * beam + e_src[e];
+                const int sl = e_blank[e] ? S.comm_slot[src] : S.new_slot[src];
+                s_comm[e] = sl;
+                used |= 1u << (sl >= d.NLp ? beam + (sl - d.NLp - b * beam) : sl - b * beam);
+            }
+            // every lane of the utterance, idle ones too, gets a free slot of its own: the recurrent-product jobs write
+            // pool_g[new_slot[n]] for all lanes and must never land in a slot that is in use
+            int bit = 0;
+            for (int e = 0; e < beam; ++e) {
+                while (used & (1u << bit)) ++bit;
+                s_new[e] = bit < beam ? b * beam + bit : d.NLp + b * beam + (bit - beam);
+                if (e >= keep) s_comm[e] = s_new[e];
+                ++bit;
+            }
+        }
+        __syncthreads();
+        if (tid < beam) { S.comm_slot[b * beam + tid] = s_comm[tid]; S.new_slot[b * beam + tid] = s_new[tid]; }
+        for (int e = 0; e < keep; ++e) lstm_layer0_cell(S, b * beam + e, e_last[e], s_comm[e], s_new[e]);
+    } else {
     // next predictor inputs
     {
         constexpr int UN = 4;
@@ -1599,6 +1775,7 @@ __global__ __launch_bounds__(256) void beam_update_kernel(DevState *sp)
                 }
             }
         }
+    }
     }
     if (tid < beam) {
         const int nfr = fr + 1;
@@ -1699,6 +1876,7 @@ size_t carve(const wr_transducer_weights *w, int max_lanes, int max_utt, int Tma
     Dims d;
     d.V = w->vocab_size; d.E = w->enc_dim; d.P = w->pred_dim; d.D = w->embed_dim; d.H = w->hidden; d.L = w->n_layers;
     d.J = w->join_dim;
+    d.Ve = w->embed_rows > 0 ? w->embed_rows : w->vocab_size;
     d.act = w->activation;
     d.ptype = w->predictor_type; d.ctx = w->context_size; d.heads = w->n_head; d.pact = w->pred_activation;
     d.ln_eps = w->ln_eps;
@@ -1714,8 +1892,7 @@ size_t carve(const wr_transducer_weights *w, int max_lanes, int max_utt, int Tma
     DevState *devp = c.take<DevState>(1);
     const size_t zero_begin = align_up(c.off, 256);       // everything from here to zero_end is zero-filled at create
     for (int l = 0; l < d.L && d.ptype == kPredLstm; ++l) {
-        const int in_p = l == 0 ? d.Dp : d.Hp;
-        s.wt_ih[l] = c.take<float>((size_t)in_p * d.G4p);
+        if (l > 0) s.wt_ih[l] = c.take<float>((size_t)d.Hp * d.G4p);     // layer 0's input product is the table `etab`
         s.wt_hh[l] = c.take<float>((size_t)d.Hp * d.G4p);
         s.bsum[l] = c.take<float>((size_t)d.G4p);
     }
@@ -1739,7 +1916,13 @@ size_t carve(const wr_transducer_weights *w, int max_lanes, int max_utt, int Tma
     s.new_hT = c.take<float>(cs); s.new_cT = c.take<float>(cs);
     s.outT = c.take<float>((size_t)d.Pp * d.NLp);
     s.ht = c.take<float>((size_t)d.Jp * kMaxLook * d.NLp);
+    s.comm_slot = c.take<int32_t>(d.NLp); s.new_slot = c.take<int32_t>(d.NLp);
+    if (d.ptype == kPredLstm) {
+        s.pool_c = c.take<float>((size_t)d.L * 2 * d.NLp * d.Hp);
+        s.pool_g = c.take<float>((size_t)d.L * 2 * d.NLp * d.G4p);
+    }
     const size_t zero_end = align_up(c.off, 256);
+    if (d.ptype == kPredLstm) s.etab = c.take<float>((size_t)d.Ve * d.G4p);
     s.ep_all = c.take<float>((size_t)max_utt * Tmax * d.J);
     s.token = c.take<int32_t>(d.NLp); s.lane_t = c.take<int32_t>(d.NLp); s.noblk = c.take<int32_t>(d.NLp);
     s.need_pred = c.take<int32_t>(d.NLp); s.lane_active = c.take<int32_t>(d.NLp);
@@ -1826,8 +2009,41 @@ void launch_gemm(const GemmArgs &g, int n_cols_padded, int n_lanes, hipStream_t 
     }
 }
 
-// predictor step (predicated per lane): L LSTM layers (cell fused) + projection
-void launch_predictor(wr_decoder *h, int n_lanes, hipStream_t st, bool with_projection = true)
+// two GEMMs over the same lanes in one launch (lane_gemm_pair_kernel)
+template <int EPI0, int EPI1>
+void launch_gemm_pair(const GemmArgs &g0, int cols0, const GemmArgs &g1, int cols1, int n_lanes, hipStream_t st)
+{
+    const int mt = (n_lanes + 31) / 32, ct0 = cols0 / 32, ct = ct0 + cols1 / 32;
+    const int policy = tune_get(kTuneLaneGemmTile);
+    if (mt == 1 || policy == 1 || (policy == 0 && ct * mt <= 256)) {
+        hipLaunchKernelGGL((lane_gemm_pair_kernel<1, EPI0, EPI1>), dim3(ct, mt), dim3(64 * kGemmWaves), 0, st, g0, g1, ct0);
+    } else {
+        hipLaunchKernelGGL((lane_gemm_pair_kernel<2, EPI0, EPI1>), dim3(ct, (mt + 1) / 2), dim3(64 * kGemmWaves), 0, st, g0, g1, ct0);
+    }
+}
+
+// pool_g[l][new_slot[n]] = W_hh_l . new_h_l[n] + b_l: the recurrent product of the state a lane's step has just produced,
+// for whichever later step starts from that state (see "LSTM predictor step").  Rides in the launch of the next stage.
+GemmArgs recurrent_job(const wr_decoder *h, int l, int n_lanes, const int32_t *slot_idx)
+{
+    const Dims &d = h->d;
+    const DevState &s = h->host;
+    GemmArgs g{};
+    g.A0 = s.new_hT + (size_t)l * d.Hp * d.NLp; g.B0 = s.wt_hh[l]; g.K0 = d.Hp;
+    g.lda = d.NLp; g.ldb = d.G4p; g.bias = s.bsum[l];
+    g.C = s.pool_g + (size_t)l * 2 * d.NLp * d.G4p; g.ldc = d.G4p; g.N = d.G4p; g.n_lanes = n_lanes;
+    g.slot_idx = slot_idx;
+#ifdef WR_STAMPS
+    g.dbg_slot = -1;
+#endif
+    return g;
+}
+
+// predictor step (predicated per lane).  LSTM: layer 0 was evaluated by the kernel that decided the token (or by the init
+// kernel); here layers 1 .. L-1, each one GEMM of depth H with the recurrent product of the layer below in the same
+// launch, and -- unless the caller folds it into pred_ffn -- the projection (with the last layer's recurrent product).
+// Returns true if the last layer's recurrent product is still to be launched (the caller pairs it with its next GEMM).
+bool launch_predictor(wr_decoder *h, int n_lanes, hipStream_t st, bool with_projection = true)
 {
     const Dims &d = h->d;
     const DevState &s = h->host;
@@ -1843,32 +2059,33 @@ void launch_predictor(wr_decoder *h, int n_lanes, hipStream_t st, bool with_proj
 #endif
         launch_gemm<kEpiKMajor>(g, up(d.D, 32), n_lanes, st);
         hipLaunchKernelGGL(ctx_predictor_kernel<1>, dim3(n_lanes), dim3(kCtxThreads), 0, st, h->dev);
-        return;
+        return false;
     }
     if (d.ptype == kPredConv) {
         hipLaunchKernelGGL(ctx_predictor_kernel<2>, dim3(n_lanes), dim3(kCtxThreads), 0, st, h->dev);
-        return;
+        return false;
     }
-    for (int l = 0; l < d.L; ++l) {
+    for (int l = 1; l < d.L; ++l) {
         GemmArgs g{};
-        g.A0 = l == 0 ? s.xT : s.new_hT + (size_t)(l - 1) * ls;  g.B0 = s.wt_ih[l];  g.K0 = l == 0 ? d.Dp : d.Hp;
-        g.A1 = s.cache_hT + (size_t)l * ls;                       g.B1 = s.wt_hh[l];  g.K1 = d.Hp;
-        g.lda = d.NLp; g.ldb = d.G4p; g.bias = s.bsum[l]; g.C = nullptr; g.ldc = d.NLp; g.N = d.G4p; g.n_lanes = n_lanes;
-        g.lane_active = s.lane_active; g.need_pred = s.need_pred; g.H = d.H;
-        g.cache_cT = s.cache_cT + (size_t)l * ls; g.new_cT = s.new_cT + (size_t)l * ls; g.new_hT = s.new_hT + (size_t)l * ls;
+        g.A0 = s.new_hT + (size_t)(l - 1) * ls; g.B0 = s.wt_ih[l]; g.K0 = d.Hp;
+        g.lda = d.NLp; g.ldb = d.G4p; g.N = d.G4p; g.n_lanes = n_lanes;
+        g.lane_active = s.lane_active; g.need_pred = s.need_pred; g.H = d.H; g.Hp = d.Hp; g.G4p = d.G4p;
+        g.pool_g = s.pool_g + (size_t)l * 2 * d.NLp * d.G4p; g.pool_c = s.pool_c + (size_t)l * 2 * d.NLp * d.Hp;
+        g.comm_slot = s.comm_slot; g.new_slot = s.new_slot; g.new_hT = s.new_hT + (size_t)l * ls;
 #ifdef WR_STAMPS
         g.dbg_slot = l < 2 ? l : -1;
 #endif
-        launch_gemm<kEpiLstmCell>(g, d.G4p, n_lanes, st);
+        launch_gemm_pair<kEpiLstmCell, kEpiSlotRow>(g, d.G4p, recurrent_job(h, l - 1, n_lanes, s.new_slot), d.G4p, n_lanes, st);
     }
-    if (!with_projection) return;                 // the caller applies the composed projection + pred_ffn
+    if (!with_projection) return true;            // the caller applies the composed projection + pred_ffn
     GemmArgs g{};
     g.A0 = s.new_hT + (size_t)(d.L - 1) * ls; g.B0 = s.proj_wt; g.K0 = d.Hp;
     g.lda = d.NLp; g.ldb = up(d.P, 32); g.bias = s.proj_b; g.C = s.outT; g.ldc = d.NLp; g.N = d.P; g.n_lanes = n_lanes;
 #ifdef WR_STAMPS
     g.dbg_slot = 8;
 #endif
-    launch_gemm<kEpiKMajor>(g, up(d.P, 32), n_lanes, st);
+    launch_gemm_pair<kEpiKMajor, kEpiSlotRow>(g, up(d.P, 32), recurrent_job(h, d.L - 1, n_lanes, s.new_slot), d.G4p, n_lanes, st);
+    return false;
 }
 
 void launch_predictor_and_joint(wr_decoder *h, int n_lanes, hipStream_t st, int look = 1, bool row_stats = false)
@@ -1879,7 +2096,7 @@ void launch_predictor_and_joint(wr_decoder *h, int n_lanes, hipStream_t st, int 
     // LSTM predictor: the projection is folded into pred_ffn (one launch less per micro-step; wr_tune_set(11, 1) keeps
     // them apart).  The hot-word search and wr_predictor_step need the projected output itself and keep the two stages.
     const bool fold = d.ptype == kPredLstm && tune_get(kTuneFoldProj) != 1;
-    launch_predictor(h, n_lanes, st, !fold);
+    const bool recurrent_pending = launch_predictor(h, n_lanes, st, !fold);
     {   // pred_ffn with the joiner activation as epilogue
         GemmArgs g{};
         if (fold) {
@@ -1893,7 +2110,10 @@ void launch_predictor_and_joint(wr_decoder *h, int n_lanes, hipStream_t st, int 
 #ifdef WR_STAMPS
         g.dbg_slot = 2;
 #endif
-        launch_gemm<kEpiJointAct>(g, up(d.J, 32), n_lanes, st);
+        if (recurrent_pending)
+            launch_gemm_pair<kEpiJointAct, kEpiSlotRow>(g, up(d.J, 32), recurrent_job(h, d.L - 1, n_lanes, s.new_slot), d.G4p, n_lanes, st);
+        else
+            launch_gemm<kEpiJointAct>(g, up(d.J, 32), n_lanes, st);
     }
     GemmArgs g{};
 #ifdef WR_STAMPS
@@ -1977,8 +2197,10 @@ extern "C" int wr_decoder_create(const wr_transducer_weights *w, int max_lanes, 
     s.conv_b = w->conv_b;
     if (d.ptype == kPredEmbedding) launch_transpose(w->ffn_w, d.D, d.D, up(d.D, 32), d.Dp, s.pffn_wt, st);
     for (int l = 0; l < d.L && d.ptype == kPredLstm; ++l) {
-        const int in_dim = l == 0 ? d.D : d.H, in_p = l == 0 ? d.Dp : d.Hp;
-        hipLaunchKernelGGL(lstm_weight_prep_kernel, dim3(256), dim3(256), 0, st, w->w_ih[l], d.H, d.Hp, in_dim, in_p, s.wt_ih[l]);
+        if (l > 0)
+            hipLaunchKernelGGL(lstm_weight_prep_kernel, dim3(256), dim3(256), 0, st, w->w_ih[l], d.H, d.Hp, d.H, d.Hp, s.wt_ih[l]);
+        else
+            hipLaunchKernelGGL(lstm_etab_kernel, dim3(2048), dim3(256), 0, st, w->embed, w->w_ih[0], d.Ve, d.D, d.H, d.Hp, s.etab);
         hipLaunchKernelGGL(lstm_weight_prep_kernel, dim3(256), dim3(256), 0, st, w->w_hh[l], d.H, d.Hp, d.H, d.Hp, s.wt_hh[l]);
         hipLaunchKernelGGL(lstm_bias_prep_kernel, dim3((d.G4p + 255) / 256), dim3(256), 0, st, w->b_ih[l], w->b_hh[l], d.H, d.Hp,
                            s.bsum[l]);
@@ -2289,8 +2511,30 @@ __global__ void step_setup_kernel(DevState *s, const int32_t *tokens, int N)
         s->need_pred[n] = on;
         s->lane_t[n] = 0;
         s->token[n] = tok;
+        s->comm_slot[n] = n;
+        s->new_slot[n] = s->d.NLp + n;
     }
-    write_embedding_column(s, n, tok);
+    if (s->d.ptype != kPredLstm) write_embedding_column(s, n, tok);
+}
+
+// LSTM step API: caller's cell state [L][N][H] -> the committed slots of the pool; the new slots' cell state -> caller
+__global__ void pool_c_import_kernel(DevState *s, const float *__restrict__ src, int N)
+{
+    const Dims &d = s->d;
+    const long total = (long)d.L * N * d.H;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % d.H), n = (int)((i / d.H) % N), l = (int)(i / ((long)d.H * N));
+        s->pool_c[((size_t)l * 2 * d.NLp + n) * d.Hp + k] = src[i];
+    }
+}
+__global__ void pool_c_export_kernel(DevState *s, float *__restrict__ dst, int N)
+{
+    const Dims &d = s->d;
+    const long total = (long)d.L * N * d.H;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % d.H), n = (int)((i / d.H) % N), l = (int)(i / ((long)d.H * N));
+        dst[i] = s->pool_c[((size_t)l * 2 * d.NLp + s->new_slot[n]) * d.Hp + k];
+    }
 }
 }  // namespace
 
@@ -2310,13 +2554,25 @@ extern "C" int wr_predictor_step(wr_decoder *h, const int32_t *tokens_d, const f
     s.n_utt = 1; s.T = 1; s.lanes_per_utt = d.NL; s.n_lanes = N; s.enc = nullptr; s.enc_lens = nullptr;
     if (int rc = upload_state(h, st)) return rc;
     hipLaunchKernelGGL(step_setup_kernel, dim3(d.NLp), dim3(64), 0, st, h->dev, tokens_d, N);
-    hipLaunchKernelGGL(cache_to_kmajor_kernel, dim3(64), dim3(256), 0, st, cache_h_d, N, d.L, d.H, d.Hp, d.NLp, s.cache_hT);
-    hipLaunchKernelGGL(cache_to_kmajor_kernel, dim3(64), dim3(256), 0, st, cache_c_d, N, d.L, d.H, d.Hp, d.NLp, s.cache_cT);
+    if (d.ptype == kPredLstm) {
+        // the caller's state becomes the lanes' committed slots: cell states as they are, hidden states through their
+        // recurrent products (pool_g = W_hh . h + b, one GEMM per layer); then layer 0, layers >= 1, projection
+        hipLaunchKernelGGL(cache_to_kmajor_kernel, dim3(64), dim3(256), 0, st, cache_h_d, N, d.L, d.H, d.Hp, d.NLp, s.new_hT);
+        hipLaunchKernelGGL(pool_c_import_kernel, dim3(64), dim3(256), 0, st, h->dev, cache_c_d, N);
+        for (int l = 0; l < d.L; ++l) launch_gemm<kEpiSlotRow>(recurrent_job(h, l, N, s.comm_slot), d.G4p, N, st);
+        hipLaunchKernelGGL(lstm_layer0_kernel, dim3(N), dim3(256), 0, st, h->dev);
+    } else {
+        hipLaunchKernelGGL(cache_to_kmajor_kernel, dim3(64), dim3(256), 0, st, cache_h_d, N, d.L, d.H, d.Hp, d.NLp, s.cache_hT);
+        hipLaunchKernelGGL(cache_to_kmajor_kernel, dim3(64), dim3(256), 0, st, cache_c_d, N, d.L, d.H, d.Hp, d.NLp, s.cache_cT);
+    }
     launch_predictor(h, N, st);
     // outT [Pp][NLp] -> out [N][P]: the same index map with L = 1
     hipLaunchKernelGGL(cache_from_kmajor_kernel, dim3(32), dim3(256), 0, st, s.outT, N, 1, d.P, d.Pp, d.NLp, out_d);
     hipLaunchKernelGGL(cache_from_kmajor_kernel, dim3(64), dim3(256), 0, st, s.new_hT, N, d.L, d.H, d.Hp, d.NLp, new_h_d);
-    hipLaunchKernelGGL(cache_from_kmajor_kernel, dim3(64), dim3(256), 0, st, s.new_cT, N, d.L, d.H, d.Hp, d.NLp, new_c_d);
+    if (d.ptype == kPredLstm)
+        hipLaunchKernelGGL(pool_c_export_kernel, dim3(64), dim3(256), 0, st, h->dev, new_c_d, N);
+    else
+        hipLaunchKernelGGL(cache_from_kmajor_kernel, dim3(64), dim3(256), 0, st, s.new_cT, N, d.L, d.H, d.Hp, d.NLp, new_c_d);
     WR_CHECK_LAUNCH("predictor_step");
     scope.ok();
     return WR_OK;

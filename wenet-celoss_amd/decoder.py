@@ -87,6 +87,7 @@ class DeviceDecoder:
         w.join_dim = joint.ffn_out.weight.shape[1]
         w.activation = _joint_activation_code(joint)
         w.embed = hold(predictor.embed.weight)
+        w.embed_rows = predictor.embed.weight.shape[0]
         w.predictor_type = kind
         if kind == 0:
             w.pred_dim = predictor.projection.weight.shape[0]
