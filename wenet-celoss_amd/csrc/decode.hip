@@ -194,6 +194,16 @@ struct GemmArgs {
 #endif
 };
 
+// Handle-constant pointers of the per-lane state, passed to the deciding kernels BY VALUE: the kernel-argument segment
+// is in the scalar registers within 0.06 us of the wave's start, so the lane's flags, slots and row records are requested
+// at once instead of behind the load of the state block (one memory round trip, ~0.5 us, off the critical path of every
+// micro-step).  Everything that changes from call to call (buffers of the caller, T, n_steps ...) stays in DevState.
+struct LaneArgs {
+    int32_t *lane_active, *lane_t, *noblk, *need_pred, *new_is_cache, *comm_slot, *new_slot;
+    const float4 *row_part;
+    int n_cb, V;
+};
+
 enum GemmEpilogue { kEpiKMajor = 0, kEpiRowMajor = 1, kEpiLstmCell = 2, kEpiJointAct = 3, kEpiRowStats = 4, kEpiSlotRow = 5 };
 
 // ----------------------------------------------------------------- setup --
@@ -329,22 +339,57 @@ __device__ __forceinline__ void lane_gemm_body(const GemmArgs &g, const int bx, 
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][i], bv[i], acc[m], 0, 0, 0);
     };
+    // Loads in three groups.  (1) The few per-lane indices that later loads depend on (state slots, flags, the lane's
+    // frame) go out FIRST, so that they come back with the operands; (2) the first two operand chunks; (3) behind them
+    // the epilogue operands (bias, pool rows, enc_ffn rows), whose addresses need (1): by then (1) has long arrived, and
+    // (3) is consumed only after the K loop.  (Round 2 issued (1) after (2) and paid a second memory round trip.)
+    constexpr int kItems = MT * 1024 / NT;                                // outputs per thread of the 32 x 32*MT tile
+    float bias_v[kItems > 4 ? kItems : 4];
+    bool cell_on = false, cell_in = false;
+    int cell_j = 0, cell_n = 0, cell_unit = 0, cell_sn = 0, cell_sc = 0, cell_la = 0, cell_np = 0;
+    float cell_c = 0.f, cell_g[4];
+    int slot_v[kItems];
+    bool act_on[kItems], act_in[kItems];
+    int act_la[kItems], act_tt[kItems], act_gate[kItems];
+    float act_ep[kMaxLook][kItems];
+    int act_T = 1, act_lpu = 1;
+    if (EPI == kEpiLstmCell) {
+        const int q = tid & 255;
+        cell_j = q >> 5;
+        cell_n = lane0 + ((tid >> 8) % MT) * 32 + l31;
+        cell_unit = (n0 >> 5) * 8 + cell_j;
+        cell_in = tid < MT * 256 && cell_n < g.n_lanes && cell_unit < g.H;
+        const int nn = cell_in ? cell_n : 0;
+        cell_la = g.lane_active[nn]; cell_np = g.need_pred[nn];
+        cell_sc = g.comm_slot[nn];
+        cell_sn = g.new_slot[nn];
+    } else if (EPI == kEpiSlotRow) {
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            const int i = tid + it * NT;
+            const int n = lane0 + (i >> 10) * 32 + ((i & 1023) >> 5);
+            slot_v[it] = g.slot_idx[n < g.n_lanes ? n : 0];
+        }
+    } else if (EPI == kEpiJointAct) {
+        act_T = g.st->T; act_lpu = g.st->lanes_per_utt;
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            const int i = tid + it * NT;
+            const int v = n0 + ((i & 1023) >> 5), n = lane0 + (i >> 10) * 32 + (i & 31);
+            act_in[it] = n < g.n_lanes && v < g.N;
+            const int nn = act_in[it] ? n : 0;
+            act_la[it] = g.lane_active[nn];
+            act_tt[it] = g.lane_t[nn];
+            act_gate[it] = g.ep_gate ? g.ep_gate[nn] : 0;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     float pb[CH], pa[MT][CH], qb[CH], qa[MT][CH];
     load_chunk(0, pb, pa);
     load_chunk(nch > 1 ? 1 : 0, qb, qa);
     __builtin_amdgcn_sched_barrier(0);
 
-    // Epilogue operands that do not depend on the GEMM are requested right behind the first two chunks (memory
-    // returns in order, so they must not sit in front of them) and are consumed after the K loop.
-    constexpr int kItems = MT * 1024 / NT;                                // outputs per thread of the 32 x 32*MT tile
-    float bias_v[kItems > 4 ? kItems : 4];
-    bool cell_on = false;
-    int cell_j = 0, cell_n = 0, cell_unit = 0, cell_sn = 0;
-    float cell_c = 0.f, cell_g[4];
-    int slot_v[kItems];
-    bool act_on[kItems];
-    float act_ep[kMaxLook][kItems];
-    if (EPI == kEpiRowMajor || EPI == kEpiRowStats) {
+    if (EPI == kEpiRowMajor || EPI == kEpiRowStats || EPI == kEpiSlotRow) {
         const int v = n0 + l31;                                          // the column of every item of this thread
         bias_v[0] = g.bias ? g.bias[v < g.N ? v : g.N - 1] : 0.f;
     } else if (EPI == kEpiKMajor || EPI == kEpiJointAct) {
@@ -356,49 +401,23 @@ __device__ __forceinline__ void lane_gemm_body(const GemmArgs &g, const int bx, 
     }
     if (EPI == kEpiLstmCell) {
         // gates = (W_ih . h_below: this GEMM) + (W_hh . h + b: pool_g of the lane's committed slot); one (lane, unit) per thread
-        const int q = tid & 255;
-        cell_j = q >> 5;
-        cell_n = lane0 + ((tid >> 8) % MT) * 32 + l31;
-        cell_unit = (n0 >> 5) * 8 + cell_j;
-        const bool in = tid < MT * 256 && cell_n < g.n_lanes && cell_unit < g.H;
-        const int nn = in ? cell_n : 0;
-        const int la = g.lane_active[nn], np = g.need_pred[nn];
-        const int sc = g.comm_slot[nn];
-        cell_sn = g.new_slot[nn];
-        const float *__restrict__ gp = g.pool_g + (size_t)sc * g.G4p + n0 + cell_j;
+        const float *__restrict__ gp = g.pool_g + (size_t)cell_sc * g.G4p + n0 + cell_j;
 #pragma unroll
         for (int gt = 0; gt < 4; ++gt) cell_g[gt] = gp[gt * 8];
-        cell_c = g.pool_c[(size_t)sc * g.Hp + (in ? cell_unit : 0)];
-        cell_on = in && la && np;
-    } else if (EPI == kEpiSlotRow) {
-        const int v = n0 + l31;
-        bias_v[0] = g.bias ? g.bias[v < g.N ? v : g.N - 1] : 0.f;
-#pragma unroll
-        for (int it = 0; it < kItems; ++it) {
-            const int i = tid + it * NT;
-            const int n = lane0 + (i >> 10) * 32 + ((i & 1023) >> 5);
-            slot_v[it] = g.slot_idx[n < g.n_lanes ? n : 0];
-        }
+        cell_c = g.pool_c[(size_t)cell_sc * g.Hp + (cell_in ? cell_unit : 0)];
+        cell_on = cell_in && cell_la && cell_np;
     } else if (EPI == kEpiJointAct) {
-        const int T = g.st->T, lpu = g.st->lanes_per_utt;
-        int tt[kItems];
 #pragma unroll
-        for (int it = 0; it < kItems; ++it) {
-            const int i = tid + it * NT;
-            const int v = n0 + ((i & 1023) >> 5), n = lane0 + (i >> 10) * 32 + (i & 31);
-            const bool in = n < g.n_lanes && v < g.N;
-            act_on[it] = in && g.lane_active[in ? n : 0];
-            tt[it] = g.lane_t[in ? n : 0];
-        }
+        for (int it = 0; it < kItems; ++it) act_on[it] = act_in[it] && act_la[it];
 #pragma unroll
         for (int f = 0; f < kMaxLook; ++f)
 #pragma unroll
             for (int it = 0; it < kItems; ++it) {
                 const int i = tid + it * NT;
                 const int v = n0 + ((i & 1023) >> 5), n = lane0 + (i >> 10) * 32 + (i & 31);
-                const int t = tt[it] + f < T ? tt[it] + f : T - 1;
-                const size_t sel = g.ep_gate ? (size_t)g.ep_gate[act_on[it] ? n : 0] * g.ep_gate_stride : 0;
-                act_ep[f][it] = (act_on[it] && f < g.look) ? g.ep_all[sel + ((size_t)(n / lpu) * T + t) * g.J + v] : 0.f;
+                const int t = act_tt[it] + f < act_T ? act_tt[it] + f : act_T - 1;
+                const size_t sel = (size_t)(act_on[it] ? act_gate[it] : 0) * g.ep_gate_stride;
+                act_ep[f][it] = (act_on[it] && f < g.look) ? g.ep_all[sel + ((size_t)(n / act_lpu) * act_T + t) * g.J + v] : 0.f;
             }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -875,26 +894,41 @@ __global__ void greedy_chunk_init_kernel(DevState *s, int ref_new_cache)
 // the emission this kernel has just decided on (the reference pops the last token, predictor output, cache and
 // input and steps the predictor again from the popped state), so it costs nothing to undo: the token is not
 // appended, the cache not committed, the next input not replaced.
-template <bool HW>
-__global__ __launch_bounds__(256) void greedy_update_kernel(DevState *sp)
+template <bool HW, int PP>
+__global__ __launch_bounds__(256) void greedy_update_kernel(DevState *sp, LaneArgs a)
 {
-    __shared__ float sv[4];
-    __shared__ int si[4];
     WR_STAMP_DECL;
     WR_STAMP_RT(7);
     WR_STAMP(0);
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    // no branch before the loads: everything this lane needs is requested in one batch, the per-lane state through the
+    // kernel-argument pointers (no dependence on the state block), idle lanes leave after the first reduction
+    const int act = a.lane_active[n];
+    int t = a.lane_t[n], nb = a.noblk[n];
+    const int need = a.need_pred[n];
+    int nic = a.new_is_cache[n];
+    const int sc = a.comm_slot[n], sn = a.new_slot[n];     // LSTM predictor: state slots (unused otherwise)
+    // The row is resolved from the per-block records the ffn_out epilogue left (kEpiRowStats): {block max, sum of
+    // exp(x - block max), runner-up, first index of the block max} for every 32 columns -- V / 32 records instead of V
+    // logits.  log_softmax as the reference evaluates it, lp = (x - max) - log(sum(exp(x - max))), and its argmax with
+    // the first index on ties: lp is a monotone function of x, so the maximum of lp is (max - max) - ls and the
+    // winner is the first column whose lp equals it.  A block takes part if its maximum does; if its runner-up does too
+    // (two logits that lp cannot tell apart: they differ by less than half an ulp of ls), its 32 logits are re-read and
+    // scanned in order -- otherwise the recorded first index is the answer.
+    // Every WAVE resolves the row on its own from all the records (PP per lane; they are a few KB and come from L2 once
+    // per CU): the three reductions are register butterflies, no LDS and no workgroup barrier on the way to the token.
+    const float4 *__restrict__ rp = a.row_part + (size_t)n * a.n_cb;
+    const int ncb = (a.V + 31) / 32;
+    float4 rec[PP];
+#pragma unroll
+    for (int i = 0; i < PP; ++i) {
+        const int bq = lane + i * 64;
+        rec[i] = rp[bq < ncb ? bq : ncb - 1];
+    }
     const DevState S = *sp;                         // by value: no reloads of the pointers after the stores below
     const Dims &d = S.d;
-    const int n = blockIdx.x, tid = threadIdx.x;
-    // no branch before the loads: everything this lane needs is requested in one batch (idle lanes leave after
-    // the first reduction)
-    const int act = S.lane_active[n];
-    int t = S.lane_t[n], nb = S.noblk[n];
-    const int need = S.need_pred[n];
-    int nic = S.new_is_cache[n];
     const int len = S.hyp_lens[n];
     const int enc_len = S.enc_lens[n];
-    const int sc = S.comm_slot[n], sn = S.new_slot[n];     // LSTM predictor: state slots (unused otherwise)
     int gate_cur = 1, gb_flag = 0, gb_end = 0, last_t = 0, tlen = 0, gate_t0 = 1, gate_t1 = 1, last_gate = 1;
     if (HW) {
         gate_cur = S.cur_gate[n]; gb_flag = S.gb_flag[n]; gb_end = S.gb_end[n]; last_t = S.last_t[n];
@@ -904,39 +938,22 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(DevState *sp)
         gate_t1 = S.gate_tab[(size_t)n * S.T + tn];
         last_gate = S.trace[(size_t)n * S.trace_cap + (tlen > 0 ? (tlen <= S.trace_cap ? tlen - 1 : S.trace_cap - 1) : 0)];
     }
-    // The row is resolved from the per-block records the ffn_out epilogue left (kEpiRowStats): {block max, sum of
-    // exp(x - block max), runner-up, first index of the block max} for every 32 columns -- V / 32 records instead of V
-    // logits.  log_softmax as the reference evaluates it, lp = (x - max) - log(sum(exp(x - max))), and its argmax with
-    // the first index on ties: lp is a monotone function of x, so the maximum of lp is (max - max) - ls and the
-    // winner is the first column whose lp equals it.  A block takes part if its maximum does; if its runner-up does too
-    // (two logits that lp cannot tell apart: they differ by less than half an ulp of ls), its 32 logits are re-read and
-    // scanned in order -- otherwise the recorded first index is the answer.
-    constexpr int PP = 2;                            // records per thread: V <= 16384 -> at most 512 blocks
-    const float4 *__restrict__ rp = S.row_part + (size_t)n * S.n_cb;
-    const int ncb = (d.V + 31) / 32;
-    float4 rec[PP];
-#pragma unroll
-    for (int i = 0; i < PP; ++i) {
-        const int bq = tid + i * 256;
-        rec[i] = rp[bq < ncb ? bq : ncb - 1];
-    }
     float m = -3.0e38f;
 #pragma unroll
-    for (int i = 0; i < PP; ++i) m = fmaxf(m, (tid + i * 256 < ncb) ? rec[i].x : -3.0e38f);
-    m = block_max(m, sv);
+    for (int i = 0; i < PP; ++i) m = fmaxf(m, (lane + i * 64 < ncb) ? rec[i].x : -3.0e38f);
+    m = wave_allmax_dpp(m);
     WR_STAMP(1);                                   // state and records arrived, first reduction done
     if (!act) return;
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < PP; ++i) sum += (tid + i * 256 < ncb) ? rec[i].y * expf(rec[i].x - m) : 0.f;
-    sum = block_sum(sum, sv);
+    for (int i = 0; i < PP; ++i) sum += (lane + i * 64 < ncb) ? rec[i].y * expf(rec[i].x - m) : 0.f;
+    sum = wave_allsum_dpp(sum);
     const float ls = logf(sum);
     const float top = (m - m) - ls;                 // log-probability of the maximum, exactly as the elementwise formula gives it
-    float best = 0.f;
     int bi = 0x7fffffff;
 #pragma unroll
     for (int i = 0; i < PP; ++i) {
-        const int bq = tid + i * 256;
+        const int bq = lane + i * 64;
         if (bq >= ncb) continue;
         if (((rec[i].x - m) - ls) != top) continue;
         int idx = __builtin_bit_cast(int, rec[i].w);
@@ -948,9 +965,9 @@ __global__ __launch_bounds__(256) void greedy_update_kernel(DevState *sp)
                 if (v < d.V && ((x[v] - m) - ls) == top) idx = v;
             }
         }
-        if (idx < bi) { best = 1.f; bi = idx; }
+        if (idx < bi) bi = idx;
     }
-    block_argmax(best, bi, sv, si);
+    bi = wave_allmin_dpp(bi);
     WR_STAMP(2);                                   // token decided
     const int k = bi;
     const bool emit = (k != S.blank);
@@ -2272,12 +2289,32 @@ int upload_state(wr_decoder *h, hipStream_t st)
     return WR_OK;
 }
 
+LaneArgs lane_args(const wr_decoder *h)
+{
+    const DevState &s = h->host;
+    LaneArgs a;
+    a.lane_active = s.lane_active; a.lane_t = s.lane_t; a.noblk = s.noblk; a.need_pred = s.need_pred;
+    a.new_is_cache = s.new_is_cache; a.comm_slot = s.comm_slot; a.new_slot = s.new_slot;
+    a.row_part = s.row_part; a.n_cb = s.n_cb; a.V = h->d.V;
+    return a;
+}
+
+template <bool HW>
+void launch_greedy_update(wr_decoder *h, int n_lanes, hipStream_t st)
+{
+    const LaneArgs a = lane_args(h);
+    if ((h->d.V + 31) / 32 <= 3 * 64)              // records per lane of a wave: V <= 6144 -> 3, else 8 (V <= 16384)
+        hipLaunchKernelGGL((greedy_update_kernel<HW, 3>), dim3(n_lanes), dim3(256), 0, st, h->dev, a);
+    else
+        hipLaunchKernelGGL((greedy_update_kernel<HW, 8>), dim3(n_lanes), dim3(256), 0, st, h->dev, a);
+}
+
 void greedy_micro_step(wr_decoder *h, int n_lanes, hipStream_t st, int look)
 {
     launch_predictor_and_joint(h, n_lanes, st, look, look == 1);
     const int V = h->d.V;                           // <= 16384 (check_weights)
     if (look == 1) {
-        hipLaunchKernelGGL((greedy_update_kernel<false>), dim3(n_lanes), dim3(256), 0, st, h->dev);
+        launch_greedy_update<false>(h, n_lanes, st);
         return;
     }
     const dim3 grid(n_lanes, look);
@@ -2651,7 +2688,7 @@ void hw_micro_step(wr_decoder *h, int n_lanes, hipStream_t st)
     g.lda = kMaxLook * d.NLp; g.ldb = d.Vp; g.bias = s.out_b; g.C = s.logits; g.ldc = d.V; g.N = d.V; g.n_lanes = n_lanes;
     g.row_part = s.row_part; g.row_part_ld = s.n_cb;
     launch_gemm<kEpiRowStats>(g, d.Vp, n_lanes, st);
-    hipLaunchKernelGGL((greedy_update_kernel<true>), dim3(n_lanes), dim3(256), 0, st, h->dev);
+    launch_greedy_update<true>(h, n_lanes, st);
 }
 
 }  // namespace

@@ -194,6 +194,23 @@ __device__ __forceinline__ float wave_allmax_dpp(float v)
     const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
     return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
+// sum over the wave, the same value in every lane: butterflies inside the rows of 16 (both partners add the same two
+// numbers, a + b == b + a), then the four row sums in a fixed order
+__device__ __forceinline__ float wave_allsum_dpp(float v)
+{
+#define WR_DPP_F(x, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, false))
+    v += WR_DPP_F(v, 0xB1);
+    v += WR_DPP_F(v, 0x4E);
+    v += WR_DPP_F(v, 0x141);
+    v += WR_DPP_F(v, 0x140);
+#undef WR_DPP_F
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
+}
 __device__ __forceinline__ int wave_allmin_dpp(int v)
 {
 #define WR_DPP_I(x, ctrl) __builtin_amdgcn_update_dpp(0, x, ctrl, 0xf, 0xf, false)
