@@ -36,7 +36,7 @@ NAMES = {0: "lstm_l0 (lane_gemm LstmCell)", 1: "lstm_l1 (lane_gemm LstmCell)", 2
 GEMM_PHASES = [("kernarg", 0, 9), ("issue", 0, 1), ("first", 1, 2), ("mfma", 2, 3), ("barrier", 3, 4), ("epilogue", 4, 5), ("drain", 5, 6)]
 UPD_PHASES = [("loads+max", 0, 1), ("decide", 1, 2), ("state+copies", 2, 5), ("drain", 5, 6)]
 TOPK_PHASES = [("loads+max", 0, 1), ("sum", 1, 2), ("select", 2, 3), ("barrier", 3, 4), ("merge", 4, 5), ("drain", 5, 6)]
-BUPD_PHASES = [("candidates", 0, 1), ("classes", 1, 2), ("fuse+rank", 2, 3), ("hyps+inputs", 3, 4), ("caches", 4, 5), ("drain", 5, 6)]
+BUPD_PHASES = [("candidates", 0, 1), ("classes", 1, 2), ("fuse", 2, 9), ("rank+prune", 9, 3), ("hyps", 3, 4), ("state (slots + layer 0 | inputs + caches)", 4, 5), ("drain", 5, 6)]
 
 
 def build(level: int) -> str:

@@ -290,8 +290,12 @@ __global__ void lstm_bias_prep_kernel(const float *__restrict__ b_ih, const floa
 // memory latency.  Loads are unconditional (clamped rows, masked by a 0/1 factor) so the waits stay counted.
 // Epilogues: k-major store, row-major store (logits), LSTM cell (gate columns are permuted at create time so a
 // 32-column tile holds i,f,g,o of 8 hidden units), joiner activation tanh(enc_ffn(enc)[t] + pred_ffn(pred)).
+// VW ("virtual waves" per wave): with VW = 2 a workgroup has 4 waves (256 threads) and every wave works through two of
+// the eight K slices one after the other, each into accumulators of its own -- the same eight partial tiles, summed in the
+// same order, so the results are BIT-IDENTICAL to the 8-wave form, but four workgroups fit a CU instead of two (the
+// 640-workgroup joiner GEMM of a 128-lane beam search then runs in one round instead of two).
 constexpr int kGemmWaves = 8;
-template <int MT, int EPI>
+template <int MT, int EPI, int VW = 1>
 __device__ __forceinline__ void lane_gemm_body(const GemmArgs &g, const int bx, float (&red)[kGemmWaves][MT][32 * 32])
 {
     WR_STAMP_DECL;
@@ -299,13 +303,10 @@ __device__ __forceinline__ void lane_gemm_body(const GemmArgs &g, const int bx, 
     WR_STAMP(0);
     const int n0 = bx * 32;
     const int lane0 = blockIdx.y * (32 * MT);                          // first decode lane of this workgroup
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave_phys = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    constexpr int CH = 16;
-    constexpr int NT = 64 * kGemmWaves;
-    f32x16 acc[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = (f32x16){0};
+    constexpr int CH = (VW == 2 || MT >= 4) ? 8 : 16;                   // k-pairs per chunk (NBUF chunks in flight)
+    constexpr int NT = 64 * kGemmWaves / VW;
 #ifdef WR_STAMPS
     asm volatile("" ::"s"(g.K0), "s"(g.ldb));      // the kernel-argument segment has arrived
     WR_STAMP(9);
@@ -313,31 +314,45 @@ __device__ __forceinline__ void lane_gemm_body(const GemmArgs &g, const int bx, 
     const int kq0 = g.K0 / kGemmWaves, kq1 = (g.A1 != nullptr) ? g.K1 / kGemmWaves : 0;
     const int nch0 = (kq0 + 2 * CH - 1) / (2 * CH), nch1 = (kq1 + 2 * CH - 1) / (2 * CH);
     const int nch = nch0 + nch1;
+    int wave = wave_phys * VW;                                          // the K slice being worked on
+    f32x16 acc[MT];
 
-    auto load_chunk = [&](int ci, float (&bv)[CH], float (&av)[MT][CH]) {
+    auto load_chunk = [&](int ci, float (&bv)[CH], float (&av)[MT][CH], int slice_ahead = 0) {
         const bool s1 = ci >= nch0;
         const int cj = s1 ? ci - nch0 : ci;
         const int kq = s1 ? kq1 : kq0;
         const float *__restrict__ As = s1 ? g.A1 : g.A0;
         const float *__restrict__ Bs = s1 ? g.B1 : g.B0;
-        const int kb = wave * kq;
+        const int kb = (wave + slice_ahead) * kq;
         const float *__restrict__ A = As + (size_t)(kb + half) * g.lda + lane0 + l31;
         const float *__restrict__ Bm = Bs + (size_t)(kb + half) * g.ldb + n0 + l31;
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int k = cj * 2 * CH + 2 * i;
             const int kc = k < kq ? k : kq - 2;                         // K >= 16: kq - 2 is a valid row pair
-            const float keep = k < kq ? 1.f : 0.f;
-            bv[i] = Bm[(size_t)kc * g.ldb] * keep;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) av[m][i] = A[(size_t)kc * g.lda + m * 32];
+            bv[i] = Bm[(size_t)kc * g.ldb];                             // nothing consumes the value here: the load stays
+#pragma unroll                                                          // in flight until its MFMA (round 2 multiplied by a
+            for (int m = 0; m < MT; ++m) av[m][i] = A[(size_t)kc * g.lda + m * 32];   // 0/1 mask here and so WAITED here)
         }
     };
-    auto mfma_chunk = [&](const float (&bv)[CH], const float (&av)[MT][CH]) {
+    // chunk `ci`: its k-pairs beyond the slice's end (only when the slice is not a multiple of the chunk) are masked
+    // at use; the test is wave-uniform and false for the shipped sizes
+    auto mfma_chunk = [&](int ci, const float (&bv)[CH], const float (&av)[MT][CH]) {
+        const bool s1 = ci >= nch0;
+        const int valid = (s1 ? kq1 : kq0) - (s1 ? ci - nch0 : ci) * 2 * CH;   // k rows of this chunk inside the slice
+        if (valid >= 2 * CH) {
 #pragma unroll
-        for (int i = 0; i < CH; ++i)
+            for (int i = 0; i < CH; ++i)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][i], bv[i], acc[m], 0, 0, 0);
+                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][i], bv[i], acc[m], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const float b = 2 * i < valid ? bv[i] : 0.f;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][i], b, acc[m], 0, 0, 0);
+            }
+        }
     };
     // Loads in three groups.  (1) The few per-lane indices that later loads depend on (state slots, flags, the lane's
     // frame) go out FIRST, so that they come back with the operands; (2) the first two operand chunks; (3) behind them
@@ -384,9 +399,23 @@ __device__ __forceinline__ void lane_gemm_body(const GemmArgs &g, const int bx, 
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    float pb[CH], pa[MT][CH], qb[CH], qa[MT][CH];
-    load_chunk(0, pb, pa);
-    load_chunk(nch > 1 ? 1 : 0, qb, qa);
+    // The wave works through its VW slices one after the other as ONE sequence of chunks with NBUF chunk buffers in
+    // flight (a ring: the MFMAs of chunk c are followed by the request for chunk c + NBUF, across slice boundaries too);
+    // at the end of a slice the accumulators go to LDS and start again from zero.  What bounds these kernels is how
+    // many loads a CU has in flight (~2 us of memory latency): two buffers for the 8- and 4-wave forms, four where a
+    // wave is alone on its SIMD (VW >= 4).
+    constexpr int NBUF = VW >= 4 ? 4 : 2;
+    float bb[NBUF][CH], ba[NBUF][MT][CH];
+    const int n_chunks = VW * nch;
+    int ld_cc = 0, ld_slice = 0;                                        // next chunk to request: (slice, chunk in slice)
+    auto request = [&](float (&bv)[CH], float (&av)[MT][CH]) {
+        wave = wave_phys * VW + ld_slice;
+        load_chunk(ld_cc, bv, av);
+        const bool last = ld_slice == VW - 1 && ld_cc == nch - 1;       // past the end: the last chunk again (counted waits)
+        if (!last) { if (++ld_cc == nch) { ld_cc = 0; ++ld_slice; } }
+    };
+#pragma unroll
+    for (int j = 0; j < NBUF; ++j) request(bb[j], ba[j]);
     __builtin_amdgcn_sched_barrier(0);
 
     if (EPI == kEpiRowMajor || EPI == kEpiRowStats || EPI == kEpiSlotRow) {
@@ -427,28 +456,40 @@ __device__ __forceinline__ void lane_gemm_body(const GemmArgs &g, const int bx, 
     WR_STAMP(2);
 #endif
 
-    for (int ci = 0;; ci += 2) {
-        mfma_chunk(pb, pa);
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = (f32x16){0};
+    int mm_cc = 0, mm_slice = 0;
+    for (int c0 = 0; c0 < n_chunks; c0 += NBUF) {
+#pragma unroll
+        for (int j = 0; j < NBUF; ++j) {
+            if (c0 + j < n_chunks) {
+                mfma_chunk(mm_cc, bb[j], ba[j]);
+                __builtin_amdgcn_sched_barrier(0);
 #if defined(WR_STAMPS) && WR_STAMPS < 2
-        if (ci == 0) WR_STAMP(2);                  // first chunk's operands arrived and its MFMAs issued
+                if (c0 + j == 0) WR_STAMP(2);      // first chunk's operands arrived and its MFMAs issued
 #endif
-        if (ci + 1 >= nch) break;
-        load_chunk(ci + 2 < nch ? ci + 2 : ci + 1, pb, pa);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_chunk(qb, qa);
-        __builtin_amdgcn_sched_barrier(0);
-        if (ci + 2 >= nch) break;
-        load_chunk(ci + 3 < nch ? ci + 3 : ci + 2, qb, qa);
-        __builtin_amdgcn_sched_barrier(0);
-    }
+                if (mm_cc == nch - 1) {            // slice complete: its partial tile to LDS
+                    const int wslice = wave_phys * VW + mm_slice;
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+                    for (int m = 0; m < MT; ++m) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;       // C/D layout of the 32x32 MFMA
-            red[wave][m][row * 32 + (l31 ^ row)] = acc[m][r];      // XOR swizzle: both epilogue orders are conflict-free
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;       // C/D layout of the 32x32 MFMA
+                            red[wslice][m][row * 32 + (l31 ^ row)] = acc[m][r];    // XOR swizzle: both epilogue orders are conflict-free
+                        }
+                        acc[m] = (f32x16){0};
+                    }
+                    mm_cc = 0; ++mm_slice;
+                } else {
+                    ++mm_cc;
+                }
+                if (c0 + j + NBUF < n_chunks) {
+                    request(bb[j], ba[j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
+    }
     WR_STAMP(3);                                   // MFMAs retired (accumulators read), partial tiles on their way to LDS
     __syncthreads();
     WR_STAMP(4);
@@ -545,6 +586,25 @@ __global__ __launch_bounds__(64 * kGemmWaves) void lane_gemm_kernel(GemmArgs g)
 {
     __shared__ float red[kGemmWaves][MT][32 * 32];
     lane_gemm_body<MT, EPI>(g, blockIdx.x, red);
+}
+
+// the 1-wave form (VW = 8): ONE wave works through all eight K slices of a 32 x 32 tile.  For the 640 tiles of a 128-lane
+// beam search's joiner GEMM this is the fastest shape: 640 independent waves on the chip's 1024 SIMDs, no barrier, each
+// MFMA-bound for K / 2 * 64 cycles (7 us at K = 512) with its loads hidden behind them, where the 8-wave form needs two
+// rounds of workgroups (20 us).  Same eight partial tiles summed in the same order: bit-identical.
+template <int EPI>
+__global__ __launch_bounds__(64) void lane_gemm1_kernel(GemmArgs g)
+{
+    __shared__ float red[kGemmWaves][1][32 * 32];
+    lane_gemm_body<1, EPI, 8>(g, blockIdx.x, red);
+}
+
+// the 4-wave form (VW = 2, 32-lane tiles): same results, four workgroups per CU
+template <int EPI>
+__global__ __launch_bounds__(64 * kGemmWaves / 2, 4) void lane_gemm4_kernel(GemmArgs g)
+{
+    __shared__ float red[kGemmWaves][1][32 * 32];
+    lane_gemm_body<1, EPI, 2>(g, blockIdx.x, red);
 }
 
 // Two independent GEMMs over the same lanes in ONE launch (column tiles [0, ct0) belong to the first): the small
@@ -1459,14 +1519,20 @@ __global__ void beam_init_kernel(DevState *s)
     first_predictor_input(s, n);
 }
 
-// per lane: log-softmax, mixture with the CTC posterior of this frame, top-`beam`.  The row lives in registers
-// (NV values per thread, V <= 256 * NV); each selection round is one block-wide argmax, after which the thread
-// that owns the winner retires it and rescans its own values.
+// per lane: log-softmax, mixture with the CTC posterior of this frame, top-`beam`.  One 1024-thread workgroup per lane
+// (round 2: 256 threads with 24 classes each -- the accurate exp / exp / log of the mixture and the rescans of the
+// selection rounds were 7 of the kernel's 13 us; with NV <= 5 classes per thread they are a quarter of that and the
+// sixteen waves run four to a SIMD).  The row lives in registers; every wave extracts the top-`beam` of its part with
+// wave-local argmax rounds (DPP, no barriers), wave 0 merges the 16 x beam survivors.  Ties go to the lowest index
+// throughout.
+constexpr int kTopkThreads = 1024;
 template <int NV>
-__global__ __launch_bounds__(256) void beam_topk_kernel(DevState *sp)
+__global__ __launch_bounds__(kTopkThreads) void beam_topk_kernel(DevState *sp)
 {
-    __shared__ float sv[4];
-    __shared__ int si[4];
+    constexpr int NW = kTopkThreads / 64;
+    __shared__ float sv[NW];
+    __shared__ float wv[NW * kMaxBeam];
+    __shared__ int wi[NW * kMaxBeam];
     WR_STAMP_DECL;
     WR_STAMP_RT(7);
     WR_STAMP(0);
@@ -1485,19 +1551,19 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(DevState *sp)
     float xv[NV], cv[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int v = tid + i * 256;
+        const int v = tid + i * kTopkThreads;
         xv[i] = x[v < d.V ? v : d.V - 1];
         cv[i] = cp[v < d.V ? v : d.V - 1];
     }
     float m = -3.0e38f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) m = fmaxf(m, (tid + i * 256 < d.V) ? xv[i] : -3.0e38f);
+    for (int i = 0; i < NV; ++i) m = fmaxf(m, (tid + i * kTopkThreads < d.V) ? xv[i] : -3.0e38f);
     m = block_max(m, sv);
     WR_STAMP(1);                                   // rows arrived, first reduction done
     if (!act) return;
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) sum += (tid + i * 256 < d.V) ? expf(xv[i] - m) : 0.f;
+    for (int i = 0; i < NV; ++i) sum += (tid + i * kTopkThreads < d.V) ? expf(xv[i] - m) : 0.f;
     sum = block_sum(sum, sv);
     const float ls = logf(sum);
     WR_STAMP(2);
@@ -1505,25 +1571,21 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(DevState *sp)
     for (int i = 0; i < NV; ++i) {
         const float l = (xv[i] - m) - ls;
         // prefix_beam_search.py:99-101: log(tw * exp(logp) + cw * exp(ctc[i]))
-        xv[i] = (tid + i * 256 < d.V) ? logf(S.tr_weight * expf(l) + S.ctc_weight * expf(cv[i])) : ninf;
+        xv[i] = (tid + i * kTopkThreads < d.V) ? logf(S.tr_weight * expf(l) + S.ctc_weight * expf(cv[i])) : ninf;
     }
-    // selection: every wave extracts the top-`beam` of its quarter of the row with wave-local argmax rounds (DPP,
-    // no barriers); wave 0 then merges the 4 x beam survivors.  Ties go to the lowest index throughout.
-    __shared__ float wv[4 * kMaxBeam];
-    __shared__ int wi[4 * kMaxBeam];
     const int lane = tid & 63, wave = tid >> 6;
     for (int k = 0; k < S.beam; ++k) {
         float best = ninf;
         int bi = 0x7fffffff;
 #pragma unroll
         for (int i = 0; i < NV; ++i)
-            if (xv[i] > best) { best = xv[i]; bi = tid + i * 256; }   // ascending scan: lowest index wins ties
+            if (xv[i] > best) { best = xv[i]; bi = tid + i * kTopkThreads; }   // ascending scan: lowest index wins ties
         wave_argmax_dpp(best, bi);
         if (lane == 0) { wv[wave * S.beam + k] = best; wi[wave * S.beam + k] = bi; }
-        if ((bi & 255) == tid) {                   // taken
+        if (bi != 0x7fffffff && (bi % kTopkThreads) == tid) {                     // taken
 #pragma unroll
             for (int i = 0; i < NV; ++i)
-                if (i == (bi >> 8)) xv[i] = ninf;
+                if (i == bi / kTopkThreads) xv[i] = ninf;
         }
     }
     // touch the next frame's CTC row (one word per 128-byte line) so that it is already in the Infinity Cache and
@@ -1536,18 +1598,30 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(DevState *sp)
     __syncthreads();
     WR_STAMP(4);
     if (wave == 0) {
-        const bool in = lane < 4 * S.beam;
-        float cv0 = in ? wv[lane] : ninf;
-        const int ci = in ? wi[lane] : 0x7fffffff;
+        constexpr int PM = NW * kMaxBeam / 64;      // survivors per lane of wave 0
+        const int total = NW * S.beam;
+        float c0[PM];
+        int ci[PM];
+#pragma unroll
+        for (int q = 0; q < PM; ++q) {
+            const int j = lane + q * 64;
+            c0[q] = j < total ? wv[j] : ninf;
+            ci[q] = j < total ? wi[j] : 0x7fffffff;
+        }
         for (int k = 0; k < S.beam; ++k) {
-            float best = cv0;
-            int bi = ci;
+            float best = ninf;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int q = 0; q < PM; ++q)
+                if (c0[q] > best || (c0[q] == best && ci[q] < bi)) { best = c0[q]; bi = ci[q]; }
             wave_argmax_dpp(best, bi);
             if (lane == 0) {
                 S.topv[(size_t)n * S.beam + k] = best;
                 S.topi[(size_t)n * S.beam + k] = (bi < d.V) ? bi : 0;
             }
-            if (ci == bi) cv0 = ninf;
+#pragma unroll
+            for (int q = 0; q < PM; ++q)
+                if (ci[q] == bi) c0[q] = ninf;
         }
     }
     WR_STAMP(5);
@@ -1562,8 +1636,10 @@ __device__ __forceinline__ double log_add2(double a, double b)
     // wenet/utils/common.py:268-276 for two arguments, float64
     const double ninf = -__builtin_huge_val();
     if (a == ninf && b == ninf) return ninf;
-    const double mx = a > b ? a : b;
-    return mx + log(exp(a - mx) + exp(b - mx));
+    // mx + log(exp(a - mx) + exp(b - mx)): the larger argument contributes exp(0.0) = 1.0 exactly, so one exp suffices
+    // (the sum is the same two addends in either order)
+    const double mx = a > b ? a : b, mn = a > b ? b : a;
+    return mx + log(1.0 + exp(mn - mx));
 }
 
 // one workgroup per utterance: expansion, prefix fusion, stable prune (prefix_beam_search.py:107-146).
@@ -1572,8 +1648,11 @@ __device__ __forceinline__ double log_add2(double a, double b)
 // verified token by token only when the hashes agree, so fusion is exact.  Then the survivors' hypotheses,
 // predictor caches and next input embeddings are moved into place (rows of the k-major caches are independent,
 // so each batch of rows is read into registers, synchronised and written back in place).
-__global__ __launch_bounds__(256) void beam_update_kernel(DevState *sp)
+constexpr int kBeamUpdThreads = 1024;   // one workgroup per utterance; 256 threads in round 2 (the all-pairs steps and the
+                                        // layer-0 cells of the survivors are 4 x as parallel now)
+__global__ __launch_bounds__(kBeamUpdThreads) void beam_update_kernel(DevState *sp)
 {
+    constexpr int NT = kBeamUpdThreads;
     constexpr int MC = kMaxBeam * kMaxBeam;
     __shared__ int c_base[MC], c_tok[MC], c_len[MC], c_last[MC], c_rep[MC], c_rank[MC], order[kMaxBeam];
     __shared__ unsigned long long c_hash[MC];
@@ -1623,7 +1702,7 @@ __global__ __launch_bounds__(256) void beam_update_kernel(DevState *sp)
     __syncthreads();
     WR_STAMP(1);                                   // candidates built
     // phase 2: class representative = the first candidate with the same token sequence (:130-142)
-    for (int p = tid; p < C * C; p += 256) {
+    for (int p = tid; p < C * C; p += NT) {
         const int i = p / C, f = p - i * C;
         if (f >= i || c_hash[f] != c_hash[i] || c_len[f] != c_len[i] || c_last[f] != c_last[i]) continue;
         // equal hashes, lengths and last tokens: the sequences are equal iff the first len-1 tokens of the two base
@@ -1649,18 +1728,24 @@ __global__ __launch_bounds__(256) void beam_update_kernel(DevState *sp)
     __syncthreads();
     WR_STAMP(2);                                   // classes known
     // phase 3: a representative accumulates its duplicates' scores in candidate order with float64 log_add
-    if (tid < C) {
-        double sc = c_score[tid];
-        if (c_rep[tid] == tid) {
+    // (a float64 exp + log is ~2 us of dependent instructions and a wave runs it for one lane at a time: consecutive
+    // candidates sit in different waves, so that the few duplicates of a frame are summed side by side)
+    {
+        const int c = (tid & 63) * (NT / 64) + (tid >> 6);
+        if (c < C) {
+            double sc = c_score[c];
+            if (c_rep[c] == c) {
 #pragma unroll 8
-            for (int f = tid + 1; f < C; ++f)
-                if (c_rep[f] == tid) sc = log_add2(sc, c_score[f]);
+                for (int f = c + 1; f < C; ++f)
+                    if (c_rep[f] == c) sc = log_add2(sc, c_score[f]);
+            }
+            f_score[c] = sc;
         }
-        f_score[tid] = sc;
     }
     __syncthreads();
+    WR_STAMP(9);                                   // duplicates' scores summed
     // phase 4: stable descending sort position among representatives (list.sort(reverse=True) keeps order on ties)
-    for (int p = tid; p < C * C; p += 256) {
+    for (int p = tid; p < C * C; p += NT) {
         const int i = p / C, f = p - i * C;
         if (c_rep[i] != i || c_rep[f] != f) continue;
         const double me = f_score[i], ot = f_score[f];
@@ -1691,18 +1776,18 @@ __global__ __launch_bounds__(256) void beam_update_kernel(DevState *sp)
         int maxlb = 0;
         for (int e = 0; e < keep; ++e) maxlb = e_lb[e_src[e]] > maxlb ? e_lb[e_src[e]] : maxlb;
         constexpr int UN = 4;
-        for (int i0 = 0; i0 < keep * maxlb; i0 += 256 * UN) {
+        for (int i0 = 0; i0 < keep * maxlb; i0 += NT * UN) {
             int val[UN];
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                const int i = i0 + u * 256 + tid;
+                const int i = i0 + u * NT + tid;
                 const int e = i / maxlb, q = i - e * maxlb;
                 const bool in = e < keep && q < e_lb[e_src[e < keep ? e : 0]];
                 val[u] = in ? hy[(size_t)e_src[e] * S.Lmax + q] : 0;
             }
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                const int i = i0 + u * 256 + tid;
+                const int i = i0 + u * NT + tid;
                 const int e = i / maxlb, q = i - e * maxlb;
                 if (e < keep && q < e_lb[e_src[e]]) hy2[(size_t)e * S.Lmax + q] = val[u];
             }
@@ -1712,17 +1797,19 @@ __global__ __launch_bounds__(256) void beam_update_kernel(DevState *sp)
             if (!e_blank[tid] && lb < S.Lmax) hy2[(size_t)tid * S.Lmax + lb] = e_tok[tid];
         }
     }
+    WR_STAMP(4);                                   // hypotheses moved
     if (d.ptype == kPredLstm) {
         // LSTM predictor: a survivor inherits a slot NUMBER -- its base hypothesis' committed slot for a blank extension,
         // the slot of the base's new state for a label (:111-124; several survivors may share one) -- and gets a free slot
         // of the utterance's 2 * beam for its own next step; then layer 0 of that step (lstm_layer0_cell).  Nothing is
         // copied.  Slots of utterance b: lanes' numbers b * beam + j and NLp + b * beam + j.
-        __shared__ int s_comm[kMaxBeam], s_new[kMaxBeam];
+        __shared__ int s_comm[kMaxBeam], s_new[kMaxBeam], s_oc[kMaxBeam], s_on[kMaxBeam];
+        if (tid < beam) { s_oc[tid] = S.comm_slot[b * beam + tid]; s_on[tid] = S.new_slot[b * beam + tid]; }
+        __syncthreads();
         if (tid == 0) {
             unsigned used = 0;                                   // bit j: slot b*beam + j, bit beam + j: slot NLp + b*beam + j
             for (int e = 0; e < keep; ++e) {
-                const int src = b * beam + e_src[e];
-                const int sl = e_blank[e] ? S.comm_slot[src] : S.new_slot[src];
+                const int sl = e_blank[e] ? s_oc[e_src[e]] : s_on[e_src[e]];
                 s_comm[e] = sl;
                 used |= 1u << (sl >= d.NLp ? beam + (sl - d.NLp - b * beam) : sl - b * beam);
             }
@@ -1738,34 +1825,65 @@ __global__ __launch_bounds__(256) void beam_update_kernel(DevState *sp)
         }
         __syncthreads();
         if (tid < beam) { S.comm_slot[b * beam + tid] = s_comm[tid]; S.new_slot[b * beam + tid] = s_new[tid]; }
-        for (int e = 0; e < keep; ++e) lstm_layer0_cell(S, b * beam + e, e_last[e], s_comm[e], s_new[e]);
+        // layer 0 of every survivor's next step (lstm_layer0_cell), (survivor, unit) pairs spread over the workgroup with
+        // the loads of two pairs per thread in flight together
+        {
+            constexpr int UN = 2;
+            const int items = keep * d.H;
+            for (int i0 = 0; i0 < items; i0 += NT * UN) {
+                float ev[UN][4], gv[UN][4], cv[UN];
+#pragma unroll
+                for (int q = 0; q < UN; ++q) {
+                    const int i = i0 + q * NT + tid;
+                    const int e = i < items ? i / d.H : 0, u = i < items ? i - e * d.H : 0;
+                    const int col = (u >> 3) * 32 + (u & 7);
+                    const float *__restrict__ er = S.etab + (size_t)e_last[e] * d.G4p + col;
+                    const float *__restrict__ gr = S.pool_g + (size_t)s_comm[e] * d.G4p + col;
+#pragma unroll
+                    for (int gt = 0; gt < 4; ++gt) { ev[q][gt] = er[gt * 8]; gv[q][gt] = gr[gt * 8]; }
+                    cv[q] = S.pool_c[(size_t)s_comm[e] * d.Hp + u];
+                }
+#pragma unroll
+                for (int q = 0; q < UN; ++q) {
+                    const int i = i0 + q * NT + tid;
+                    if (i >= items) continue;
+                    const int e = i / d.H, u = i - e * d.H;
+                    const float ig = sigmoidf_(ev[q][0] + gv[q][0]);
+                    const float fg = sigmoidf_(ev[q][1] + gv[q][1]);
+                    const float gg = tanhf(ev[q][2] + gv[q][2]);
+                    const float og = sigmoidf_(ev[q][3] + gv[q][3]);
+                    const float c = fg * cv[q] + ig * gg;
+                    S.pool_c[(size_t)s_new[e] * d.Hp + u] = c;
+                    S.new_hT[(size_t)u * d.NLp + b * beam + e] = og * tanhf(c);
+                }
+            }
+        }
     } else {
     // next predictor inputs
     {
         constexpr int UN = 4;
         const float *__restrict__ emb = S.embed;
-        for (int i0 = 0; i0 < keep * d.D; i0 += 256 * UN) {
+        for (int i0 = 0; i0 < keep * d.D; i0 += NT * UN) {
             float val[UN];
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                const int i = i0 + u * 256 + tid;
+                const int i = i0 + u * NT + tid;
                 const int e = i / d.D, k = i - e * d.D;
                 val[u] = e < keep ? emb[(size_t)e_last[e] * d.D + k] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                const int i = i0 + u * 256 + tid;
+                const int i = i0 + u * NT + tid;
                 const int e = i / d.D, k = i - e * d.D;
                 if (e < keep) S.xT[(size_t)k * d.NLp + b * beam + e] = val[u];
             }
         }
     }
-    WR_STAMP(4);                                   // hypotheses and next inputs moved
     // predictor caches: a blank extension keeps the base hypothesis' cache, a label takes the predictor's new
     // cache (:111-124).  Rows i of [L*Hp][NLp]; a thread owns (row, survivor) pairs, `beam` survivors per row.
     {
         constexpr int UN = 8;
-        const int rows = d.L * d.Hp, per_it = 256 / beam;           // rows per pass of the workgroup
+        const int rows = d.L * d.Hp, per_it = NT / beam;           // rows per pass of the workgroup
         const int e = tid % beam, r0 = tid / beam;
         const bool on = e < keep && r0 < per_it;
         const int src = b * beam + (on ? e_src[e] : 0), dst = b * beam + e;
@@ -2012,6 +2130,9 @@ void launch_transpose(const float *src, int R, int C, int Rp, int Cp, float *dst
     hipLaunchKernelGGL(transpose_pad_kernel, dim3((Rp + 31) / 32, (Cp + 31) / 32), dim3(256), 0, st, src, R, C, Rp, Cp, dst);
 }
 
+// a 128-lane workgroup reads A columns lane0 .. lane0 + 127: the k-major arrays must be that wide
+inline bool d_nlp_lt128(const GemmArgs &g) { return (g.lda % 128) != 0; }
+
 // Exact-fp32 MFMA runs at 256 flop/clk/CU, so a 64-lane x 32-column x 512-deep tile already costs 3.4 us on its
 // CU: lane tiles of 32 (more, smaller workgroups) whenever they all fit on the chip at once.
 template <int EPI>
@@ -2021,8 +2142,19 @@ void launch_gemm(const GemmArgs &g, int n_cols_padded, int n_lanes, hipStream_t 
     const int policy = tune_get(kTuneLaneGemmTile);               // 0: by occupancy, 1: 32-lane tiles, 2: 64-lane tiles
     if (mt == 1 || policy == 1 || (policy == 0 && ct * mt <= 256)) {
         hipLaunchKernelGGL((lane_gemm_kernel<1, EPI>), dim3(ct, mt), dim3(64 * kGemmWaves), 0, st, g);
-    } else {
+    } else if (policy == 2 || (policy == 0 && ct * ((mt + 1) / 2) <= 256) || !(EPI == kEpiRowMajor || EPI == kEpiRowStats) || d_nlp_lt128(g)) {
         hipLaunchKernelGGL((lane_gemm_kernel<2, EPI>), dim3(ct, (mt + 1) / 2), dim3(64 * kGemmWaves), 0, st, g);
+    } else {
+        // more tiles than one round of 64-lane workgroups (bit-identical results in every form): 128-lane workgroups
+        // (knob 6 = 3: 4-wave workgroups of 32 lanes, four per CU; 4: one wave per tile)
+        if constexpr (EPI == kEpiRowMajor || EPI == kEpiRowStats) {
+            if (policy == 3)
+                hipLaunchKernelGGL((lane_gemm4_kernel<EPI>), dim3(ct, mt), dim3(64 * kGemmWaves / 2), 0, st, g);
+            else if (policy == 4 && EPI == kEpiRowMajor)
+                hipLaunchKernelGGL((lane_gemm1_kernel<kEpiRowMajor>), dim3(ct, mt), dim3(64), 0, st, g);
+            else
+                hipLaunchKernelGGL((lane_gemm_kernel<4, EPI>), dim3(ct, (mt + 3) / 4), dim3(64 * kGemmWaves), 0, st, g);
+        }
     }
 }
 
@@ -2328,10 +2460,10 @@ void beam_frame(wr_decoder *h, int n_lanes, int n_utt, hipStream_t st)
 {
     launch_predictor_and_joint(h, n_lanes, st);
     const int V = h->d.V;                           // <= 16384 (check_weights)
-    if (V <= 256 * 8) hipLaunchKernelGGL(beam_topk_kernel<8>, dim3(n_lanes), dim3(256), 0, st, h->dev);
-    else if (V <= 256 * 24) hipLaunchKernelGGL(beam_topk_kernel<24>, dim3(n_lanes), dim3(256), 0, st, h->dev);
-    else hipLaunchKernelGGL(beam_topk_kernel<64>, dim3(n_lanes), dim3(256), 0, st, h->dev);
-    hipLaunchKernelGGL(beam_update_kernel, dim3(n_utt), dim3(256), 0, st, h->dev);
+    if (V <= kTopkThreads * 2) hipLaunchKernelGGL(beam_topk_kernel<2>, dim3(n_lanes), dim3(kTopkThreads), 0, st, h->dev);
+    else if (V <= kTopkThreads * 5) hipLaunchKernelGGL(beam_topk_kernel<5>, dim3(n_lanes), dim3(kTopkThreads), 0, st, h->dev);
+    else hipLaunchKernelGGL(beam_topk_kernel<16>, dim3(n_lanes), dim3(kTopkThreads), 0, st, h->dev);
+    hipLaunchKernelGGL(beam_update_kernel, dim3(n_utt), dim3(kBeamUpdThreads), 0, st, h->dev);
 }
 
 // Order the decoder's work stream after everything already enqueued on the caller's stream ...
