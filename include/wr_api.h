@@ -61,10 +61,13 @@ const char *wr_last_error(void);
  * stores, 4: row-lse loads; default 7), key 3 / key 4: 16-byte vectors in flight per lane in the gradient (4, 8 or 16;
  * default 16) / row-lse pass (4, 8 or 16; default 16),
  * key 5: exact-fp32 joiner forward (default: fragment-layout operands; 1: the first forward kernel, bit-identical), key 6: decoder GEMM lane
- * tile (0: by occupancy, 1: 32 lanes, 2: 64 lanes), key 7: column parts of the split joiner forward (0: automatic),
+ * tile (0: by occupancy, 1: 32 lanes, 2: 64 lanes; for GEMMs of more than 256 tiles 3: 4-wave workgroups, 4: one wave
+ * per tile instead of 128-lane workgroups -- every form gives bit-identical results), key 7: column parts of the split
+ * joiner forward (0: automatic),
  * key 8: retired (the 64-cell split dZ tiling was removed), key 9 / key 10: exact dW / dZ tiling (0: 256 x 256 blocks,
  * 1: the first tilings of joint.hip), key 11: greedy / beam micro-step with an LSTM predictor (0: projection folded
- * into pred_ffn -- one launch less, the default; 1: two launches).  Keys 6-11 pick between kernels that compute the
+ * into pred_ffn -- one launch less, the default; 1: two launches), key 12: single-term (AMP) split joiner forward
+ * (0: 64 lattice cells per workgroup, the default; 2: 128 cells -- measured slower).  Keys 6-12 pick between kernels that compute the
  * same sums; the two dZ tilings are bit-identical, the dW tilings differ in the order of fp32 additions, the folded
  * projection in the rounding of one composed weight matrix (formed in float64). */
 int wr_tune_set(int key, int value);

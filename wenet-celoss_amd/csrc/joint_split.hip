@@ -106,22 +106,28 @@ template <> __device__ __forceinline__ _Float16 to_out<_Float16>(float x) { retu
 template <> __device__ __forceinline__ __bf16 to_out<__bf16>(float x) { return (__bf16)x; }
 
 // LSE = true (float logits, npart = 1): the epilogue also produces the RNN-T loss's row statistics (joint_lse.hpp).
-template <int TERMS, typename OutT, bool LSE = false>
+// RT = row tiles of 32 lattice cells per workgroup: 2 (64 cells; all modes) or 4 (128 cells; single-term / AMP mode only:
+// one bf16 image of 128 x J fits LDS where the hi + lo images of the split modes do not).  A workgroup streams ALL of W
+// for its cells, so 128 cells halve the W traffic per logit -- the stream out of the L2s is what bounds this kernel
+// (round 2: 9.7 TB/s at 64 cells).  A wave then owns 4 x 2 accumulator tiles per round.
+template <int TERMS, typename OutT, bool LSE = false, int RT = 2>
 __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
     const float *__restrict__ ep, const float *__restrict__ pp, const u32x4 *__restrict__ wh, const u32x4 *__restrict__ wl,
     const float *__restrict__ bias, const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens, int B, int T,
     int U1, int J, int Jp, int V, int Vp, int npart, int act, OutT *__restrict__ out, JointLse lse = JointLse{})
 {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds_s[];
+    constexpr int SM = 32 * RT;                            // lattice cells of this workgroup
+    static_assert(RT == 2 || (RT == 4 && TERMS == 1 && !LSE), "128-cell tiles: single-term mode without row statistics");
     const int JS = Jp + 8;                                 // padded row stride (bf16 elements): 16-byte pad
-    unsigned short *Ahi = lds_s;                            // [64][JS]
-    unsigned short *Alo = lds_s + (size_t)kSM * JS;         // [64][JS]   (TERMS == 3)
-    float *bias_s = reinterpret_cast<float *>(lds_s + (size_t)(TERMS == 3 ? 2 : 1) * kSM * JS);   // this part's bias
+    unsigned short *Ahi = lds_s;                            // [SM][JS]
+    unsigned short *Alo = lds_s + (size_t)SM * JS;          // [SM][JS]   (TERMS == 3)
+    float *bias_s = reinterpret_cast<float *>(lds_s + (size_t)(TERMS == 3 ? 2 : 1) * SM * JS);    // this part's bias
     const long M = (long)B * T * U1;
     // consecutive workgroups land on consecutive XCDs: part = blockIdx % npart keeps each XCD on one column slab of W
     // (<= ~2.5 MB of fragments, resident in its 4 MB L2) for the whole launch
     const int part = blockIdx.x % npart;
-    const long m0 = (long)(blockIdx.x / npart) * kSM;
+    const long m0 = (long)(blockIdx.x / npart) * SM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     float rm[32], rs[32];                                   // LSE: this lane's (reference, partial sum) of its 32 rows
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
     if (llens != nullptr && tlens != nullptr) {
         int valid = 0;
         const long m = m0 + tid;
-        if (tid < kSM && m < M) {
+        if (tid < SM && m < M) {
             const long bt = m / U1;
             const int u = (int)(m - bt * U1);
             const int b = (int)(bt / T), t = (int)(bt - (long)b * T);
@@ -182,8 +188,8 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
     // activation tile: a wave takes rows wave, wave+4, ...; four rows (32 loads per lane) in flight at a time;
     // a lane owns the k pairs 2*lane + 128*i (packed 32-bit LDS writes)
     constexpr int KI = 4;                                   // Jp <= 512: at most 4 k pairs per lane per row
-    static_assert(kSM / kSWaves % 4 == 0, "rows per wave");
-    for (int rb = 0; rb < kSM / kSWaves; rb += 4) {
+    static_assert(SM / kSWaves % 4 == 0, "rows per wave");
+    for (int rb = 0; rb < SM / kSWaves; rb += 4) {
         float2 ev[4][KI], pv[4][KI];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -227,17 +233,17 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
 
     const unsigned short *a_hi = Ahi + (size_t)l31 * JS + 8 * half;
     const unsigned short *a_lo = Alo + (size_t)l31 * JS + 8 * half;
-    f32x16 acc[2][kSCT];
+    f32x16 acc[RT][kSCT];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < RT; ++r)
 #pragma unroll
         for (int c = 0; c < kSCT; ++c) acc[r][c] = (f32x16){0};
 
     // A fragments (LDS) run one k-step ahead of the MFMAs that consume them
-    bf16x8 ah[2][2], al[2][2];                              // [buffer][row tile]
+    bf16x8 ah[2][RT], al[2][RT];                            // [buffer][row tile]
     auto read_a = [&](int s, int buf) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < RT; ++r) {
             ah[buf][r] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(a_hi + (size_t)(32 * r) * JS + 16 * s));
             if (TERMS == 3)
                 al[buf][r] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(a_lo + (size_t)(32 * r) * JS + 16 * s));
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
             const int buf = i & 1;                          // kSPF is even: every chunk starts on buffer 0
             read_a(i + 1 < kSPF ? c0 * kSPF + i + 1 : cn * kSPF, buf ^ 1);
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+            for (int r = 0; r < RT; ++r)
 #pragma unroll
                 for (int c = 0; c < kSCT; ++c) {
                     const bf16x8 bhv = __builtin_bit_cast(bf16x8, bh[i][c]);
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
         const int ct0 = (pair0 + pr) * kSCT;
         // interior tiles (all 64 cells and all 64 columns valid: everything but the matrix edges) store without
         // per-element guards, so the stores issue back to back
-        const bool full = m0 + kSM <= M && pr < npairs && (ct0 + kSCT) * 32 <= V;
+        const bool full = m0 + SM <= M && pr < npairs && (ct0 + kSCT) * 32 <= V;
 #pragma unroll
         for (int c = 0; c < kSCT; ++c) {
             const int col = (ct0 + c) * 32 + l31;
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
             const float bv = colin ? bias_s[(pr * kSCT + c) * 32 + l31] : 0.f;
             OutT *__restrict__ ocol = out + (size_t)m0 * V + (colin ? col : 0);
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 if (LSE) {
 #pragma unroll
                     for (int q = 0; q < 16; ++q)
@@ -1371,19 +1377,36 @@ int joint_fwd_split_launch(const float *ep_d, const float *pp_d, const float *w_
     int npart = 1;
     if (const int forced = tune_get(kTuneSplitParts)) npart = forced;
     if (lse) npart = 1;                                     // the row statistics need every column in one workgroup
-    size_t tile_lds = (size_t)(terms == 3 ? 2 : 1) * kSM * (Jp + 8) * sizeof(unsigned short);
+    // single-term (AMP) mode, experiment: 128 cells per workgroup -- their one bf16 image and the bias
+    // slab fit LDS (J <= 512 at V = 5000) -- halve the W traffic per logit.  Measured at the B = 8 BASELINE slice: 13.84 ms
+    // against 12.21 ms for the 64-cell form (eight accumulator tiles per wave leave the allocator 196 bytes of scratch per
+    // lane, and with half the W traffic the kernel is no faster: the stream out of the L2s is not what bounds the
+    // single-term mode).  Kept behind wr_tune_set(12, 2); the 64-cell form stays the default.
+    const bool wide = terms == 1 && !lse && tune_get(kTuneSplitFwdCells) == 2 && M >= 128 * 512 &&
+                      (size_t)128 * (Jp + 8) * sizeof(unsigned short) + (size_t)Vp * sizeof(float) <= 160 * 1024;
+    const int cells = wide ? 128 : kSM;
+    size_t tile_lds = (size_t)(terms == 3 ? 2 : 1) * cells * (Jp + 8) * sizeof(unsigned short);
     if (lse && tile_lds < joint_lse_exchange_bytes(kSWaves)) tile_lds = joint_lse_exchange_bytes(kSWaves);
     const size_t extra = 0;
     if (lse) (void)hipMemsetAsync(lse->repair, 0, sizeof(int32_t), st);
     while (!lse && npart < 64 &&
            tile_lds + (size_t)((Vp / (32 * kSCT) + npart - 1) / npart) * 32 * kSCT * sizeof(float) > 160 * 1024)
         npart *= 2;                                         // large vocabularies: the bias slab must fit beside the tile
-    WR_REQUIRE((M + kSM - 1) / kSM * npart < (1L << 31), WR_EUNSUPPORTED, "joint_fwd_split: too many lattice cells");
+    WR_REQUIRE((M + cells - 1) / cells * npart < (1L << 31), WR_EUNSUPPORTED, "joint_fwd_split: too many lattice cells");
     const int pairs_per_part = (Vp / (32 * kSCT) + npart - 1) / npart;
     const size_t bias_lds = (size_t)pairs_per_part * 32 * kSCT * sizeof(float);
     const size_t lds = tile_lds + bias_lds + extra;
     WR_REQUIRE(lds <= 160 * 1024, WR_EUNSUPPORTED, "joint_fwd_split: V=%d needs %zu bytes of LDS", V, lds);
-    const dim3 grid((unsigned)((M + kSM - 1) / kSM * npart));
+    const dim3 grid((unsigned)((M + cells - 1) / cells * npart));
+#define WR_LAUNCH_SPLIT_WIDE(OutT)                                                                                       \
+    do {                                                                                                              \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_fwd_split_kernel<1, OutT, false, 4>),            \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+        hipLaunchKernelGGL((joint_fwd_split_kernel<1, OutT, false, 4>), grid, dim3(64 * kSWaves), lds, st, ep_d, pp_d, \
+                           reinterpret_cast<const u32x4 *>(wh), reinterpret_cast<const u32x4 *>(wl), b_out_d,          \
+                           logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, npart, act, static_cast<OutT *>(out_d), \
+                           JointLse{});                                                                               \
+    } while (0)
 #define WR_LAUNCH_SPLIT(TERMS, OutT)                                                                                  \
     do {                                                                                                              \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_fwd_split_kernel<TERMS, OutT>),                  \
@@ -1408,11 +1431,16 @@ int joint_fwd_split_launch(const float *ep_d, const float *pp_d, const float *w_
         if (out_dtype == 0) WR_LAUNCH_SPLIT(3, float);
         else if (out_dtype == 1) WR_LAUNCH_SPLIT(3, _Float16);
         else WR_LAUNCH_SPLIT(3, __bf16);
+    } else if (wide) {
+        if (out_dtype == 0) WR_LAUNCH_SPLIT_WIDE(float);
+        else if (out_dtype == 1) WR_LAUNCH_SPLIT_WIDE(_Float16);
+        else WR_LAUNCH_SPLIT_WIDE(__bf16);
     } else {
         if (out_dtype == 0) WR_LAUNCH_SPLIT(1, float);
         else if (out_dtype == 1) WR_LAUNCH_SPLIT(1, _Float16);
         else WR_LAUNCH_SPLIT(1, __bf16);
     }
+#undef WR_LAUNCH_SPLIT_WIDE
 #undef WR_LAUNCH_SPLIT
 #undef WR_LAUNCH_SPLIT_LSE
     WR_CHECK_LAUNCH("joint_fwd_split_kernel");
