@@ -71,7 +71,7 @@ def _build_locked(build_dir: str, verbose: bool) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + _INCLUDE, "-I" + _CSRC,
-             "-Wall", "-Wno-unused-function"]
+             "-Wall", "-Wno-unused-function"] + os.environ.get("WR_EXTRA_HIPCC_FLAGS", "").split()
     procs = []
     for src in _sources():
         obj = os.path.join(build_dir, os.path.basename(src) + ".o")

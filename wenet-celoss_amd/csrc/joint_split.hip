@@ -100,6 +100,11 @@ __global__ void split_w_kernel(const float *__restrict__ w, int V, int J, int Vp
     }
 }
 
+#ifdef WR_SPLIT_PLAIN_STORE
+#define WR_SPLIT_STORE(v, p) (*(p) = (v))
+#else
+#define WR_SPLIT_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
 template <typename OutT> __device__ __forceinline__ OutT to_out(float x);
 template <> __device__ __forceinline__ float to_out<float>(float x) { return x; }
 template <> __device__ __forceinline__ _Float16 to_out<_Float16>(float x) { return (_Float16)x; }
@@ -114,15 +119,22 @@ template <int TERMS, typename OutT, bool LSE = false, int RT = 2>
 __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
     const float *__restrict__ ep, const float *__restrict__ pp, const u32x4 *__restrict__ wh, const u32x4 *__restrict__ wl,
     const float *__restrict__ bias, const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens, int B, int T,
-    int U1, int J, int Jp, int V, int Vp, int npart, int act, OutT *__restrict__ out, JointLse lse = JointLse{})
+    int U1, int J, int Jp, int V, int Vp, int npart, int act, OutT *__restrict__ out, JointLse lse = JointLse{},
+    int lds_bias_bytes = 0, int lds_stage = 0)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds_s[];
     constexpr int SM = 32 * RT;                            // lattice cells of this workgroup
+    constexpr int PF = RT == 4 ? 2 : kSPF;                 // k-steps per register set (eight accumulator tiles leave room for less)
     static_assert(RT == 2 || (RT == 4 && TERMS == 1 && !LSE), "128-cell tiles: single-term mode without row statistics");
     const int JS = Jp + 8;                                 // padded row stride (bf16 elements): 16-byte pad
     unsigned short *Ahi = lds_s;                            // [SM][JS]
     unsigned short *Alo = lds_s + (size_t)SM * JS;          // [SM][JS]   (TERMS == 3)
     float *bias_s = reinterpret_cast<float *>(lds_s + (size_t)(TERMS == 3 ? 2 : 1) * SM * JS);    // this part's bias
+    // per-wave store stage of the single-term mode (see finish_round): behind the bias slab; rows of V elements must keep
+    // 16-byte alignment for the vector stores
+    char *stage = reinterpret_cast<char *>(bias_s) + lds_bias_bytes;
+    const bool stage_ok = TERMS == 1 && !LSE && lds_stage && ((size_t)V * sizeof(OutT)) % 16 == 0 &&
+                          (reinterpret_cast<size_t>(out) & 15) == 0;
     const long M = (long)B * T * U1;
     // consecutive workgroups land on consecutive XCDs: part = blockIdx % npart keeps each XCD on one column slab of W
     // (<= ~2.5 MB of fragments, resident in its 4 MB L2) for the whole launch
@@ -147,8 +159,8 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
         }
         if (!__syncthreads_or(valid)) return;
     }
-    const int S = Jp / 16;                                  // k-steps per column tile; Jp is a multiple of 16 * kSPF
-    const int cpr = S / kSPF;                               // register sets ("chunks") per round
+    const int S = Jp / 16;                                  // k-steps per column tile; Jp is a multiple of 16 * PF
+    const int cpr = S / PF;                               // register sets ("chunks") per round
     const int n_ct = Vp / 32;                               // column tiles
     const int pairs = n_ct / kSCT;                          // a wave's unit of work: 64 columns
     const int ppp = (pairs + npart - 1) / npart;            // pairs per part
@@ -162,14 +174,14 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
     const u32x4 *__restrict__ whl = wh + lane;
     const u32x4 *__restrict__ wll = wl + lane;
 
-    auto load_set = [&](int ci, u32x4 (&bh)[kSPF][kSCT], u32x4 (&bl)[kSPF][kSCT]) {
+    auto load_set = [&](int ci, u32x4 (&bh)[PF][kSCT], u32x4 (&bl)[PF][kSCT]) {
         const int cc = ci < total ? ci : total - 1;
         const int r = cc / cpr, c0 = cc - r * cpr;
         const int pr = r * kSWaves + wave;
         const int ct0 = (pair0 + (pr < npairs ? pr : npairs - 1)) * kSCT;   // waves past the last pair reload it (results dropped)
 #pragma unroll
-        for (int i = 0; i < kSPF; ++i) {
-            const int s = c0 * kSPF + i;
+        for (int i = 0; i < PF; ++i) {
+            const int s = c0 * PF + i;
 #pragma unroll
             for (int c = 0; c < kSCT; ++c) {
                 const size_t f = ((size_t)(ct0 + c) * S + s) * 64;
@@ -178,7 +190,7 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
             }
         }
     };
-    u32x4 pbh[kSPF][kSCT], pbl[kSPF][kSCT], qbh[kSPF][kSCT], qbl[kSPF][kSCT], rbh[kSPF][kSCT], rbl[kSPF][kSCT];
+    u32x4 pbh[PF][kSCT], pbl[PF][kSCT], qbh[PF][kSCT], qbl[PF][kSCT], rbh[PF][kSCT], rbl[PF][kSCT];
 
     // bias of this part's columns -> LDS (read back per round without touching the vector-memory counter)
     for (int i = tid; i < npairs * 32 * kSCT; i += 64 * kSWaves) {
@@ -252,13 +264,13 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
     load_set(0, pbh, pbl);
     load_set(1, qbh, qbl);
     read_a(0, 0);
-    auto mfma_set = [&](int ci, const u32x4 (&bh)[kSPF][kSCT], const u32x4 (&bl)[kSPF][kSCT]) {
+    auto mfma_set = [&](int ci, const u32x4 (&bh)[PF][kSCT], const u32x4 (&bl)[PF][kSCT]) {
         const int c0 = ci % cpr;
         const int cn = (c0 + 1 == cpr) ? 0 : c0 + 1;        // next chunk's first step (wraps to the next round)
 #pragma unroll
-        for (int i = 0; i < kSPF; ++i) {
-            const int buf = i & 1;                          // kSPF is even: every chunk starts on buffer 0
-            read_a(i + 1 < kSPF ? c0 * kSPF + i + 1 : cn * kSPF, buf ^ 1);
+        for (int i = 0; i < PF; ++i) {
+            const int buf = i & 1;                          // PF is even: every chunk starts on buffer 0
+            read_a(i + 1 < PF ? c0 * PF + i + 1 : cn * PF, buf ^ 1);
 #pragma unroll
             for (int r = 0; r < RT; ++r)
 #pragma unroll
@@ -281,6 +293,45 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
         // interior tiles (all 64 cells and all 64 columns valid: everything but the matrix edges) store without
         // per-element guards, so the stores issue back to back
         const bool full = m0 + SM <= M && pr < npairs && (ct0 + kSCT) * 32 <= V;
+        if constexpr (TERMS == 1 && !LSE) {
+            // Interior tiles of the single-term mode leave through a per-wave LDS stage as whole 128-byte lines: in the
+            // C/D layout a lane holds ONE column, so a direct store moves 2 or 4 bytes per lane (64 store instructions per
+            // round and wave, 64-byte pieces of lines); staged, a lane stores 16 bytes of 8 (bf16 / f16) or 4 (fp32)
+            // consecutive columns and one instruction covers 8 or 4 full rows of the wave's 64 columns.  Measured at the
+            // B = 8 BASELINE slice, bf16 logits: 12.1 -> see DESIGN.md section 6.
+            constexpr int ROWB = kSCT * 32 * (int)sizeof(OutT);            // bytes of the wave's 64 columns in one row
+            constexpr int SROW = ROWB + 16;                                 // padded stage row (bank spread)
+            if (full && stage_ok) {
+                char *stg = stage + (size_t)wave * 32 * SROW;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+                    for (int c = 0; c < kSCT; ++c) {
+                        const float bv = bias_s[(pr * kSCT + c) * 32 + l31];
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const int row = (q & 3) + 8 * (q >> 2) + 4 * half;
+                            *reinterpret_cast<OutT *>(stg + row * SROW + (c * 32 + l31) * (int)sizeof(OutT)) = to_out<OutT>(acc[rt][c][q] + bv);
+                        }
+                        acc[rt][c] = (f32x16){0};
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    constexpr int LPR = ROWB / 16;                          // lanes per row: 8 (16-bit logits) or 16 (fp32)
+                    constexpr int RPI = 64 / LPR;                           // rows per store instruction
+                    const int rr = lane / LPR, seg = lane - rr * LPR;
+                    char *obase = reinterpret_cast<char *>(out + (size_t)(m0 + 32 * rt) * V + (size_t)ct0 * 32) + seg * 16;
+#pragma unroll
+                    for (int i = 0; i < 32 / RPI; ++i) {
+                        const int row = i * RPI + rr;
+                        const u32x4 v = *reinterpret_cast<const u32x4 *>(stg + row * SROW + seg * 16);
+                        *reinterpret_cast<u32x4 *>(obase + (size_t)row * V * sizeof(OutT)) = v;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int c = 0; c < kSCT; ++c) {
             const int col = (ct0 + c) * 32 + l31;
@@ -298,13 +349,13 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
                         const int row = 32 * rt + (q & 3) + 8 * (q >> 2) + 4 * half;   // C/D layout of the 32x32 MFMA
-                        __builtin_nontemporal_store(to_out<OutT>(acc[rt][c][q] + bv), ocol + (size_t)row * V);
+                        WR_SPLIT_STORE(to_out<OutT>(acc[rt][c][q] + bv), ocol + (size_t)row * V);
                     }
                 } else {
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
                         const int row = 32 * rt + (q & 3) + 8 * (q >> 2) + 4 * half;
-                        if (m0 + row < M && colin) __builtin_nontemporal_store(to_out<OutT>(acc[rt][c][q] + bv), ocol + (size_t)row * V);
+                        if (m0 + row < M && colin) WR_SPLIT_STORE(to_out<OutT>(acc[rt][c][q] + bv), ocol + (size_t)row * V);
                     }
                 }
                 acc[rt][c] = (f32x16){0};
@@ -1395,7 +1446,13 @@ int joint_fwd_split_launch(const float *ep_d, const float *pp_d, const float *w_
     WR_REQUIRE((M + cells - 1) / cells * npart < (1L << 31), WR_EUNSUPPORTED, "joint_fwd_split: too many lattice cells");
     const int pairs_per_part = (Vp / (32 * kSCT) + npart - 1) / npart;
     const size_t bias_lds = (size_t)pairs_per_part * 32 * kSCT * sizeof(float);
-    const size_t lds = tile_lds + bias_lds + extra;
+    // single-term mode: a store stage of 32 rows x (64 columns + 16 bytes) per wave behind the (16-byte rounded) bias slab
+    const size_t esz = out_dtype == 0 ? 4 : 2;
+    const size_t bias_al = align_up(bias_lds, 16);
+    const size_t stage_lds = (terms == 1 && !lse) ? (size_t)kSWaves * 32 * (kSCT * 32 * esz + 16) : 0;
+    const bool stage_fits = stage_lds > 0 && tile_lds + bias_al + stage_lds <= 160 * 1024;
+    const size_t lds = tile_lds + (stage_fits ? bias_al + stage_lds : bias_lds) + extra;
+    const int kb_bias = (int)bias_al, kb_stage = stage_fits ? 1 : 0;
     WR_REQUIRE(lds <= 160 * 1024, WR_EUNSUPPORTED, "joint_fwd_split: V=%d needs %zu bytes of LDS", V, lds);
     const dim3 grid((unsigned)((M + cells - 1) / cells * npart));
 #define WR_LAUNCH_SPLIT_WIDE(OutT)                                                                                       \
@@ -1405,7 +1462,7 @@ int joint_fwd_split_launch(const float *ep_d, const float *pp_d, const float *w_
         hipLaunchKernelGGL((joint_fwd_split_kernel<1, OutT, false, 4>), grid, dim3(64 * kSWaves), lds, st, ep_d, pp_d, \
                            reinterpret_cast<const u32x4 *>(wh), reinterpret_cast<const u32x4 *>(wl), b_out_d,          \
                            logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, npart, act, static_cast<OutT *>(out_d), \
-                           JointLse{});                                                                               \
+                           JointLse{}, kb_bias, kb_stage);                                                            \
     } while (0)
 #define WR_LAUNCH_SPLIT(TERMS, OutT)                                                                                  \
     do {                                                                                                              \
@@ -1414,7 +1471,7 @@ int joint_fwd_split_launch(const float *ep_d, const float *pp_d, const float *w_
         hipLaunchKernelGGL((joint_fwd_split_kernel<TERMS, OutT>), grid, dim3(64 * kSWaves), lds, st, ep_d, pp_d,       \
                            reinterpret_cast<const u32x4 *>(wh), reinterpret_cast<const u32x4 *>(wl), b_out_d,          \
                            logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, npart, act, static_cast<OutT *>(out_d), \
-                           JointLse{});                                                                               \
+                           JointLse{}, kb_bias, kb_stage);                                                            \
     } while (0)
 #define WR_LAUNCH_SPLIT_LSE(TERMS)                                                                                    \
     do {                                                                                                              \
