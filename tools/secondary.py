@@ -237,9 +237,15 @@ def leg_hotword(dev, steps=3):
     run = lambda: greedy_search_both_device(m, enc, lens, ctx, ctx_len, n_steps=64, filter_on=True)
     ms, (hyps, traces) = _wall_ms(run, steps, warmup=2)
     decisions = len(hyps[0]) + T                        # lower bound: a go-back re-decodes frames
-    return {"config": "hot-word greedy ('both', filter on), 1 stream, T=200, V=5000, D=256, 4 heads, hw_odim 100, 50 hot words",
-            "ms_per_call": round(ms, 2), "tokens": len(hyps[0]), "gate_ones": sum(t.count(1) for t in traces),
-            "gate_zeros": sum(t.count(0) for t in traces), "us_per_decision": round(ms * 1e3 / decisions, 1)}
+    res = {"config": "hot-word greedy ('both', filter on), 1 stream, T=200, V=5000, D=256, 4 heads, hw_odim 100, 50 hot words",
+           "ms_per_call": round(ms, 2), "tokens": len(hyps[0]), "gate_ones": sum(t.count(1) for t in traces),
+           "gate_zeros": sum(t.count(0) for t in traces), "us_per_decision": round(ms * 1e3 / decisions, 1)}
+    # filter off: every predictor step is biased with the hot-word list (all gates 1) -- the cost of a gate-1 decision
+    run1 = lambda: greedy_search_both_device(m, enc, lens, ctx, ctx_len, n_steps=64, filter_on=False)
+    ms1, (h1, t1) = _wall_ms(run1, steps, warmup=1)
+    res["filter_off_all_gate_1"] = {"ms_per_call": round(ms1, 2), "tokens": len(h1[0]),
+                                    "us_per_decision": round(ms1 * 1e3 / (len(h1[0]) + T), 1)}
+    return res
 
 
 LEGS = (("joiner", leg_joiner), ("loss_block", leg_loss_block), ("ctc", leg_ctc), ("greedy", leg_greedy),
