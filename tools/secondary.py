@@ -199,7 +199,7 @@ def leg_greedy(dev, steps=5):
     return res
 
 
-def leg_beam(dev, steps=2):
+def leg_beam(dev, steps=3):
     import wenet_celoss_amd as w
     pred, joint = _decode_modules(dev, 6)
     B, T, beam = 16, 1500, 8
@@ -207,7 +207,7 @@ def leg_beam(dev, steps=2):
     bs = w.PrefixBeamSearch(None, pred, joint, ctc, 0)
     enc = torch.randn(B, T, 256, device=dev)
     lens = torch.full((B,), T, dtype=torch.int32)
-    ms, out = _wall_ms(lambda: bs.search_encoded(enc, lens, beam_size=beam), steps, warmup=1)
+    ms, out = _wall_ms(lambda: bs.search_encoded(enc, lens, beam_size=beam), steps, warmup=2)
     return {"config": "beam 8, B=16, T=1500, V=5000, ctc_weight 0.3 / transducer_weight 0.7", "ms_per_call": round(ms, 2),
             "frames_per_s": round(B * T / ms * 1e3), "utt_per_s": round(B / ms * 1e3, 2), "us_per_frame": round(ms * 1e3 / T, 2),
             "best_len": len(out[0][0].hyp)}

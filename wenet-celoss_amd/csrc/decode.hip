@@ -1519,13 +1519,12 @@ __global__ void beam_init_kernel(DevState *s)
     first_predictor_input(s, n);
 }
 
-// per lane: log-softmax, mixture with the CTC posterior of this frame, top-`beam`.  One 1024-thread workgroup per lane
-// (round 2: 256 threads with 24 classes each -- the accurate exp / exp / log of the mixture and the rescans of the
-// selection rounds were 7 of the kernel's 13 us; with NV <= 5 classes per thread they are a quarter of that and the
-// sixteen waves run four to a SIMD).  The row lives in registers; every wave extracts the top-`beam` of its part with
+// per lane: log-softmax, mixture with the CTC posterior of this frame, top-`beam`.  One 512-thread workgroup per lane
+// (round 2: 256 threads with 24 classes each; 1 024 threads were tried too: the transcendentals shrink with the classes
+// per thread, the fixed cost of a selection round -- two DPP reductions per wave -- grows with the waves per SIMD).  The row lives in registers; every wave extracts the top-`beam` of its part with
 // wave-local argmax rounds (DPP, no barriers), wave 0 merges the 16 x beam survivors.  Ties go to the lowest index
 // throughout.
-constexpr int kTopkThreads = 1024;
+constexpr int kTopkThreads = 512;
 template <int NV>
 __global__ __launch_bounds__(kTopkThreads) void beam_topk_kernel(DevState *sp)
 {
@@ -1730,7 +1729,12 @@ __global__ __launch_bounds__(kBeamUpdThreads) void beam_update_kernel(DevState *
     // phase 3: a representative accumulates its duplicates' scores in candidate order with float64 log_add
     // (a float64 exp + log is ~2 us of dependent instructions and a wave runs it for one lane at a time: consecutive
     // candidates sit in different waves, so that the few duplicates of a frame are summed side by side)
-    {
+    // Most frames have no duplicate at all: then the fused scores are the candidates' own (one count over the workgroup
+    // instead of every candidate scanning all later ones).
+    const int n_dup = __syncthreads_count(tid < C && c_rep[tid] != tid);
+    if (n_dup == 0) {
+        if (tid < C) f_score[tid] = c_score[tid];
+    } else {
         const int c = (tid & 63) * (NT / 64) + (tid >> 6);
         if (c < C) {
             double sc = c_score[c];
@@ -2460,9 +2464,9 @@ void beam_frame(wr_decoder *h, int n_lanes, int n_utt, hipStream_t st)
 {
     launch_predictor_and_joint(h, n_lanes, st);
     const int V = h->d.V;                           // <= 16384 (check_weights)
-    if (V <= kTopkThreads * 2) hipLaunchKernelGGL(beam_topk_kernel<2>, dim3(n_lanes), dim3(kTopkThreads), 0, st, h->dev);
-    else if (V <= kTopkThreads * 5) hipLaunchKernelGGL(beam_topk_kernel<5>, dim3(n_lanes), dim3(kTopkThreads), 0, st, h->dev);
-    else hipLaunchKernelGGL(beam_topk_kernel<16>, dim3(n_lanes), dim3(kTopkThreads), 0, st, h->dev);
+    if (V <= kTopkThreads * 4) hipLaunchKernelGGL(beam_topk_kernel<4>, dim3(n_lanes), dim3(kTopkThreads), 0, st, h->dev);
+    else if (V <= kTopkThreads * 10) hipLaunchKernelGGL(beam_topk_kernel<10>, dim3(n_lanes), dim3(kTopkThreads), 0, st, h->dev);
+    else hipLaunchKernelGGL(beam_topk_kernel<32>, dim3(n_lanes), dim3(kTopkThreads), 0, st, h->dev);
     hipLaunchKernelGGL(beam_update_kernel, dim3(n_utt), dim3(kBeamUpdThreads), 0, st, h->dev);
 }
 
