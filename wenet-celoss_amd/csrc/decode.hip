@@ -1226,6 +1226,20 @@ struct HwDev {
     float *kbuf[2], *vbuf[2];         // [max_ctx][D]: K / V of the empty list (0) and of the hot-word list (1)
     float *cold_c;                    // [D] one-entry empty list: combine(second half) of its constant bias feature + bias
     int32_t *gate_tab;                // [max_utt * Tmax]
+    // attention folded over a short list (heads * entries <= D), built once per call by hw_fold_kernel:
+    //   scores = mqT^T x + mq_c      mqT[k][r] = sum_{j in head h} Wq[j][k] K[c][j] / sqrt(d_k),  r = h * n_ctx + c
+    //   out    = noT^T p + b_o       noT[r][j] = sum_{i in head h} Wo[j][i] V[c][i]
+    float *mqT[2], *mq_c[2], *noT[2]; // [D][D], [D], [D][D] per list (used when 1 < entries and heads * entries <= D)
+    // the predictor's projection (predictor.py:198) is evaluated here too: x = proj_wt^T h + proj_b, from the LSTM's last
+    // layer output (k-major [Hp][NLp]) -- one launch per decision less than a projection GEMM of its own
+    const float *proj_wt, *proj_b, *h_lastT;
+    int Hp, P, proj_ld, NLp;
+    // ... and where the hidden size allows (Hp <= D) it is composed into what consumes x: nothing non-linear sits between
+    // the projection and the query / combine Linears, so  combine[:, :D] (Wp h + bp) = c1p_wt^T h + c1p_b  (per handle,
+    // float64 sums) and  scores = mqpT^T h + mqp_c  (per call, short lists) -- one dependent matrix-vector stage less
+    float *c1p_wt, *c1p_b;            // [Hp][D], [D]
+    float *cold_cp;                   // [D] cold_c with the composed bias: the one-entry empty list's whole constant
+    float *mqpT[2], *mqp_c[2];        // [Hp][D], [D] per list
 };
 
 // K / V projections of an encoded context list: out[c][j] = b[j] + sum_k hidden[c][k] * W[j][k].
@@ -1342,6 +1356,71 @@ __device__ __forceinline__ void block_gemv_kmajor(const float *__restrict__ WT, 
     __syncthreads();
 }
 
+// c1p_wt[i][j] = sum_p combine_w[j][p] * Wp[p][i],  c1p_b[j] = combine_b[j] + sum_p combine_w[j][p] * bp[p]   (p < P = D: the
+// first half of the combine Linear's input); float64 sums rounded once.  proj_wt is the handle's k-major projection weight.
+__global__ void hw_compose_kernel(const float *__restrict__ cw /* [D][2D] */, const float *__restrict__ cb,
+                                  const float *__restrict__ proj_wt /* [Hp][Pn] */, const float *__restrict__ proj_b, int D, int P,
+                                  int H, int Hp, int Pn, float *__restrict__ wt /* [Hp][D] */, float *__restrict__ bias)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)Hp * D) {
+        const int i = (int)(idx / D), j = (int)(idx - (long)i * D);
+        double a = 0.0;
+        if (i < H)
+            for (int p = 0; p < P; ++p) a += (double)cw[(size_t)j * 2 * D + p] * (double)proj_wt[(size_t)i * Pn + p];
+        wt[idx] = (float)a;
+    } else if (idx < (long)Hp * D + D) {
+        const int j = (int)(idx - (long)Hp * D);
+        double a = (double)cb[j];
+        for (int p = 0; p < P; ++p) a += (double)cw[(size_t)j * 2 * D + p] * (double)proj_b[p];
+        bias[j] = (float)a;
+    }
+}
+
+// Per call, per list with heads * entries <= D: the query projection folded into the keys and the output projection folded
+// into the values (see HwDev).  One workgroup per (head, entry) row r.
+__global__ __launch_bounds__(256) void hw_fold_kernel(HwDev hw, int list, int nctx)
+{
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int D = hw.D, dk = D / hw.heads;
+    const int hh = r / nctx, c = r - hh * nctx;
+    const float *__restrict__ kr = hw.kbuf[list] + (size_t)c * D + hh * dk;
+    const float *__restrict__ vr = hw.vbuf[list] + (size_t)c * D + hh * dk;
+    const float inv = 1.f / sqrtf((float)dk);
+    const int R = hw.heads * nctx;
+    for (int k = tid; k < D; k += 256) {
+        const float *__restrict__ wq = hw.q_wt + (size_t)k * D + hh * dk;      // q_wt is k-major: [in k][out j]
+        float a = 0.f;
+        for (int j = 0; j < dk; ++j) a = fmaf(wq[j], kr[j], a);
+        hw.mqT[list][(size_t)k * R + r] = a * inv;
+        float o = 0.f;
+        for (int i = 0; i < dk; ++i) o = fmaf(hw.o_wt[(size_t)(hh * dk + i) * D + k], vr[i], o);   // o_wt: [in i][out j = k here]
+        hw.noT[list][(size_t)r * D + k] = o;
+    }
+    if (tid == 0) {
+        float a = 0.f;
+        for (int j = 0; j < dk; ++j) a = fmaf(hw.q_b[hh * dk + j], kr[j], a);
+        hw.mq_c[list][r] = a * inv;
+    }
+    if (hw.proj_wt == nullptr || hw.Hp > D) return;
+    // ... and the predictor's projection composed in front: mqpT[i][r] = sum_k Wp[k][i] mqT[k][r]
+    __syncthreads();                                          // this workgroup's column of mqT is complete
+    __shared__ float mcol[1024];
+    for (int k = tid; k < D; k += 256) mcol[k] = hw.mqT[list][(size_t)k * R + r];
+    __syncthreads();
+    for (int i = tid; i < hw.Hp; i += 256) {
+        const float *__restrict__ wp = hw.proj_wt + (size_t)i * hw.proj_ld;
+        float a = 0.f;
+        for (int k = 0; k < D; ++k) a = fmaf(wp[k], mcol[k], a);
+        hw.mqpT[list][(size_t)i * R + r] = a;
+    }
+    if (tid == 0) {
+        float a = hw.mq_c[list][r];
+        for (int k = 0; k < D; ++k) a = fmaf(hw.proj_b[k], mcol[k], a);
+        hw.mqp_c[list][r] = a;
+    }
+}
+
 // ContextBias.forward_predictor_bias (context_bias.py:375-381) for the lanes whose predictor has just stepped, with
 // the list the gate selected (cur_gate: 1 = hot words, 0 = empty list -- greedy_search.py:357,394-395 evaluate the hot
 // variant first and replace it when the gate says 0; only the one that reaches the joiner is computed here):
@@ -1362,13 +1441,57 @@ __global__ __launch_bounds__(kHwThreads) void hw_bias_kernel(DevState *sp, HwDev
     const float *__restrict__ Vb = hw.vbuf[g];
     float *x = sm, *q = sm + D, *ctx = sm + 2 * D, *o = sm + 3 * D, *pb = sm + 4 * D;
     float *part = sm + 5 * D, *p = part + (kHwThreads / 64) * D;
-    for (int j = tid; j < D; j += kHwThreads) x[j] = S.outT[(size_t)j * d.NLp + n];
-    __syncthreads();
+    // x = projection(h_last) (predictor.py:198): the lane's column of the k-major LSTM output through LDS
+    // (stateless predictors have no projection: their kernels leave the output in outT)
+    const bool short_list = nctx > 1 && hw.heads * nctx <= D;     // (a function of the call's list length: hw_fold_kernel ran)
+    const bool composed = hw.proj_wt != nullptr && hw.Hp <= D && (short_list || (g == 0 && nctx == 1));
+    float *hcol = pb;                                             // the lane's LSTM output (pb is free until the first LayerNorm)
+    if (composed) {
+        for (int j = tid; j < hw.Hp; j += kHwThreads) hcol[j] = hw.h_lastT[(size_t)j * hw.NLp + n];
+        __syncthreads();
+    } else if (hw.proj_wt != nullptr) {
+        for (int j = tid; j < hw.Hp; j += kHwThreads) q[j] = hw.h_lastT[(size_t)j * hw.NLp + n];
+        __syncthreads();
+        block_gemv_kmajor(hw.proj_wt, hw.proj_ld, hw.proj_b, q, hw.Hp, hw.P, part, x);
+    } else {
+        for (int j = tid; j < D; j += kHwThreads) x[j] = S.outT[(size_t)j * d.NLp + n];
+        __syncthreads();
+    }
     if (g == 0 && nctx == 1) {
         // The empty list has ONE entry: softmax over one score is exactly 1, the context is exactly that entry's value
         // row, so the bias feature -- and the second half of the combine Linear applied to it -- is the same vector
         // for every step of the call (hw_cold_kernel computed it once).  Only the first half depends on the predictor.
-        block_gemv_kmajor(hw.c_wt, D, hw.cold_c, x, D, D, part, ctx);
+        if (composed) block_gemv_kmajor(hw.c1p_wt, D, hw.cold_cp, hcol, hw.Hp, D, part, ctx);
+        else block_gemv_kmajor(hw.c_wt, D, hw.cold_c, x, D, D, part, ctx);
+        block_layer_norm(ctx, D, hw.on_w, hw.on_b, sv, [&](int j, float v) { S.biasT[(size_t)j * d.NLp + n] = v; });
+        return;
+    }
+    if (short_list) {
+        // short list: scores and the attention output as ONE matrix-vector product each (folded projections, HwDev)
+        const int R = hw.heads * nctx;
+        if (composed) {
+            block_gemv_kmajor(hw.mqpT[g], R, hw.mqp_c[g], hcol, hw.Hp, R, part, p);
+            block_gemv_kmajor(hw.c1p_wt, D, hw.c1p_b, hcol, hw.Hp, D, part, q);   // first half of the combine Linear
+        } else {
+            block_gemv_kmajor(hw.mqT[g], R, hw.mq_c[g], x, D, R, part, p);
+            block_gemv_kmajor(hw.c_wt, D, hw.c_b, x, D, D, part, q);        // first half of the combine Linear (needs x only)
+        }
+        {   // softmax over the list, one wave per head (torch.softmax: exp(x - max) / sum)
+            const int lane = tid & 63, wave = tid >> 6;
+            for (int hh = wave; hh < hw.heads; hh += kHwThreads / 64) {
+                float mx = -3.0e38f;
+                for (int c = lane; c < nctx; c += 64) mx = fmaxf(mx, p[hh * nctx + c]);
+                mx = wave_max(mx);
+                float ssum = 0.f;
+                for (int c = lane; c < nctx; c += 64) { const float e = expf(p[hh * nctx + c] - mx); p[hh * nctx + c] = e; ssum += e; }
+                ssum = wave_sum(ssum);
+                for (int c = lane; c < nctx; c += 64) p[hh * nctx + c] = p[hh * nctx + c] / ssum;
+            }
+        }
+        __syncthreads();
+        block_gemv_kmajor(hw.noT[g], D, hw.o_b, p, R, D, part, o);
+        block_layer_norm(o, D, hw.bn_w, hw.bn_b, sv, [&](int j, float v) { pb[j] = v; });
+        block_gemv_kmajor(hw.c_wt + (size_t)D * D, D, q, pb, D, D, part, ctx);
         block_layer_norm(ctx, D, hw.on_w, hw.on_b, sv, [&](int j, float v) { S.biasT[(size_t)j * d.NLp + n] = v; });
         return;
     }
@@ -1449,7 +1572,10 @@ __global__ __launch_bounds__(kHwThreads) void hw_cold_kernel(HwDev hw)
     block_gemv_kmajor(hw.o_wt, D, hw.o_b, v, D, D, part, o);
     block_layer_norm(o, D, hw.bn_w, hw.bn_b, sv, [&](int j, float val) { pb[j] = val; });
     block_gemv_kmajor(hw.c_wt + (size_t)D * D, D, hw.c_b, pb, D, D, part, o);
-    for (int j = tid; j < D; j += kHwThreads) hw.cold_c[j] = o[j];
+    for (int j = tid; j < D; j += kHwThreads) {
+        hw.cold_c[j] = o[j];
+        if (hw.proj_wt != nullptr && hw.Hp <= D) hw.cold_cp[j] = o[j] + (hw.c1p_b[j] - hw.c_b[j]);   // + combine[:, :D] . bp
+    }
 }
 
 __global__ void greedy_hw_init_kernel(DevState *s)
@@ -2755,7 +2881,8 @@ extern "C" int wr_predictor_step(wr_decoder *h, const int32_t *tokens_d, const f
 namespace {
 
 struct HwCarve {
-    size_t q_wt, o_wt, c_wt, kbuf[2], vbuf[2], cold_c, gate_tab, ep2, state, biasT, total;
+    size_t q_wt, o_wt, c_wt, kbuf[2], vbuf[2], cold_c, mqT[2], mq_c[2], noT[2], c1p_wt, c1p_b, cold_cp, mqpT[2], mqp_c[2], gate_tab,
+        ep2, state, biasT, total;
 };
 
 HwCarve hw_carve(const wr_decoder *h, int D, int max_ctx)
@@ -2769,6 +2896,13 @@ HwCarve hw_carve(const wr_decoder *h, int D, int max_ctx)
     c.c_wt = take((size_t)2 * D * D * sizeof(float));
     for (int i = 0; i < 2; ++i) { c.kbuf[i] = take((size_t)max_ctx * D * sizeof(float)); c.vbuf[i] = take((size_t)max_ctx * D * sizeof(float)); }
     c.cold_c = take((size_t)D * sizeof(float));
+    for (int i = 0; i < 2; ++i) {
+        c.mqT[i] = take((size_t)D * D * sizeof(float)); c.mq_c[i] = take((size_t)D * sizeof(float));
+        c.noT[i] = take((size_t)D * D * sizeof(float));
+        c.mqpT[i] = take((size_t)d.Hp * D * sizeof(float)); c.mqp_c[i] = take((size_t)D * sizeof(float));
+    }
+    c.c1p_wt = take((size_t)d.Hp * D * sizeof(float)); c.c1p_b = take((size_t)D * sizeof(float));
+    c.cold_cp = take((size_t)D * sizeof(float));
     c.gate_tab = take((size_t)h->max_utt * h->Tmax * sizeof(int32_t));
     c.ep2 = take((size_t)2 * h->max_utt * h->Tmax * d.J * sizeof(float));
     c.state = take((size_t)4 * d.NLp * sizeof(int32_t));
@@ -2787,6 +2921,8 @@ int hw_check(const wr_decoder *h, const wr_hotword_weights *hw, int max_ctx)
     WR_REQUIRE(hw->dim <= 512 && hw->hw_dim <= 256 && hw->n_labels <= 8 && hw->dim % hw->heads == 0 && hw->heads <= 16, WR_EUNSUPPORTED,
                "hotword: dim=%d (<= 512), hw_dim=%d (<= 256), n_labels=%d (<= 8), heads=%d (divides dim, <= 16)", hw->dim,
                hw->hw_dim, hw->n_labels, hw->heads);
+    WR_REQUIRE(h->d.ptype != kPredLstm || h->d.Hp <= 4 * hw->dim, WR_EUNSUPPORTED,
+               "hotword: LSTM hidden size %d exceeds 4 * dim (%d)", h->d.H, hw->dim);
     WR_REQUIRE((size_t)(21 * hw->dim + hw->heads * max_ctx) * sizeof(float) <= 60 * 1024, WR_EUNSUPPORTED,
                "hotword: max_ctx=%d does not fit the bias kernel's LDS", max_ctx);
     WR_REQUIRE(hw->q_w && hw->q_b && hw->k_w && hw->k_b && hw->v_w && hw->v_b && hw->o_w && hw->o_b && hw->bias_norm_w &&
@@ -2801,7 +2937,8 @@ void hw_micro_step(wr_decoder *h, int n_lanes, hipStream_t st)
     const Dims &d = h->d;
     const DevState &s = h->host;
     auto up = [](int x, int m) { return (x + m - 1) / m * m; };
-    launch_predictor(h, n_lanes, st);
+    // LSTM predictor: the projection runs inside hw_bias_kernel; stateless predictors write outT themselves
+    const bool recurrent_pending = launch_predictor(h, n_lanes, st, d.ptype != kPredLstm);
     const size_t lds = (size_t)(21 * h->hw.D + h->hw.heads * h->hw.max_ctx) * sizeof(float);
     hipLaunchKernelGGL(hw_bias_kernel, dim3(n_lanes), dim3(kHwThreads), lds, st, h->dev, h->hw);
     {   // pred_ffn of the biased predictor output; the joiner activation takes the encoder stream the gate selected
@@ -2814,7 +2951,10 @@ void hw_micro_step(wr_decoder *h, int n_lanes, hipStream_t st)
 #ifdef WR_STAMPS
         g.dbg_slot = 2;
 #endif
-        launch_gemm<kEpiJointAct>(g, up(d.J, 32), n_lanes, st);
+        if (recurrent_pending)
+            launch_gemm_pair<kEpiJointAct, kEpiSlotRow>(g, up(d.J, 32), recurrent_job(h, d.L - 1, n_lanes, s.new_slot), d.G4p, n_lanes, st);
+        else
+            launch_gemm<kEpiJointAct>(g, up(d.J, 32), n_lanes, st);
     }
     GemmArgs g{};
 #ifdef WR_STAMPS
@@ -2864,6 +3004,26 @@ extern "C" int wr_decoder_attach_hotword(wr_decoder *h, const wr_hotword_weights
         v.vbuf[i] = reinterpret_cast<float *>(ws + c.vbuf[i]);
     }
     v.cold_c = reinterpret_cast<float *>(ws + c.cold_c);
+    for (int i = 0; i < 2; ++i) {
+        v.mqT[i] = reinterpret_cast<float *>(ws + c.mqT[i]); v.mq_c[i] = reinterpret_cast<float *>(ws + c.mq_c[i]);
+        v.noT[i] = reinterpret_cast<float *>(ws + c.noT[i]);
+        v.mqpT[i] = reinterpret_cast<float *>(ws + c.mqpT[i]); v.mqp_c[i] = reinterpret_cast<float *>(ws + c.mqp_c[i]);
+    }
+    v.c1p_wt = reinterpret_cast<float *>(ws + c.c1p_wt); v.c1p_b = reinterpret_cast<float *>(ws + c.c1p_b);
+    v.cold_cp = reinterpret_cast<float *>(ws + c.cold_cp);
+    {
+        const Dims &dd = h->d;
+        auto up32 = [](int x) { return (x + 31) / 32 * 32; };
+        v.proj_wt = dd.ptype == kPredLstm ? h->host.proj_wt : nullptr; v.proj_b = h->host.proj_b;
+        v.h_lastT = h->host.new_hT + (size_t)(dd.L - 1) * dd.Hp * dd.NLp;
+        v.Hp = dd.Hp; v.P = dd.P; v.proj_ld = up32(dd.P); v.NLp = dd.NLp;
+        if (v.proj_wt != nullptr && dd.Hp <= D) {
+            const long nn = (long)dd.Hp * D + D;
+            hipLaunchKernelGGL(hw_compose_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, hw->combine_w, hw->combine_b,
+                               v.proj_wt, v.proj_b, D, dd.P, dd.H, dd.Hp, v.proj_ld, v.c1p_wt, v.c1p_b);
+            WR_CHECK_LAUNCH("decoder_attach_hotword (composed projection)");
+        }
+    }
     v.gate_tab = reinterpret_cast<int32_t *>(ws + c.gate_tab);
     h->hw_ep2 = reinterpret_cast<float *>(ws + c.ep2);
     h->hw_state = reinterpret_cast<int32_t *>(ws + c.state);
@@ -2909,6 +3069,12 @@ extern "C" int wr_greedy_search_hotword(wr_decoder *h, const float *enc_hot_d, c
     // loop-invariant work: list projections, the gate of every frame, enc_ffn of both encoder streams
     hipLaunchKernelGGL(hw_kv_kernel, dim3(n_ctx_cold, 2), dim3(256), 0, st, h->hw, hidden_cold_d, 0);
     hipLaunchKernelGGL(hw_kv_kernel, dim3(n_ctx_hot, 2), dim3(256), 0, st, h->hw, hidden_hot_d, 1);
+    {   // short lists: fold the query / output projections into K / V once per call
+        const int nc[2] = {n_ctx_cold, n_ctx_hot};
+        for (int i = 0; i < 2; ++i)
+            if (nc[i] > 1 && h->hw.heads * nc[i] <= h->hw.D)
+                hipLaunchKernelGGL(hw_fold_kernel, dim3(h->hw.heads * nc[i]), dim3(256), 0, st, h->hw, i, nc[i]);
+    }
     if (n_ctx_cold == 1)
         hipLaunchKernelGGL(hw_cold_kernel, dim3(1), dim3(kHwThreads), (size_t)(3 + kHwThreads / 64) * h->hw.D * sizeof(float), st, h->hw);
     hipLaunchKernelGGL(hw_gate_table_kernel, dim3((unsigned)((long)N * T)), dim3(256),
