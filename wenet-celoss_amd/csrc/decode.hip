@@ -1240,6 +1240,8 @@ struct HwDev {
     float *c1p_wt, *c1p_b;            // [Hp][D], [D]
     float *cold_cp;                   // [D] cold_c with the composed bias: the one-entry empty list's whole constant
     float *mqpT[2], *mqp_c[2];        // [Hp][D], [D] per list
+    // handle-constant pointers of the lane state the bias kernel starts from (kernel arguments: no wait for the state block)
+    const int32_t *lane_active, *need_pred, *cur_gate;
 };
 
 // K / V projections of an encoded context list: out[c][j] = b[j] + sum_k hidden[c][k] * W[j][k].
@@ -1431,11 +1433,15 @@ __global__ __launch_bounds__(kHwThreads) void hw_bias_kernel(DevState *sp, HwDev
 {
     extern __shared__ float sm[];                   // x[D] q[D] ctx[D] o[D] pb[D] | part[16][D] | p[heads * max_ctx]
     __shared__ float sv[kHwThreads / 64];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    // the lane's flags and (below) its LSTM output are requested through the kernel-argument pointers, beside the load of
+    // the state block instead of behind it
+    const int la = hw.lane_active[n], np = hw.need_pred[n], gate = hw.cur_gate[n];
+    const float h_early = (hw.proj_wt != nullptr && tid < hw.Hp) ? hw.h_lastT[(size_t)tid * hw.NLp + n] : 0.f;   // Hp <= 1024 = threads
     const DevState S = *sp;
     const Dims &d = S.d;
-    const int n = blockIdx.x, tid = threadIdx.x;
-    if (!S.lane_active[n] || !S.need_pred[n]) return;             // after a blank the predictor output is kept
-    const int D = hw.D, g = S.cur_gate[n] ? 1 : 0;
+    if (!la || !np) return;                                       // after a blank the predictor output is kept
+    const int D = hw.D, g = gate ? 1 : 0;
     const int nctx = S.hw_nctx[g];
     const float *__restrict__ Kb = hw.kbuf[g];
     const float *__restrict__ Vb = hw.vbuf[g];
@@ -1447,10 +1453,10 @@ __global__ __launch_bounds__(kHwThreads) void hw_bias_kernel(DevState *sp, HwDev
     const bool composed = hw.proj_wt != nullptr && hw.Hp <= D && (short_list || (g == 0 && nctx == 1));
     float *hcol = pb;                                             // the lane's LSTM output (pb is free until the first LayerNorm)
     if (composed) {
-        for (int j = tid; j < hw.Hp; j += kHwThreads) hcol[j] = hw.h_lastT[(size_t)j * hw.NLp + n];
+        if (tid < hw.Hp) hcol[tid] = h_early;
         __syncthreads();
     } else if (hw.proj_wt != nullptr) {
-        for (int j = tid; j < hw.Hp; j += kHwThreads) q[j] = hw.h_lastT[(size_t)j * hw.NLp + n];
+        if (tid < hw.Hp) q[tid] = h_early;
         __syncthreads();
         block_gemv_kmajor(hw.proj_wt, hw.proj_ld, hw.proj_b, q, hw.Hp, hw.P, part, x);
     } else {
@@ -3009,6 +3015,8 @@ extern "C" int wr_decoder_attach_hotword(wr_decoder *h, const wr_hotword_weights
         v.noT[i] = reinterpret_cast<float *>(ws + c.noT[i]);
         v.mqpT[i] = reinterpret_cast<float *>(ws + c.mqpT[i]); v.mqp_c[i] = reinterpret_cast<float *>(ws + c.mqp_c[i]);
     }
+    v.lane_active = h->host.lane_active; v.need_pred = h->host.need_pred;
+    v.cur_gate = reinterpret_cast<const int32_t *>(ws + c.state);          // = h->hw_state (cur_gate is its first NLp words)
     v.c1p_wt = reinterpret_cast<float *>(ws + c.c1p_wt); v.c1p_b = reinterpret_cast<float *>(ws + c.c1p_b);
     v.cold_cp = reinterpret_cast<float *>(ws + c.cold_cp);
     {
