@@ -479,7 +479,10 @@ def test_two_rank_ddp_at_librispeech_shapes(tmp_path):
     checked = 0
     for n in per_rank[0]:
         want = (per_rank[0][n] + per_rank[1][n]) / 2
-        tol = 2e-5 * float(want.abs().max()) + 1e-7 * top
+        # two separately started processes against this one: the library GEMMs' split-K / atomics and the CTC kernel's LDS
+        # float atomics sum in run-dependent order, and the stand-in encoder is 48 layers deep -- 2e-4 of the tensor's
+        # largest entry (a wrong all-reduce, a missed no_sync or a wrong 1 / world_size shows at the 0.5 level)
+        tol = 2e-4 * float(want.abs().max()) + 1e-6 * top
         for r in range(2):
             assert float((got[r]["grads"][n] - want).abs().max()) <= tol, (n, r)
         checked += 1
