@@ -175,6 +175,9 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
     const u32x4 *__restrict__ wll = wl + lane;
 
     auto load_set = [&](int ci, u32x4 (&bh)[PF][kSCT], u32x4 (&bl)[PF][kSCT]) {
+#ifdef WR_X_NOLOAD
+        if (ci >= 2) return;                                // experiment: the k-loop without its W stream
+#endif
         const int cc = ci < total ? ci : total - 1;
         const int r = cc / cpr, c0 = cc - r * cpr;
         const int pr = r * kSWaves + wave;
@@ -303,6 +306,17 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
             constexpr int SROW = ROWB + 16;                                 // padded stage row (bank spread)
             if (full && stage_ok) {
                 char *stg = stage + (size_t)wave * 32 * SROW;
+#ifdef WR_X_NOEPI
+                {                                           // experiment: the k-loop without its epilogue
+                    float sum = 0.f;
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int c = 0; c < kSCT; ++c) { sum += acc[rt][c][0] + acc[rt][c][7]; acc[rt][c] = (f32x16){0}; }
+                    if (sum == 1.2345e30f) out[0] = to_out<OutT>(sum);
+                    return;
+                }
+#endif
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
@@ -325,6 +339,9 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
                     for (int i = 0; i < 32 / RPI; ++i) {
                         const int row = i * RPI + rr;
                         const u32x4 v = *reinterpret_cast<const u32x4 *>(stg + row * SROW + seg * 16);
+#ifdef WR_X_NOSTORE
+                        if (v.x == 0x7fc12345u && v.y == 0x7fc12345u)   // experiment: the epilogue without its global stores
+#endif
                         *reinterpret_cast<u32x4 *>(obase + (size_t)row * V * sizeof(OutT)) = v;
                     }
                     __builtin_amdgcn_wave_barrier();
