@@ -41,6 +41,18 @@ constexpr int kSCT = 2;          // 32-column tiles per wave per round
 constexpr int kSWaves = 4;       // one per SIMD, 512 registers each: three fragment sets without register reuse stalls
 constexpr int kSPF = 4;          // k-steps (of 16) per register set; three sets rotate, two are in flight
 
+// ---- diagnostic build only (-DWR_JS_STAMPS, tools/amp_stamps.py): s_memtime / s_memrealtime stamps of the forward
+// kernel's phases, one record per wave of every 16th workgroup; the values go to a buffer nothing else reads.
+#ifdef WR_JS_STAMPS
+constexpr int kJsWgs = 2048, kJsPts = 12;
+__device__ unsigned long long g_js[kJsWgs * kSWaves * kJsPts];
+#define WR_JS_NOW(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WR_JS_NOW_RT(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define WR_JS_NOW(v)
+#define WR_JS_NOW_RT(v)
+#endif
+
 inline int split_jpad(int J) { return (J + 16 * kSPF - 1) / (16 * kSPF) * (16 * kSPF); }
 inline int split_vpad(int V) { return (V + 32 * kSCT - 1) / (32 * kSCT) * (32 * kSCT); }
 
@@ -115,8 +127,13 @@ template <> __device__ __forceinline__ __bf16 to_out<__bf16>(float x) { return (
 // one bf16 image of 128 x J fits LDS where the hi + lo images of the split modes do not).  A workgroup streams ALL of W
 // for its cells, so 128 cells halve the W traffic per logit -- the stream out of the L2s is what bounds this kernel
 // (round 2: 9.7 TB/s at 64 cells).  A wave then owns 4 x 2 accumulator tiles per round.
-template <int TERMS, typename OutT, bool LSE = false, int RT = 2>
-__global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
+// OCC = workgroups per CU the kernel is built for: 1 (512 registers per wave) or, single-term mode with 64 cells only, 2
+// (256 registers per wave, LDS <= 80 KB: the bias comes from memory a round ahead instead of from an LDS slab, the store
+// stage takes 16 or 8 rows at a time) -- with one wave per SIMD nothing overlaps a workgroup's tile build, the issue of
+// its W loads (the CU's 64 B/clk vector-memory path is busy for as long as the MFMAs of the set) and its epilogues;
+// a second workgroup's MFMAs do (stamps: profiles/r03_amp_stamps_*.json).
+template <int TERMS, typename OutT, bool LSE = false, int RT = 2, int OCC = 1>
+__global__ __launch_bounds__(64 * kSWaves, OCC) void joint_fwd_split_kernel(
     const float *__restrict__ ep, const float *__restrict__ pp, const u32x4 *__restrict__ wh, const u32x4 *__restrict__ wl,
     const float *__restrict__ bias, const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens, int B, int T,
     int U1, int J, int Jp, int V, int Vp, int npart, int act, OutT *__restrict__ out, JointLse lse = JointLse{},
@@ -126,6 +143,7 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
     constexpr int SM = 32 * RT;                            // lattice cells of this workgroup
     constexpr int PF = RT == 4 ? 2 : kSPF;                 // k-steps per register set (eight accumulator tiles leave room for less)
     static_assert(RT == 2 || (RT == 4 && TERMS == 1 && !LSE), "128-cell tiles: single-term mode without row statistics");
+    static_assert(OCC == 1 || (OCC == 2 && RT == 2 && TERMS == 1 && !LSE), "two workgroups per CU: single-term mode, 64 cells");
     const int JS = Jp + 8;                                 // padded row stride (bf16 elements): 16-byte pad
     unsigned short *Ahi = lds_s;                            // [SM][JS]
     unsigned short *Alo = lds_s + (size_t)SM * JS;          // [SM][JS]   (TERMS == 3)
@@ -142,6 +160,12 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
     const long m0 = (long)(blockIdx.x / npart) * SM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
+#ifdef WR_JS_STAMPS
+    unsigned long long js_t0 = 0, js_r0 = 0, js_t1 = 0, js_t2 = 0, js_r2 = 0, js_a = 0, js_b = 0, js_c = 0, js_d = 0;
+    unsigned long long js_ld = 0, js_mm = 0, js_ep = 0, js_ep_n = 0, js_mm_first = 0;
+    WR_JS_NOW_RT(js_r0);
+    WR_JS_NOW(js_t0);
+#endif
     float rm[32], rs[32];                                   // LSE: this lane's (reference, partial sum) of its 32 rows
     if (LSE) {
 #pragma unroll
@@ -196,10 +220,23 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
     u32x4 pbh[PF][kSCT], pbl[PF][kSCT], qbh[PF][kSCT], qbl[PF][kSCT], rbh[PF][kSCT], rbl[PF][kSCT];
 
     // bias of this part's columns -> LDS (read back per round without touching the vector-memory counter)
-    for (int i = tid; i < npairs * 32 * kSCT; i += 64 * kSWaves) {
-        const int col = pair0 * 32 * kSCT + i;
-        bias_s[i] = col < V ? bias[col] : 0.f;
+    if (OCC == 1) {
+        for (int i = tid; i < npairs * 32 * kSCT; i += 64 * kSWaves) {
+            const int col = pair0 * 32 * kSCT + i;
+            bias_s[i] = col < V ? bias[col] : 0.f;
+        }
     }
+    float bvr[kSCT] = {0.f, 0.f};                           // OCC == 2: this lane's bias values of the current round
+    auto next_bias = [&](int r) {
+        if (OCC == 1) return;
+        const int pr = r * kSWaves + wave;
+#pragma unroll
+        for (int c = 0; c < kSCT; ++c) {
+            const int col = ((pair0 + pr) * kSCT + c) * 32 + l31;
+            bvr[c] = (pr < npairs && col < V) ? bias[col] : 0.f;
+        }
+    };
+    next_bias(0);
     // activation tile: a wave takes rows wave, wave+4, ...; four rows (32 loads per lane) in flight at a time;
     // a lane owns the k pairs 2*lane + 128*i (packed 32-bit LDS writes)
     constexpr int KI = 4;                                   // Jp <= 512: at most 4 k pairs per lane per row
@@ -245,6 +282,7 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
         }
     }
     __syncthreads();
+    WR_JS_NOW(js_t1);
 
     const unsigned short *a_hi = Ahi + (size_t)l31 * JS + 8 * half;
     const unsigned short *a_lo = Alo + (size_t)l31 * JS + 8 * half;
@@ -304,8 +342,10 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
             // B = 8 BASELINE slice, bf16 logits: 12.1 -> see DESIGN.md section 6.
             constexpr int ROWB = kSCT * 32 * (int)sizeof(OutT);            // bytes of the wave's 64 columns in one row
             constexpr int SROW = ROWB + 16;                                 // padded stage row (bank spread)
+            constexpr int SR = OCC == 2 ? (sizeof(OutT) == 4 ? 8 : 16) : 32; // rows staged per pass
+            constexpr int GP = SR / 8;                                      // accumulator row groups (of 8 rows) per pass
             if (full && stage_ok) {
-                char *stg = stage + (size_t)wave * 32 * SROW;
+                char *stg = stage + (size_t)wave * SR * SROW;
 #ifdef WR_X_NOEPI
                 {                                           // experiment: the k-loop without its epilogue
                     float sum = 0.f;
@@ -314,38 +354,47 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
 #pragma unroll
                         for (int c = 0; c < kSCT; ++c) { sum += acc[rt][c][0] + acc[rt][c][7]; acc[rt][c] = (f32x16){0}; }
                     if (sum == 1.2345e30f) out[0] = to_out<OutT>(sum);
+                    next_bias(r + 1);
                     return;
                 }
 #endif
+                float bv[kSCT];
+#pragma unroll
+                for (int c = 0; c < kSCT; ++c) bv[c] = OCC == 2 ? bvr[c] : bias_s[(pr * kSCT + c) * 32 + l31];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
-                    for (int c = 0; c < kSCT; ++c) {
-                        const float bv = bias_s[(pr * kSCT + c) * 32 + l31];
+                    for (int g0 = 0; g0 < 4; g0 += GP) {
 #pragma unroll
-                        for (int q = 0; q < 16; ++q) {
-                            const int row = (q & 3) + 8 * (q >> 2) + 4 * half;
-                            *reinterpret_cast<OutT *>(stg + row * SROW + (c * 32 + l31) * (int)sizeof(OutT)) = to_out<OutT>(acc[rt][c][q] + bv);
+                        for (int c = 0; c < kSCT; ++c) {
+#pragma unroll
+                            for (int q = 4 * g0; q < 4 * (g0 + GP); ++q) {
+                                const int row = (q & 3) + 8 * ((q >> 2) - g0) + 4 * half;
+                                *reinterpret_cast<OutT *>(stg + row * SROW + (c * 32 + l31) * (int)sizeof(OutT)) =
+                                    to_out<OutT>(acc[rt][c][q] + bv[c]);
+                            }
                         }
-                        acc[rt][c] = (f32x16){0};
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    constexpr int LPR = ROWB / 16;                          // lanes per row: 8 (16-bit logits) or 16 (fp32)
-                    constexpr int RPI = 64 / LPR;                           // rows per store instruction
-                    const int rr = lane / LPR, seg = lane - rr * LPR;
-                    char *obase = reinterpret_cast<char *>(out + (size_t)(m0 + 32 * rt) * V + (size_t)ct0 * 32) + seg * 16;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        constexpr int LPR = ROWB / 16;                      // lanes per row: 8 (16-bit logits) or 16 (fp32)
+                        constexpr int RPI = 64 / LPR;                       // rows per store instruction
+                        const int rr = lane / LPR, seg = lane - rr * LPR;
+                        char *obase = reinterpret_cast<char *>(out + (size_t)(m0 + 32 * rt + 8 * g0) * V + (size_t)ct0 * 32) + seg * 16;
 #pragma unroll
-                    for (int i = 0; i < 32 / RPI; ++i) {
-                        const int row = i * RPI + rr;
-                        const u32x4 v = *reinterpret_cast<const u32x4 *>(stg + row * SROW + seg * 16);
+                        for (int i = 0; i < SR / RPI; ++i) {
+                            const int row = i * RPI + rr;
+                            const u32x4 v = *reinterpret_cast<const u32x4 *>(stg + row * SROW + seg * 16);
 #ifdef WR_X_NOSTORE
-                        if (v.x == 0x7fc12345u && v.y == 0x7fc12345u)   // experiment: the epilogue without its global stores
+                            if (v.x == 0x7fc12345u && v.y == 0x7fc12345u)   // experiment: the epilogue without its global stores
 #endif
-                        *reinterpret_cast<u32x4 *>(obase + (size_t)row * V * sizeof(OutT)) = v;
+                            *reinterpret_cast<u32x4 *>(obase + (size_t)row * V * sizeof(OutT)) = v;
+                        }
+                        __builtin_amdgcn_wave_barrier();
                     }
-                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int c = 0; c < kSCT; ++c) acc[rt][c] = (f32x16){0};
                 }
+                next_bias(r + 1);
                 return;
             }
         }
@@ -353,7 +402,7 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
         for (int c = 0; c < kSCT; ++c) {
             const int col = (ct0 + c) * 32 + l31;
             const bool colin = pr < npairs && col < V;
-            const float bv = colin ? bias_s[(pr * kSCT + c) * 32 + l31] : 0.f;
+            const float bv = colin ? (OCC == 2 ? bvr[c] : bias_s[(pr * kSCT + c) * 32 + l31]) : 0.f;
             OutT *__restrict__ ocol = out + (size_t)m0 * V + (colin ? col : 0);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
@@ -378,27 +427,47 @@ __global__ __launch_bounds__(64 * kSWaves) void joint_fwd_split_kernel(
                 acc[rt][c] = (f32x16){0};
             }
         }
+        next_bias(r + 1);
     };
 
+#ifdef WR_JS_STAMPS
+#define WR_JS_PHASE(ci_, ld_, P, Q)                                                                                      \
+    WR_JS_NOW(js_a);                                                                                                      \
+    load_set(ld_, P##bh, P##bl);                                                                                          \
+    WR_JS_NOW(js_b);                                                                                                      \
+    mfma_set(ci_, Q##bh, Q##bl);                                                                                          \
+    WR_JS_NOW(js_c);                                                                                                      \
+    finish_round(ci_);                                                                                                    \
+    WR_JS_NOW(js_d);                                                                                                      \
+    js_ld += js_b - js_a;                                                                                                 \
+    js_mm += js_c - js_b;                                                                                                 \
+    if ((ci_) % cpr == 0) js_mm_first += js_c - js_b;                                                                     \
+    if (((ci_) + 1) % cpr == 0) { js_ep += js_d - js_c; js_ep_n += 1; }
+#else
+#define WR_JS_PHASE(ci_, ld_, P, Q)                                                                                      \
+    load_set(ld_, P##bh, P##bl);                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    mfma_set(ci_, Q##bh, Q##bl);                                                                                          \
+    finish_round(ci_);                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     for (int ci = 0; ci < total; ci += 3) {
-        load_set(ci + 2, rbh, rbl);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_set(ci, pbh, pbl);
-        finish_round(ci);
-        __builtin_amdgcn_sched_barrier(0);
+        WR_JS_PHASE(ci, ci + 2, r, p)
         if (ci + 1 >= total) break;
-        load_set(ci + 3, pbh, pbl);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_set(ci + 1, qbh, qbl);
-        finish_round(ci + 1);
-        __builtin_amdgcn_sched_barrier(0);
+        WR_JS_PHASE(ci + 1, ci + 3, p, q)
         if (ci + 2 >= total) break;
-        load_set(ci + 4, qbh, qbl);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_set(ci + 2, rbh, rbl);
-        finish_round(ci + 2);
-        __builtin_amdgcn_sched_barrier(0);
+        WR_JS_PHASE(ci + 2, ci + 4, q, r)
     }
+#undef WR_JS_PHASE
+#ifdef WR_JS_STAMPS
+    WR_JS_NOW(js_t2);
+    WR_JS_NOW_RT(js_r2);
+    if (lane == 0 && blockIdx.x % 16 == 0 && blockIdx.x / 16 < kJsWgs) {
+        unsigned long long *o = g_js + ((size_t)(blockIdx.x / 16) * kSWaves + wave) * kJsPts;
+        o[0] = js_t0; o[1] = js_t1; o[2] = js_t2; o[3] = js_r0; o[4] = js_r2; o[5] = js_ld; o[6] = js_mm; o[7] = js_ep;
+        o[8] = js_ep_n; o[9] = js_mm_first; o[10] = (unsigned long long)total; o[11] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    }
+#endif
     if (LSE) {
         __syncthreads();                                    // every wave is done with the activation images: reuse them
         joint_lse_finish<kSWaves>(lse, reinterpret_cast<float *>(lds_s), rm, rs, llens, tlens,
@@ -1419,6 +1488,16 @@ int joint_bwd_dw_block(const float *gout_d, const float *h_d, const int32_t *lle
 
 using namespace wr;
 
+#ifdef WR_JS_STAMPS
+extern "C" int wr_debug_read_js_stamps(void *host, size_t n_u64)
+{
+    const size_t have = sizeof(wr::g_js) / sizeof(unsigned long long);
+    if (hipDeviceSynchronize() != hipSuccess) return WR_ELAUNCH;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(wr::g_js), (n_u64 < have ? n_u64 : have) * sizeof(unsigned long long)) == hipSuccess
+               ? WR_OK : WR_ELAUNCH;
+}
+#endif
+
 extern "C" size_t wr_joint_split_workspace_bytes(int J, int V)
 {
     if (J <= 0 || V <= 0) return 0;
@@ -1453,6 +1532,13 @@ int joint_fwd_split_launch(const float *ep_d, const float *pp_d, const float *w_
     const bool wide = terms == 1 && !lse && tune_get(kTuneSplitFwdCells) == 2 && M >= 128 * 512 &&
                       (size_t)128 * (Jp + 8) * sizeof(unsigned short) + (size_t)Vp * sizeof(float) <= 160 * 1024;
     const int cells = wide ? 128 : kSM;
+    // single-term mode, default since round 3: TWO workgroups per CU (256 registers per wave, <= 80 KB of LDS each: no
+    // bias slab, a store stage of 16 / 8 rows) -- wr_tune_set(12, 1) keeps the one-per-CU form
+    const size_t esz0 = out_dtype == 0 ? 4 : 2;
+    const size_t stage2 = (size_t)kSWaves * (esz0 == 4 ? 8 : 16) * (kSCT * 32 * esz0 + 16);
+    const bool two = terms == 1 && !lse && !wide && npart == 1 && tune_get(kTuneSplitFwdCells) != 1 &&
+                     (size_t)kSM * (Jp + 8) * sizeof(unsigned short) + stage2 <= 80 * 1024 &&
+                     ((size_t)V * esz0) % 16 == 0 && (reinterpret_cast<size_t>(out_d) & 15) == 0;
     size_t tile_lds = (size_t)(terms == 3 ? 2 : 1) * cells * (Jp + 8) * sizeof(unsigned short);
     if (lse && tile_lds < joint_lse_exchange_bytes(kSWaves)) tile_lds = joint_lse_exchange_bytes(kSWaves);
     const size_t extra = 0;
@@ -1468,8 +1554,8 @@ int joint_fwd_split_launch(const float *ep_d, const float *pp_d, const float *w_
     const size_t bias_al = align_up(bias_lds, 16);
     const size_t stage_lds = (terms == 1 && !lse) ? (size_t)kSWaves * 32 * (kSCT * 32 * esz + 16) : 0;
     const bool stage_fits = stage_lds > 0 && tile_lds + bias_al + stage_lds <= 160 * 1024;
-    const size_t lds = tile_lds + (stage_fits ? bias_al + stage_lds : bias_lds) + extra;
-    const int kb_bias = (int)bias_al, kb_stage = stage_fits ? 1 : 0;
+    const size_t lds = two ? tile_lds + stage2 : tile_lds + (stage_fits ? bias_al + stage_lds : bias_lds) + extra;
+    const int kb_bias = two ? 0 : (int)bias_al, kb_stage = (two || stage_fits) ? 1 : 0;
     WR_REQUIRE(lds <= 160 * 1024, WR_EUNSUPPORTED, "joint_fwd_split: V=%d needs %zu bytes of LDS", V, lds);
     const dim3 grid((unsigned)((M + cells - 1) / cells * npart));
 #define WR_LAUNCH_SPLIT_WIDE(OutT)                                                                                       \
@@ -1478,6 +1564,15 @@ int joint_fwd_split_launch(const float *ep_d, const float *pp_d, const float *w_
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
         hipLaunchKernelGGL((joint_fwd_split_kernel<1, OutT, false, 4>), grid, dim3(64 * kSWaves), lds, st, ep_d, pp_d, \
                            reinterpret_cast<const u32x4 *>(wh), reinterpret_cast<const u32x4 *>(wl), b_out_d,          \
+                           logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, npart, act, static_cast<OutT *>(out_d), \
+                           JointLse{}, kb_bias, kb_stage);                                                            \
+    } while (0)
+#define WR_LAUNCH_SPLIT_TWO(OutT)                                                                                        \
+    do {                                                                                                              \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_fwd_split_kernel<1, OutT, false, 2, 2>),         \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+        hipLaunchKernelGGL((joint_fwd_split_kernel<1, OutT, false, 2, 2>), grid, dim3(64 * kSWaves), lds, st, ep_d,    \
+                           pp_d, reinterpret_cast<const u32x4 *>(wh), reinterpret_cast<const u32x4 *>(wl), b_out_d,    \
                            logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, npart, act, static_cast<OutT *>(out_d), \
                            JointLse{}, kb_bias, kb_stage);                                                            \
     } while (0)
@@ -1505,6 +1600,10 @@ int joint_fwd_split_launch(const float *ep_d, const float *pp_d, const float *w_
         if (out_dtype == 0) WR_LAUNCH_SPLIT(3, float);
         else if (out_dtype == 1) WR_LAUNCH_SPLIT(3, _Float16);
         else WR_LAUNCH_SPLIT(3, __bf16);
+    } else if (two) {
+        if (out_dtype == 0) WR_LAUNCH_SPLIT_TWO(float);
+        else if (out_dtype == 1) WR_LAUNCH_SPLIT_TWO(_Float16);
+        else WR_LAUNCH_SPLIT_TWO(__bf16);
     } else if (wide) {
         if (out_dtype == 0) WR_LAUNCH_SPLIT_WIDE(float);
         else if (out_dtype == 1) WR_LAUNCH_SPLIT_WIDE(_Float16);
@@ -1515,6 +1614,7 @@ int joint_fwd_split_launch(const float *ep_d, const float *pp_d, const float *w_
         else WR_LAUNCH_SPLIT(1, __bf16);
     }
 #undef WR_LAUNCH_SPLIT_WIDE
+#undef WR_LAUNCH_SPLIT_TWO
 #undef WR_LAUNCH_SPLIT
 #undef WR_LAUNCH_SPLIT_LSE
     WR_CHECK_LAUNCH("joint_fwd_split_kernel");
