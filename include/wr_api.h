@@ -67,7 +67,9 @@ const char *wr_last_error(void);
  * key 8: retired (the 64-cell split dZ tiling was removed), key 9 / key 10: exact dW / dZ tiling (0: 256 x 256 blocks,
  * 1: the first tilings of joint.hip), key 11: greedy / beam micro-step with an LSTM predictor (0: projection folded
  * into pred_ffn -- one launch less, the default; 1: two launches), key 12: single-term (AMP) split joiner forward
- * (0: 64 lattice cells per workgroup, the default; 2: 128 cells -- measured slower).  Keys 6-12 pick between kernels that compute the
+ * (0: 64 lattice cells per workgroup, two workgroups per CU, the default; 1: 64 cells, one workgroup per CU; 2: 128
+ * cells -- measured slower), key 13: its logit stores (0: cell-major tiles through a per-wave LDS stage as whole lines, the
+ * default; 1: transposed tiles stored from registers in 8/16-byte pieces -- measured slower).  Keys 6-13 pick between kernels that compute the
  * same sums; the two dZ tilings are bit-identical, the dW tilings differ in the order of fp32 additions, the folded
  * projection in the rounding of one composed weight matrix (formed in float64). */
 int wr_tune_set(int key, int value);

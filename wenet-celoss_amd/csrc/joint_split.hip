@@ -132,7 +132,11 @@ template <> __device__ __forceinline__ __bf16 to_out<__bf16>(float x) { return (
 // stage takes 16 or 8 rows at a time) -- with one wave per SIMD nothing overlaps a workgroup's tile build, the issue of
 // its W loads (the CU's 64 B/clk vector-memory path is busy for as long as the MFMAs of the set) and its epilogues;
 // a second workgroup's MFMAs do (stamps: profiles/r03_amp_stamps_*.json).
-template <int TERMS, typename OutT, bool LSE = false, int RT = 2, int OCC = 1>
+// TRN (single-term mode): the MFMAs take the W fragment as the A operand and the activation fragment as the B operand
+// (both have the same register layout), so a tile comes out transposed -- a lane holds ONE lattice cell and 4 x 4
+// consecutive vocabulary entries of it, which it adds the bias to, packs and stores itself (8 or 16 bytes per lane and
+// store): no LDS stage, no wave barriers, a quarter of the store instructions of the cell-major layout.
+template <int TERMS, typename OutT, bool LSE = false, int RT = 2, int OCC = 1, bool TRN = false>
 __global__ __launch_bounds__(64 * kSWaves, OCC) void joint_fwd_split_kernel(
     const float *__restrict__ ep, const float *__restrict__ pp, const u32x4 *__restrict__ wh, const u32x4 *__restrict__ wl,
     const float *__restrict__ bias, const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens, int B, int T,
@@ -144,6 +148,7 @@ __global__ __launch_bounds__(64 * kSWaves, OCC) void joint_fwd_split_kernel(
     constexpr int PF = RT == 4 ? 2 : kSPF;                 // k-steps per register set (eight accumulator tiles leave room for less)
     static_assert(RT == 2 || (RT == 4 && TERMS == 1 && !LSE), "128-cell tiles: single-term mode without row statistics");
     static_assert(OCC == 1 || (OCC == 2 && RT == 2 && TERMS == 1 && !LSE), "two workgroups per CU: single-term mode, 64 cells");
+    static_assert(!TRN || (TERMS == 1 && !LSE), "transposed tiles: single-term mode without row statistics");
     const int JS = Jp + 8;                                 // padded row stride (bf16 elements): 16-byte pad
     unsigned short *Ahi = lds_s;                            // [SM][JS]
     unsigned short *Alo = lds_s + (size_t)SM * JS;          // [SM][JS]   (TERMS == 3)
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(64 * kSWaves, OCC) void joint_fwd_split_kernel(
     // (<= ~2.5 MB of fragments, resident in its 4 MB L2) for the whole launch
     const int part = blockIdx.x % npart;
     const long m0 = (long)(blockIdx.x / npart) * SM;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
 #ifdef WR_JS_STAMPS
     unsigned long long js_t0 = 0, js_r0 = 0, js_t1 = 0, js_t2 = 0, js_r2 = 0, js_a = 0, js_b = 0, js_c = 0, js_d = 0;
@@ -198,23 +203,19 @@ __global__ __launch_bounds__(64 * kSWaves, OCC) void joint_fwd_split_kernel(
     const u32x4 *__restrict__ whl = wh + lane;
     const u32x4 *__restrict__ wll = wl + lane;
 
-    auto load_set = [&](int ci, u32x4 (&bh)[PF][kSCT], u32x4 (&bl)[PF][kSCT]) {
-#ifdef WR_X_NOLOAD
-        if (ci >= 2) return;                                // experiment: the k-loop without its W stream
-#endif
-        const int cc = ci < total ? ci : total - 1;
-        const int r = cc / cpr, c0 = cc - r * cpr;
-        const int pr = r * kSWaves + wave;
+    // W fragments of set li (PF k-steps x kSCT column tiles of this wave's pair) -> registers; k-step i alone when i >= 0
+    // (the main loop issues a set's loads between the MFMAs of the set two ahead of it, one k-step's loads per k-step)
+    auto set_base = [&](int lr, int lc0) -> size_t {
+        const int pr = lr * kSWaves + wave;
         const int ct0 = (pair0 + (pr < npairs ? pr : npairs - 1)) * kSCT;   // waves past the last pair reload it (results dropped)
+        return ((size_t)ct0 * S + (size_t)lc0 * PF) * 64;
+    };
+    auto load_step = [&](size_t base, int i, u32x4 (&bh)[PF][kSCT], u32x4 (&bl)[PF][kSCT]) {
 #pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const int s = c0 * PF + i;
-#pragma unroll
-            for (int c = 0; c < kSCT; ++c) {
-                const size_t f = ((size_t)(ct0 + c) * S + s) * 64;
-                bh[i][c] = whl[f];
-                if (TERMS == 3) bl[i][c] = wll[f];
-            }
+        for (int c = 0; c < kSCT; ++c) {
+            const size_t f = base + ((size_t)c * S + i) * 64;
+            bh[i][c] = whl[f];
+            if (TERMS == 3) bl[i][c] = wll[f];
         }
     };
     u32x4 pbh[PF][kSCT], pbl[PF][kSCT], qbh[PF][kSCT], qbl[PF][kSCT], rbh[PF][kSCT], rbl[PF][kSCT];
@@ -227,61 +228,134 @@ __global__ __launch_bounds__(64 * kSWaves, OCC) void joint_fwd_split_kernel(
         }
     }
     float bvr[kSCT] = {0.f, 0.f};                           // OCC == 2: this lane's bias values of the current round
+    f32x4 bvt[kSCT][4];                                     // ... of a transposed tile: entries 8 g + 4 half + (0..3) of tile c
+    const bool bias_vec = (reinterpret_cast<size_t>(bias) & 15) == 0;
     auto next_bias = [&](int r) {
         if (OCC == 1) return;
         const int pr = r * kSWaves + wave;
+        if constexpr (TRN) {
 #pragma unroll
-        for (int c = 0; c < kSCT; ++c) {
-            const int col = ((pair0 + pr) * kSCT + c) * 32 + l31;
-            bvr[c] = (pr < npairs && col < V) ? bias[col] : 0.f;
+            for (int c = 0; c < kSCT; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int v = ((pair0 + pr) * kSCT + c) * 32 + 8 * g + 4 * half;
+                    if (pr < npairs && v + 4 <= V && bias_vec) {
+                        bvt[c][g] = *reinterpret_cast<const f32x4 *>(bias + v);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) bvt[c][g][j] = (pr < npairs && v + j < V) ? bias[v + j] : 0.f;
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int c = 0; c < kSCT; ++c) {
+                const int col = ((pair0 + pr) * kSCT + c) * 32 + l31;
+                bvr[c] = (pr < npairs && col < V) ? bias[col] : 0.f;
+            }
         }
     };
     next_bias(0);
-    // activation tile: a wave takes rows wave, wave+4, ...; four rows (32 loads per lane) in flight at a time;
-    // a lane owns the k pairs 2*lane + 128*i (packed 32-bit LDS writes)
-    constexpr int KI = 4;                                   // Jp <= 512: at most 4 k pairs per lane per row
-    static_assert(SM / kSWaves % 4 == 0, "rows per wave");
-    for (int rb = 0; rb < SM / kSWaves; rb += 4) {
-        float2 ev[4][KI], pv[4][KI];
+    // activation tile H = act(ep[b,t,:] + pp[b,u,:]): a wave takes rows wave, wave+4, ...; a lane owns k = VW*lane + 64*VW*i.
+    // The vector-memory path of the CU is what the two resident workgroups share, so the build keeps its instruction count
+    // down: 16-byte loads (J % 4 == 0), an ep row fetched again only when (b, t) changes from one of the wave's cells to
+    // the next (64 consecutive cells span one or two frames when U1 >= 64).  Small batches: requesting a second batch
+    // before the first is evaluated, or 8 rows at once, was 12 % SLOWER -- the other workgroup's W stream waits behind
+    // those loads.
+    // (b, t, u) of the wave's cells by stepping, one division pair per wave: cell m0 + wave + 4 j
+    long w_bt, w_b;
+    int w_u, w_t;
+    {
+        const long m = m0 + wave < M ? m0 + wave : M - 1;
+        w_bt = m / U1;
+        w_u = (int)(m - w_bt * U1);
+        w_b = w_bt / T;
+        w_t = (int)(w_bt - w_b * T);
+    }
+    auto build_tile = [&](auto vw_tag) {
+        constexpr int VW = decltype(vw_tag)::value;         // floats per lane and load: 4 or 2
+        constexpr int KI = 512 / (64 * VW);                 // Jp <= 512
+        constexpr int RB = 2;                               // rows per batch (8 or 16 loads per lane in flight; larger batches
+                                                            // measured no faster -- at 8 rows of 16-byte loads 12 % slower)
+        typedef float fvec __attribute__((ext_vector_type(VW)));
+        static_assert(SM / kSWaves % RB == 0, "rows per wave");
+        fvec ec[KI];                                        // the ep row of the cell being evaluated
+        long ec_bt = -1;
+        for (int rb = 0; rb < SM / kSWaves; rb += RB) {
+            fvec ev[RB][KI], pv[RB][KI];
+            bool fresh[RB];
+            long bt_last = ec_bt;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = wave + kSWaves * (rb + q);
-            const long m = m0 + row < M ? m0 + row : M - 1;
-            const long bt = m / U1;
-            const int u = (int)(m - bt * U1);
-            const long b = bt / T;
-            const float *__restrict__ e = ep + (size_t)bt * J;
-            const float *__restrict__ p = pp + ((size_t)b * U1 + u) * J;
+            for (int q = 0; q < RB; ++q) {
+                const int row = wave + kSWaves * (rb + q);
+                const float *__restrict__ e = ep + (size_t)w_bt * J;
+                const float *__restrict__ p = pp + ((size_t)w_b * U1 + w_u) * J;
+                fresh[q] = w_bt != bt_last;
+                bt_last = w_bt;
+                if (m0 + row + kSWaves < M) {               // the wave's next cell (cells past M keep the last valid address)
+                    w_u += kSWaves;
+                    while (w_u >= U1) {
+                        w_u -= U1;
+                        ++w_bt;
+                        if (++w_t == T) { w_t = 0; ++w_b; }
+                    }
+                }
 #pragma unroll
-            for (int i = 0; i < KI; ++i) {
-                const int k = 2 * lane + 128 * i;
-                const int kc = k < J ? k : J - 2;           // J is even
-                ev[q][i] = *reinterpret_cast<const float2 *>(e + kc);
-                pv[q][i] = *reinterpret_cast<const float2 *>(p + kc);
+                for (int i = 0; i < KI; ++i) {
+                    const int k = VW * lane + 64 * VW * i;
+                    const int kc = k < J ? k : J - VW;      // J is a multiple of VW
+                    if (fresh[q]) ev[q][i] = *reinterpret_cast<const fvec *>(e + kc);
+                    pv[q][i] = *reinterpret_cast<const fvec *>(p + kc);
+                }
+            }
+            ec_bt = bt_last;
+#pragma unroll
+            for (int q = 0; q < RB; ++q) {
+                const int row = wave + kSWaves * (rb + q);
+                const bool in = m0 + row < M;
+#pragma unroll
+                for (int i = 0; i < KI; ++i) {
+                    if (fresh[q]) ec[i] = ev[q][i];
+                    const int k = VW * lane + 64 * VW * i;
+                    if (k >= Jp) continue;
+                    unsigned hp[VW / 2], lp[VW / 2];
+#pragma unroll
+                    for (int j = 0; j < VW; j += 2) {
+                        const bool kin = in && k + j < J;   // J is even
+                        const float z0 = ec[i][j] + pv[q][i][j], z1 = ec[i][j + 1] + pv[q][i][j + 1];
+                        const float a0 = act == WR_ACT_TANH ? tanh_fast(z0) : act_value(act, z0);
+                        const float a1 = act == WR_ACT_TANH ? tanh_fast(z1) : act_value(act, z1);
+                        split_pair(kin ? a0 : 0.f, kin ? a1 : 0.f, hp[j / 2], lp[j / 2]);
+                    }
+                    if constexpr (VW == 4) {
+                        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                        *reinterpret_cast<u32x2 *>(Ahi + (size_t)row * JS + k) = (u32x2){hp[0], hp[1]};
+                        if (TERMS == 3) *reinterpret_cast<u32x2 *>(Alo + (size_t)row * JS + k) = (u32x2){lp[0], lp[1]};
+                    } else {
+                        *reinterpret_cast<unsigned *>(Ahi + (size_t)row * JS + k) = hp[0];
+                        if (TERMS == 3) *reinterpret_cast<unsigned *>(Alo + (size_t)row * JS + k) = lp[0];
+                    }
+                }
             }
         }
+    };
+    if ((J & 3) == 0 && ((reinterpret_cast<size_t>(ep) | reinterpret_cast<size_t>(pp)) & 15) == 0)
+        build_tile(std::integral_constant<int, 4>{});
+    else
+        build_tile(std::integral_constant<int, 2>{});
+    {
+        const size_t b0 = set_base(0, 0), b1 = set_base(cpr > 1 ? 0 : 1, cpr > 1 ? 1 : 0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = wave + kSWaves * (rb + q);
-            const bool in = m0 + row < M;
+        for (int i = 0; i < PF; ++i) load_step(b0, i, pbh, pbl);
 #pragma unroll
-            for (int i = 0; i < KI; ++i) {
-                const int k = 2 * lane + 128 * i;
-                if (k >= Jp) continue;
-                const bool kin = in && k < J;
-                const float z0 = ev[q][i].x + pv[q][i].x, z1 = ev[q][i].y + pv[q][i].y;
-                const float a0 = act == WR_ACT_TANH ? tanh_fast(z0) : act_value(act, z0);
-                const float a1 = act == WR_ACT_TANH ? tanh_fast(z1) : act_value(act, z1);
-                const float x0 = kin ? a0 : 0.f;
-                const float x1 = kin ? a1 : 0.f;
-                unsigned hp, lp;
-                split_pair(x0, x1, hp, lp);
-                *reinterpret_cast<unsigned *>(Ahi + (size_t)row * JS + k) = hp;
-                if (TERMS == 3) *reinterpret_cast<unsigned *>(Alo + (size_t)row * JS + k) = lp;
-            }
-        }
+        for (int i = 0; i < PF; ++i) load_step(b1, i, qbh, qbl);
     }
     __syncthreads();
+#ifdef WR_X_STAGGER
+    if (OCC == 2 && (__builtin_amdgcn_s_getreg(4 | (3 << 11)) & 1)) {       // experiment: odd wave slots start their k-loop later
+#pragma unroll
+        for (int i = 0; i < WR_X_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);  // 1024 cycles each
+    }
+#endif
     WR_JS_NOW(js_t1);
 
     const unsigned short *a_hi = Ahi + (size_t)l31 * JS + 8 * half;
@@ -302,16 +376,24 @@ __global__ __launch_bounds__(64 * kSWaves, OCC) void joint_fwd_split_kernel(
                 al[buf][r] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(a_lo + (size_t)(32 * r) * JS + 16 * s));
         }
     };
-    load_set(0, pbh, pbl);
-    load_set(1, qbh, qbl);
     read_a(0, 0);
-    auto mfma_set = [&](int ci, const u32x4 (&bh)[PF][kSCT], const u32x4 (&bl)[PF][kSCT]) {
-        const int c0 = ci % cpr;
+    // set counters: (cr, cc0) = round and chunk of the set being multiplied, (lr, lc0) of the set being loaded (two ahead)
+    int cr = 0, cc0 = 0, lr = 0, lc0 = 0;
+    auto advance = [&](int &r_, int &c_) { if (++c_ == cpr) { c_ = 0; ++r_; } };
+    advance(lr, lc0);
+    advance(lr, lc0);
+    auto mfma_set = [&](const u32x4 (&bh)[PF][kSCT], const u32x4 (&bl)[PF][kSCT], u32x4 (&nh)[PF][kSCT], u32x4 (&nl)[PF][kSCT]) {
+        const int c0 = cc0;
         const int cn = (c0 + 1 == cpr) ? 0 : c0 + 1;        // next chunk's first step (wraps to the next round)
+        const bool more = lr < rounds;                      // sets past the last one are not loaded
+        const size_t lbase = set_base(more ? lr : rounds - 1, more ? lc0 : cpr - 1);
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
             const int buf = i & 1;                          // PF is even: every chunk starts on buffer 0
             read_a(i + 1 < PF ? c0 * PF + i + 1 : cn * PF, buf ^ 1);
+#ifndef WR_X_NOLOAD
+            load_step(lbase, i, nh, nl);
+#endif
 #pragma unroll
             for (int r = 0; r < RT; ++r)
 #pragma unroll
@@ -322,19 +404,84 @@ __global__ __launch_bounds__(64 * kSWaves, OCC) void joint_fwd_split_kernel(
                         acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[buf][r], bhv, acc[r][c], 0, 0, 0);   // small terms first
                         acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[buf][r], blv, acc[r][c], 0, 0, 0);
                     }
-                    acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[buf][r], bhv, acc[r][c], 0, 0, 0);
+                    if (TRN) acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bhv, ah[buf][r], acc[r][c], 0, 0, 0);
+                    else acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[buf][r], bhv, acc[r][c], 0, 0, 0);
                 }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        advance(lr, lc0);
     };
-    auto finish_round = [&](int ci) {                       // after the last chunk of a round: bias, store, reset
-        if ((ci + 1) % cpr != 0) return;
-        const int r = ci / cpr;
+    auto finish_round = [&]() {                             // after the last chunk of a round: bias, store, reset
+        const int r = cr;
+        const bool last = cc0 + 1 == cpr;
+        advance(cr, cc0);
+        if (!last) return;
         const int pr = r * kSWaves + wave;
         const int ct0 = (pair0 + pr) * kSCT;
         // interior tiles (all 64 cells and all 64 columns valid: everything but the matrix edges) store without
         // per-element guards, so the stores issue back to back
         const bool full = m0 + SM <= M && pr < npairs && (ct0 + kSCT) * 32 <= V;
-        if constexpr (TERMS == 1 && !LSE) {
+        if constexpr (TRN) {
+            // acc[rt][c][q] = logit of cell m0 + 32 rt + l31, vocabulary entry (ct0 + c) * 32 + 8 (q >> 2) + 4 half + (q & 3)
+            constexpr int VB = 4 * (int)sizeof(OutT);                       // bytes a lane stores at once
+            const bool vec = full && ((size_t)V * sizeof(OutT)) % VB == 0 && (reinterpret_cast<size_t>(out) % VB) == 0;
+#ifdef WR_X_NOEPI
+            if (vec) {                                      // experiment: the k-loop without its epilogue
+                float sum = 0.f;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int c = 0; c < kSCT; ++c) { sum += acc[rt][c][0] + acc[rt][c][7]; acc[rt][c] = (f32x16){0}; }
+                if (sum == 1.2345e30f) out[0] = to_out<OutT>(sum);
+                next_bias(r + 1);
+                return;
+            }
+#endif
+#pragma unroll
+            for (int c = 0; c < kSCT; ++c) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 b4;
+                    if constexpr (OCC == 2) b4 = bvt[c][g];
+                    else b4 = *reinterpret_cast<const f32x4 *>(bias_s + ((pr < npairs ? pr : 0) * kSCT + c) * 32 + 8 * g + 4 * half);
+                    const int v = (ct0 + c) * 32 + 8 * g + 4 * half;
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const long m = m0 + 32 * rt + l31;
+                        const float x0 = acc[rt][c][4 * g] + b4[0], x1 = acc[rt][c][4 * g + 1] + b4[1];
+                        const float x2 = acc[rt][c][4 * g + 2] + b4[2], x3 = acc[rt][c][4 * g + 3] + b4[3];
+                        OutT *__restrict__ o = out + (size_t)m * V + v;
+                        if (vec) {
+                            if constexpr (sizeof(OutT) == 4) {
+                                *reinterpret_cast<f32x4 *>(o) = (f32x4){x0, x1, x2, x3};
+                            } else {
+                                typedef OutT o2 __attribute__((ext_vector_type(2)));
+                                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                                const o2 p0 = __builtin_convertvector((f32x2){x0, x1}, o2);
+                                const o2 p1 = __builtin_convertvector((f32x2){x2, x3}, o2);
+                                const u32x2 pk = (u32x2){__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
+#ifdef WR_X_NOSTORE
+                                if (pk.x == 0x7fc12345u && pk.y == 0x7fc12345u)   // experiment: the epilogue without its stores
+#endif
+                                *reinterpret_cast<u32x2 *>(o) = pk;
+                            }
+                        } else if (m < M && pr < npairs) {
+                            if (v < V) o[0] = to_out<OutT>(x0);
+                            if (v + 1 < V) o[1] = to_out<OutT>(x1);
+                            if (v + 2 < V) o[2] = to_out<OutT>(x2);
+                            if (v + 3 < V) o[3] = to_out<OutT>(x3);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int c = 0; c < kSCT; ++c) acc[rt][c] = (f32x16){0};
+            next_bias(r + 1);
+            return;
+        }
+        if constexpr (TERMS == 1 && !LSE && !TRN) {
             // Interior tiles of the single-term mode leave through a per-wave LDS stage as whole 128-byte lines: in the
             // C/D layout a lane holds ONE column, so a direct store moves 2 or 4 bytes per lane (64 store instructions per
             // round and wave, 64-byte pieces of lines); staged, a lane stores 16 bytes of 8 (bf16 / f16) or 4 (fp32)
@@ -379,7 +526,12 @@ __global__ __launch_bounds__(64 * kSWaves, OCC) void joint_fwd_split_kernel(
                         constexpr int LPR = ROWB / 16;                      // lanes per row: 8 (16-bit logits) or 16 (fp32)
                         constexpr int RPI = 64 / LPR;                       // rows per store instruction
                         const int rr = lane / LPR, seg = lane - rr * LPR;
+#ifdef WR_X_STORE_LOCAL
+                        // experiment: every store lands in the same 2.5 MB of the output (no HBM write traffic)
+                        char *obase = reinterpret_cast<char *>(out + (size_t)((m0 + 32 * rt + 8 * g0) & 255) * V + (size_t)ct0 * 32) + seg * 16;
+#else
                         char *obase = reinterpret_cast<char *>(out + (size_t)(m0 + 32 * rt + 8 * g0) * V + (size_t)ct0 * 32) + seg * 16;
+#endif
 #pragma unroll
                         for (int i = 0; i < SR / RPI; ++i) {
                             const int row = i * RPI + rr;
@@ -387,13 +539,26 @@ __global__ __launch_bounds__(64 * kSWaves, OCC) void joint_fwd_split_kernel(
 #ifdef WR_X_NOSTORE
                             if (v.x == 0x7fc12345u && v.y == 0x7fc12345u)   // experiment: the epilogue without its global stores
 #endif
+#ifdef WR_X_NT
+                            __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(obase + (size_t)row * V * sizeof(OutT)));
+#else
                             *reinterpret_cast<u32x4 *>(obase + (size_t)row * V * sizeof(OutT)) = v;
+#endif
                         }
                         __builtin_amdgcn_wave_barrier();
                     }
 #pragma unroll
                     for (int c = 0; c < kSCT; ++c) acc[rt][c] = (f32x16){0};
                 }
+#if defined(WR_JS_STAMPS) && WR_JS_STAMPS >= 2
+                {                                           // level 2: how long until the round's stores have retired
+                    unsigned long long d0, d1;
+                    WR_JS_NOW(d0);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    WR_JS_NOW(d1);
+                    js_ld += d1 - d0;
+                }
+#endif
                 next_bias(r + 1);
                 return;
             }
@@ -431,32 +596,30 @@ __global__ __launch_bounds__(64 * kSWaves, OCC) void joint_fwd_split_kernel(
     };
 
 #ifdef WR_JS_STAMPS
-#define WR_JS_PHASE(ci_, ld_, P, Q)                                                                                      \
-    WR_JS_NOW(js_a);                                                                                                      \
-    load_set(ld_, P##bh, P##bl);                                                                                          \
+#define WR_JS_PHASE(P, Q)                                                                                                \
     WR_JS_NOW(js_b);                                                                                                      \
-    mfma_set(ci_, Q##bh, Q##bl);                                                                                          \
+    mfma_set(Q##bh, Q##bl, P##bh, P##bl);                                                                                 \
     WR_JS_NOW(js_c);                                                                                                      \
-    finish_round(ci_);                                                                                                    \
-    WR_JS_NOW(js_d);                                                                                                      \
-    js_ld += js_b - js_a;                                                                                                 \
-    js_mm += js_c - js_b;                                                                                                 \
-    if ((ci_) % cpr == 0) js_mm_first += js_c - js_b;                                                                     \
-    if (((ci_) + 1) % cpr == 0) { js_ep += js_d - js_c; js_ep_n += 1; }
+    {                                                                                                                     \
+        const bool first_ = cc0 == 0, last_ = cc0 + 1 == cpr;                                                             \
+        finish_round();                                                                                                   \
+        WR_JS_NOW(js_d);                                                                                                  \
+        js_mm += js_c - js_b;                                                                                             \
+        if (first_) js_mm_first += js_c - js_b;                                                                           \
+        if (last_) { js_ep += js_d - js_c; js_ep_n += 1; }                                                                \
+    }
 #else
-#define WR_JS_PHASE(ci_, ld_, P, Q)                                                                                      \
-    load_set(ld_, P##bh, P##bl);                                                                                          \
-    __builtin_amdgcn_sched_barrier(0);                                                                                    \
-    mfma_set(ci_, Q##bh, Q##bl);                                                                                          \
-    finish_round(ci_);                                                                                                    \
+#define WR_JS_PHASE(P, Q)                                                                                                \
+    mfma_set(Q##bh, Q##bl, P##bh, P##bl);                                                                                 \
+    finish_round();                                                                                                       \
     __builtin_amdgcn_sched_barrier(0);
 #endif
     for (int ci = 0; ci < total; ci += 3) {
-        WR_JS_PHASE(ci, ci + 2, r, p)
+        WR_JS_PHASE(r, p)
         if (ci + 1 >= total) break;
-        WR_JS_PHASE(ci + 1, ci + 3, p, q)
+        WR_JS_PHASE(p, q)
         if (ci + 2 >= total) break;
-        WR_JS_PHASE(ci + 2, ci + 4, q, r)
+        WR_JS_PHASE(q, r)
     }
 #undef WR_JS_PHASE
 #ifdef WR_JS_STAMPS
@@ -1536,9 +1699,14 @@ int joint_fwd_split_launch(const float *ep_d, const float *pp_d, const float *w_
     // bias slab, a store stage of 16 / 8 rows) -- wr_tune_set(12, 1) keeps the one-per-CU form
     const size_t esz0 = out_dtype == 0 ? 4 : 2;
     const size_t stage2 = (size_t)kSWaves * (esz0 == 4 ? 8 : 16) * (kSCT * 32 * esz0 + 16);
-    const bool two = terms == 1 && !lse && !wide && npart == 1 && tune_get(kTuneSplitFwdCells) != 1 &&
-                     (size_t)kSM * (Jp + 8) * sizeof(unsigned short) + stage2 <= 80 * 1024 &&
-                     ((size_t)V * esz0) % 16 == 0 && (reinterpret_cast<size_t>(out_d) & 15) == 0;
+    const bool trn = terms == 1 && !lse && tune_get(kTuneSplitFwdStore) == 1;      // transposed tiles, stores from registers (measured slower: 16-byte pieces)
+    const bool two = terms == 1 && !lse && !wide && tune_get(kTuneSplitFwdCells) != 1 &&
+                     (size_t)kSM * (Jp + 8) * sizeof(unsigned short) + (trn ? 0 : stage2) <= 80 * 1024 &&
+                     (trn || (((size_t)V * esz0) % 16 == 0 && (reinterpret_cast<size_t>(out_d) & 15) == 0));
+    // two per CU: W in two column slabs (a workgroup covers one; consecutive workgroups land on consecutive XCDs, so an
+    // XCD keeps re-reading ONE slab) once the bf16 image exceeds an XCD's 4 MB L2 -- 8.20 -> 7.81 ms at V = 5000, J = 512
+    // although every activation tile is then built twice; four slabs: 8.8 ms
+    if (two && tune_get(kTuneSplitParts) == 0 && img > (size_t)4 << 20) npart = 2;
     size_t tile_lds = (size_t)(terms == 3 ? 2 : 1) * cells * (Jp + 8) * sizeof(unsigned short);
     if (lse && tile_lds < joint_lse_exchange_bytes(kSWaves)) tile_lds = joint_lse_exchange_bytes(kSWaves);
     const size_t extra = 0;
@@ -1552,35 +1720,35 @@ int joint_fwd_split_launch(const float *ep_d, const float *pp_d, const float *w_
     // single-term mode: a store stage of 32 rows x (64 columns + 16 bytes) per wave behind the (16-byte rounded) bias slab
     const size_t esz = out_dtype == 0 ? 4 : 2;
     const size_t bias_al = align_up(bias_lds, 16);
-    const size_t stage_lds = (terms == 1 && !lse) ? (size_t)kSWaves * 32 * (kSCT * 32 * esz + 16) : 0;
+    const size_t stage_lds = (terms == 1 && !lse && !trn) ? (size_t)kSWaves * 32 * (kSCT * 32 * esz + 16) : 0;
     const bool stage_fits = stage_lds > 0 && tile_lds + bias_al + stage_lds <= 160 * 1024;
-    const size_t lds = two ? tile_lds + stage2 : tile_lds + (stage_fits ? bias_al + stage_lds : bias_lds) + extra;
+    const size_t lds = two ? tile_lds + (trn ? 0 : stage2) : tile_lds + (stage_fits ? bias_al + stage_lds : align_up(bias_lds, 16)) + extra;
     const int kb_bias = two ? 0 : (int)bias_al, kb_stage = (two || stage_fits) ? 1 : 0;
     WR_REQUIRE(lds <= 160 * 1024, WR_EUNSUPPORTED, "joint_fwd_split: V=%d needs %zu bytes of LDS", V, lds);
     const dim3 grid((unsigned)((M + cells - 1) / cells * npart));
-#define WR_LAUNCH_SPLIT_WIDE(OutT)                                                                                       \
+#define WR_LAUNCH_SPLIT_WIDE(OutT, TRN)                                                                                  \
     do {                                                                                                              \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_fwd_split_kernel<1, OutT, false, 4>),            \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_fwd_split_kernel<1, OutT, false, 4, 1, TRN>),    \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
-        hipLaunchKernelGGL((joint_fwd_split_kernel<1, OutT, false, 4>), grid, dim3(64 * kSWaves), lds, st, ep_d, pp_d, \
+        hipLaunchKernelGGL((joint_fwd_split_kernel<1, OutT, false, 4, 1, TRN>), grid, dim3(64 * kSWaves), lds, st, ep_d, pp_d, \
                            reinterpret_cast<const u32x4 *>(wh), reinterpret_cast<const u32x4 *>(wl), b_out_d,          \
                            logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, npart, act, static_cast<OutT *>(out_d), \
                            JointLse{}, kb_bias, kb_stage);                                                            \
     } while (0)
-#define WR_LAUNCH_SPLIT_TWO(OutT)                                                                                        \
+#define WR_LAUNCH_SPLIT_TWO(OutT, TRN)                                                                                   \
     do {                                                                                                              \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_fwd_split_kernel<1, OutT, false, 2, 2>),         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_fwd_split_kernel<1, OutT, false, 2, 2, TRN>),    \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
-        hipLaunchKernelGGL((joint_fwd_split_kernel<1, OutT, false, 2, 2>), grid, dim3(64 * kSWaves), lds, st, ep_d,    \
+        hipLaunchKernelGGL((joint_fwd_split_kernel<1, OutT, false, 2, 2, TRN>), grid, dim3(64 * kSWaves), lds, st, ep_d, \
                            pp_d, reinterpret_cast<const u32x4 *>(wh), reinterpret_cast<const u32x4 *>(wl), b_out_d,    \
                            logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, npart, act, static_cast<OutT *>(out_d), \
                            JointLse{}, kb_bias, kb_stage);                                                            \
     } while (0)
-#define WR_LAUNCH_SPLIT(TERMS, OutT)                                                                                  \
+#define WR_LAUNCH_SPLIT(TERMS, OutT, TRN)                                                                             \
     do {                                                                                                              \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_fwd_split_kernel<TERMS, OutT>),                  \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_fwd_split_kernel<TERMS, OutT, false, 2, 1, TRN>), \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
-        hipLaunchKernelGGL((joint_fwd_split_kernel<TERMS, OutT>), grid, dim3(64 * kSWaves), lds, st, ep_d, pp_d,       \
+        hipLaunchKernelGGL((joint_fwd_split_kernel<TERMS, OutT, false, 2, 1, TRN>), grid, dim3(64 * kSWaves), lds, st, ep_d, pp_d, \
                            reinterpret_cast<const u32x4 *>(wh), reinterpret_cast<const u32x4 *>(wl), b_out_d,          \
                            logit_lengths_d, target_lengths_d, B, T, U1, J, Jp, V, Vp, npart, act, static_cast<OutT *>(out_d), \
                            JointLse{}, kb_bias, kb_stage);                                                            \
@@ -1597,21 +1765,33 @@ int joint_fwd_split_launch(const float *ep_d, const float *pp_d, const float *w_
     if (lse) {
         if (terms == 3) WR_LAUNCH_SPLIT_LSE(3); else WR_LAUNCH_SPLIT_LSE(1);
     } else if (terms == 3) {
-        if (out_dtype == 0) WR_LAUNCH_SPLIT(3, float);
-        else if (out_dtype == 1) WR_LAUNCH_SPLIT(3, _Float16);
-        else WR_LAUNCH_SPLIT(3, __bf16);
+        if (out_dtype == 0) WR_LAUNCH_SPLIT(3, float, false);
+        else if (out_dtype == 1) WR_LAUNCH_SPLIT(3, _Float16, false);
+        else WR_LAUNCH_SPLIT(3, __bf16, false);
+    } else if (two && trn) {
+        if (out_dtype == 0) WR_LAUNCH_SPLIT_TWO(float, true);
+        else if (out_dtype == 1) WR_LAUNCH_SPLIT_TWO(_Float16, true);
+        else WR_LAUNCH_SPLIT_TWO(__bf16, true);
     } else if (two) {
-        if (out_dtype == 0) WR_LAUNCH_SPLIT_TWO(float);
-        else if (out_dtype == 1) WR_LAUNCH_SPLIT_TWO(_Float16);
-        else WR_LAUNCH_SPLIT_TWO(__bf16);
+        if (out_dtype == 0) WR_LAUNCH_SPLIT_TWO(float, false);
+        else if (out_dtype == 1) WR_LAUNCH_SPLIT_TWO(_Float16, false);
+        else WR_LAUNCH_SPLIT_TWO(__bf16, false);
+    } else if (wide && trn) {
+        if (out_dtype == 0) WR_LAUNCH_SPLIT_WIDE(float, true);
+        else if (out_dtype == 1) WR_LAUNCH_SPLIT_WIDE(_Float16, true);
+        else WR_LAUNCH_SPLIT_WIDE(__bf16, true);
     } else if (wide) {
-        if (out_dtype == 0) WR_LAUNCH_SPLIT_WIDE(float);
-        else if (out_dtype == 1) WR_LAUNCH_SPLIT_WIDE(_Float16);
-        else WR_LAUNCH_SPLIT_WIDE(__bf16);
+        if (out_dtype == 0) WR_LAUNCH_SPLIT_WIDE(float, false);
+        else if (out_dtype == 1) WR_LAUNCH_SPLIT_WIDE(_Float16, false);
+        else WR_LAUNCH_SPLIT_WIDE(__bf16, false);
+    } else if (trn) {
+        if (out_dtype == 0) WR_LAUNCH_SPLIT(1, float, true);
+        else if (out_dtype == 1) WR_LAUNCH_SPLIT(1, _Float16, true);
+        else WR_LAUNCH_SPLIT(1, __bf16, true);
     } else {
-        if (out_dtype == 0) WR_LAUNCH_SPLIT(1, float);
-        else if (out_dtype == 1) WR_LAUNCH_SPLIT(1, _Float16);
-        else WR_LAUNCH_SPLIT(1, __bf16);
+        if (out_dtype == 0) WR_LAUNCH_SPLIT(1, float, false);
+        else if (out_dtype == 1) WR_LAUNCH_SPLIT(1, _Float16, false);
+        else WR_LAUNCH_SPLIT(1, __bf16, false);
     }
 #undef WR_LAUNCH_SPLIT_WIDE
 #undef WR_LAUNCH_SPLIT_TWO

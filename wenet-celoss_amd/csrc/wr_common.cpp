@@ -20,7 +20,7 @@ void set_error(const char *fmt, ...)
 
 namespace wr {
 namespace {
-std::atomic<int> g_tune[kTuneCount] = {{0}, {0}, {7}, {16}, {16}, {2}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};
+std::atomic<int> g_tune[kTuneCount] = {{0}, {0}, {7}, {16}, {16}, {2}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};
 }
 int tune_get(int key) { return (key >= 0 && key < kTuneCount) ? g_tune[key].load(std::memory_order_relaxed) : 0; }
 }  // namespace wr

@@ -41,7 +41,7 @@ void set_error(const char *fmt, ...);
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- process-wide tuning knobs (wr_tune_set; defaults are the measured best) ----
-enum TuneKey { kTuneLseBlocksPerCu = 0, kTuneGradBlocksPerCu = 1, kTuneNonTemporal = 2, kTuneGradUnroll = 3, kTuneLseUnroll = 4, kTuneJointFwdVariant = 5, kTuneLaneGemmTile = 6, kTuneSplitParts = 7, kTuneDzTile = 8, kTuneDwExact = 9, kTuneDzExact = 10, kTuneFoldProj = 11, kTuneSplitFwdCells = 12, kTuneCount = 13 };
+enum TuneKey { kTuneLseBlocksPerCu = 0, kTuneGradBlocksPerCu = 1, kTuneNonTemporal = 2, kTuneGradUnroll = 3, kTuneLseUnroll = 4, kTuneJointFwdVariant = 5, kTuneLaneGemmTile = 6, kTuneSplitParts = 7, kTuneDzTile = 8, kTuneDwExact = 9, kTuneDzExact = 10, kTuneFoldProj = 11, kTuneSplitFwdCells = 12, kTuneSplitFwdStore = 13, kTuneCount = 14 };
 int tune_get(int key);
 
 // joint_split.hip: exact-fp32 activation gradient, 256 x 256 block tiling
