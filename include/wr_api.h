@@ -244,6 +244,17 @@ int wr_joint_bwd_dz_split(const float *gout_d /* [B,T,U1,V] */, const float *ep_
                           float *dz_d /* [B,T,U1,J] */, float *h_d /* [B,T,U1,J] or NULL */,
                           void *workspace_d, size_t workspace_bytes, void *stream);
 
+/* The same with the logits gradient in bf16 -- what the loss hands back for the 16-bit logits of the AMP step
+ * (reference: executor.py:91 autocast; torch casts the Linear's incoming gradient the same way).  bf16 values are their
+ * own hi parts: no conversion pass, half the gradient bytes, results identical to wr_joint_bwd_dz_split on the same
+ * values widened to fp32.  V a multiple of 8, at least 32. */
+int wr_joint_bwd_dz_split_bf16(const void *gout_bf16_d /* [B,T,U1,V] bf16 */, const float *ep_d, const float *pp_d,
+                               const float *w_out_d,
+                               const int32_t *logit_lengths_d /* nullable */, const int32_t *target_lengths_d /* nullable */,
+                               int B, int T, int U1, int J, int V, int activation, int terms,
+                               float *dz_d /* [B,T,U1,J] */, float *h_d /* [B,T,U1,J] or NULL */,
+                               void *workspace_d, size_t workspace_bytes, void *stream);
+
 /* Weight gradient of ffn_out:  dw[v, :] = sum over lattice cells of gout[cell, v] * h[cell, :],
  * db[v] = sum of gout[cell, v]  (h = tanh(ep+pp) as written by wr_joint_bwd_dz).  With lengths, cells in the
  * padded region do not contribute.  db_d may be NULL.  Deterministic (partial slabs + ordered reduction). */
@@ -264,6 +275,13 @@ int wr_joint_bwd_dw_split(const float *gout_d /* [B,T,U1,V] */, const float *h_d
                           int B, int T, int U1, int J, int V, int terms,
                           float *dw_d /* [V,J] */, float *db_d /* [V] or NULL */,
                           void *workspace_d, size_t workspace_bytes, void *stream);
+
+/* The same with the logits gradient in bf16 (see wr_joint_bwd_dz_split_bf16); workspace as wr_joint_bwd_dw_split. */
+int wr_joint_bwd_dw_split_bf16(const void *gout_bf16_d /* [B,T,U1,V] bf16 */, const float *h_d /* [B,T,U1,J] */,
+                               const int32_t *logit_lengths_d /* nullable */, const int32_t *target_lengths_d /* nullable */,
+                               int B, int T, int U1, int J, int V, int terms,
+                               float *dw_d /* [V,J] */, float *db_d /* [V] or NULL */,
+                               void *workspace_d, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------
  * Transducer decoding: batched greedy search, batched prefix beam search and

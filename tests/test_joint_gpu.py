@@ -318,6 +318,73 @@ def test_split_dw_matches_float64(terms, tol, B, T, U1, J, V):
     assert lib.wr_joint_bwd_dw_split(P(gout), P(h), None, None, B, T, U1, J, 30, terms, P(dw), P(db), P(ws), wsb, st) != 0
 
 
+@pytest.mark.parametrize("terms", [1, 3])
+@pytest.mark.parametrize("B,T,U1,J,V", [(2, 9, 5, 128, 304), (1, 70, 3, 256, 1000), (2, 13, 4, 36, 64), (1, 20, 9, 512, 5000),
+                                        (1, 33, 2, 64, 32), (3, 50, 7, 260, 520)])
+def test_split_backward_takes_a_bf16_gradient_as_it_is(terms, B, T, U1, J, V):
+    """wr_joint_bwd_dz_split_bf16 / wr_joint_bwd_dw_split_bf16 (the AMP step's gradient dtype) against the fp32 entry
+    points on the same values widened to fp32: bf16 values are their own hi parts, so dZ, H, dW and db are
+    bit-identical; row tails V % 32 != 0, partial tiles, with and without lengths.  V % 8 != 0 is refused."""
+    from wenet_celoss_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(terms * 31 + T + J + V)
+    ep = torch.randn(B, T, J, generator=g).to(DEV); pp = torch.randn(B, U1, J, generator=g).to(DEV)
+    w = (torch.randn(V, J, generator=g) * 0.1).to(DEV)
+    g16 = torch.randn(B, T, U1, V, generator=g).to(DEV).to(torch.bfloat16)
+    g32 = g16.float()
+    ll = torch.randint(1, T + 1, (B,), generator=g).to(torch.int32); ll[0] = T
+    tl = torch.randint(0, U1, (B,), generator=g).to(torch.int32); tl[0] = U1 - 1
+    ll, tl = ll.to(DEV), tl.to(DEV)
+    st, P = _lib.current_stream(torch.device(DEV)), _lib.ptr
+    wsz = lib.wr_joint_dz_split_workspace_bytes(J, V); wz = torch.empty(wsz, dtype=torch.uint8, device=DEV)
+    wsw = lib.wr_joint_dw_split_workspace_bytes(B, T, U1, J, V); ww = torch.empty(wsw, dtype=torch.uint8, device=DEV)
+    for lens in ((None, None), (ll, tl)):
+        dz0 = torch.empty(B, T, U1, J, device=DEV); h0 = torch.empty_like(dz0)
+        dz1 = torch.full_like(dz0, float("nan")); h1 = torch.full_like(dz0, float("nan"))
+        _lib.check(lib.wr_joint_bwd_dz_split(P(g32), P(ep), P(pp), P(w), P(lens[0]), P(lens[1]), B, T, U1, J, V, 0, terms,
+                                             P(dz0), P(h0), P(wz), wsz, st))
+        _lib.check(lib.wr_joint_bwd_dz_split_bf16(P(g16), P(ep), P(pp), P(w), P(lens[0]), P(lens[1]), B, T, U1, J, V, 0, terms,
+                                                  P(dz1), P(h1), P(wz), wsz, st))
+        assert torch.equal(dz0, dz1) and torch.equal(h0, h1)
+        if J % 4 == 0:
+            dw0 = torch.empty(V, J, device=DEV); db0 = torch.empty(V, device=DEV)
+            dw1 = torch.full_like(dw0, float("nan")); db1 = torch.full_like(db0, float("nan"))
+            _lib.check(lib.wr_joint_bwd_dw_split(P(g32), P(h0), P(lens[0]), P(lens[1]), B, T, U1, J, V, terms, P(dw0), P(db0),
+                                                 P(ww), wsw, st))
+            _lib.check(lib.wr_joint_bwd_dw_split_bf16(P(g16), P(h0), P(lens[0]), P(lens[1]), B, T, U1, J, V, terms, P(dw1),
+                                                      P(db1), P(ww), wsw, st))
+            assert torch.equal(dw0, dw1) and torch.equal(db0, db1)
+    assert lib.wr_joint_bwd_dz_split_bf16(P(g16), P(ep), P(pp), P(w), None, None, B, T, U1, J, 36, 0, terms, P(dz1), None,
+                                          P(wz), wsz, st) != 0      # V not a multiple of 8
+
+
+def test_amp_step_backward_uses_the_bf16_gradient():
+    """Under autocast(bfloat16) with precision="bf16" the loss returns a bf16 gradient; the joiner's backward feeds it
+    to the split kernels unwidened.  Gradients equal those of the same backward run on the widened gradient."""
+    import wenet_celoss_amd as w
+    from wenet_celoss_amd.joint import joint_backward
+    torch.manual_seed(11)
+    B, T, U, E, P, J, V = 2, 40, 12, 16, 16, 128, 200
+    m = w.TransducerJoint(V, E, P, J, precision="bf16").to(DEV)
+    enc = torch.randn(B, T, E, device=DEV, requires_grad=True); pred = torch.randn(B, U + 1, P, device=DEV, requires_grad=True)
+    y = torch.randint(1, V, (B, U), dtype=torch.int32, device=DEV)
+    ll = torch.tensor([40, 17], dtype=torch.int32, device=DEV); tl = torch.tensor([12, 5], dtype=torch.int32, device=DEV)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        logits = m(enc, pred)
+        assert logits.dtype == torch.bfloat16
+        loss = w.rnnt_loss(logits, y, ll, tl, blank=0, reduction="mean")
+    (gl,) = torch.autograd.grad(loss, logits, retain_graph=True)
+    assert gl.dtype == torch.bfloat16
+    loss.backward()
+    ep = m.enc_ffn(enc.detach()).float(); pp = m.pred_ffn(pred.detach()).float()
+    want = joint_backward(gl.float(), ep, pp, m.ffn_out.weight.detach(), None, None, 1, True, True)
+    got = joint_backward(gl, ep, pp, m.ffn_out.weight.detach(), None, None, 1, True, True)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    assert m.ffn_out.weight.grad is not None and torch.isfinite(m.ffn_out.weight.grad).all()
+    assert enc.grad is not None and torch.isfinite(enc.grad).all() and torch.isfinite(pred.grad).all()
+
+
 def test_split_training_step_with_lengths_matches_exact(monkeypatch):
     """Joiner + RNN-T loss, forward and backward, ragged lengths: every gradient of the bf16x3 mode against the exact
     mode's (tolerances at the assertion); the environment switch selects the same path as the argument."""

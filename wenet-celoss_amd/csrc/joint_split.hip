@@ -693,9 +693,12 @@ constexpr int kZM2 = 128;        // cells per workgroup
 constexpr int kZStages = 3;
 
 // FULL: all 16 column tiles are in use (J = 512, the shipped join_dim): no per-tile guards in the k-loop
-template <int TERMS, bool FULL>
+// GT: dtype of the logits gradient -- float, or __bf16 (the AMP step: the loss hands back a bf16 gradient; its values ARE
+// their own hi parts, so a lane's 16 values of a double step are two ready-made MFMA operands: half the bytes, no
+// conversion pass, no split arithmetic, and the lo term vanishes)
+template <int TERMS, bool FULL, typename GT = float>
 __global__ __launch_bounds__(256) void joint_bwd_dz_split128_kernel(
-    const float *__restrict__ gout /* [M, V] */, const float *__restrict__ ep, const float *__restrict__ pp,
+    const GT *__restrict__ gout /* [M, V] */, const float *__restrict__ ep, const float *__restrict__ pp,
     const u32x4 *__restrict__ wh, const u32x4 *__restrict__ wl, const int32_t *__restrict__ llens,
     const int32_t *__restrict__ tlens, int B, int T, int U1, int J, int V, int D, int n_jt, int act,
     float *__restrict__ dz /* [M, J] */, float *__restrict__ hout /* [M, J] or null */)
@@ -743,7 +746,8 @@ __global__ __launch_bounds__(256) void joint_bwd_dz_split128_kernel(
     for (int c = 0; c < 16; ++c) acc[c] = (f32x16){0};
 
     const long mrow = m0 + 32 * wave + l31 < M ? m0 + 32 * wave + l31 : M - 1;
-    const float *__restrict__ arow = gout + (size_t)mrow * V + 16 * half;
+    constexpr bool G16 = !std::is_same<GT, float>::value;
+    const GT *__restrict__ arow = gout + (size_t)mrow * V + 16 * half;
     const int Dfull = V / 32;
     const int steps = 2 * D;                                // 16-deep steps, two per double step
 
@@ -780,20 +784,40 @@ __global__ __launch_bounds__(256) void joint_bwd_dz_split128_kernel(
         stage[(size_t)(s % kZStages) * 2 * 16 * 64 + tid + 256 * q] = z.v[q];
     };
     // dY of this lane's row: 16 floats per double step (elements 0-7 feed the even step, 8-15 the odd one)
-    struct ARegs { f32x4 a[4]; };
+    struct ARegs32 { f32x4 a[4]; };
+    struct ARegs16 { u32x4 a[2]; };                         // elements 0-7 | 8-15 as stored
+    using ARegs = typename std::conditional<G16, ARegs16, ARegs32>::type;
     auto aload = [&](int d, ARegs &z) {
         const int dd = d < Dfull ? d : (Dfull > 0 ? Dfull - 1 : 0);
+        if constexpr (G16) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) z.a[i] = *reinterpret_cast<const f32x4 *>(arow + 32 * dd + 4 * i);
+            for (int i = 0; i < 2; ++i) z.a[i] = *reinterpret_cast<const u32x4 *>(arow + 32 * dd + 8 * i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z.a[i] = *reinterpret_cast<const f32x4 *>(arow + 32 * dd + 4 * i);
+        }
     };
     auto atail = [&](ARegs &z) {                            // the row's tail (V % 32 values): guarded scalar reads
+        if constexpr (G16) {
+            const unsigned short *arow16 = reinterpret_cast<const unsigned short *>(arow);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int v = 32 * Dfull + 16 * half + 4 * i + e;
-                z.a[i][e] = v < V ? arow[32 * Dfull + 4 * i + e] : 0.f;
-            }
+                for (int e = 0; e < 4; ++e) {
+                    const int v = 32 * Dfull + 16 * half + 8 * i + 2 * e;
+                    const unsigned x0 = v < V ? arow16[32 * Dfull + 8 * i + 2 * e] : 0u;
+                    const unsigned x1 = v + 1 < V ? arow16[32 * Dfull + 8 * i + 2 * e + 1] : 0u;
+                    z.a[i][e] = x0 | (x1 << 16);
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int v = 32 * Dfull + 16 * half + 4 * i + e;
+                    z.a[i][e] = v < V ? arow[32 * Dfull + 4 * i + e] : 0.f;
+                }
+        }
     };
     auto compute = [&](int s, const ARegs &z, WRegs &zw, auto fast_tag) {
         constexpr bool fast = decltype(fast_tag)::value;
@@ -804,7 +828,8 @@ __global__ __launch_bounds__(256) void joint_bwd_dz_split128_kernel(
             __builtin_amdgcn_sched_barrier(0);
         }
         bf16x8 ah, al;
-        split8(z.a[2 * t], z.a[2 * t + 1], ah, al, TERMS == 3);
+        if constexpr (G16) ah = __builtin_bit_cast(bf16x8, z.a[t]);
+        else split8(z.a[2 * t], z.a[2 * t + 1], ah, al, TERMS == 3);
         const u32x4 *st = stage + (size_t)(s % kZStages) * 2 * 16 * 64 + lane;
         // the fragments of column tile c + 2 are requested before the MFMAs of tile c (the compiler issued each tile's two
         // reads directly in front of its three MFMAs: an LDS round trip per 96 matrix-core cycles, the reason these kernels
@@ -827,7 +852,7 @@ __global__ __launch_bounds__(256) void joint_bwd_dz_split128_kernel(
                 const bf16x8 bhv = __builtin_bit_cast(bf16x8, rh[c % 3]);
                 if (TERMS == 3) {
                     const bf16x8 blv = __builtin_bit_cast(bf16x8, rl[c % 3]);
-                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bhv, acc[c], 0, 0, 0);
+                    if (!G16) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bhv, acc[c], 0, 0, 0);
                     acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blv, acc[c], 0, 0, 0);
                 }
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhv, acc[c], 0, 0, 0);
@@ -927,9 +952,10 @@ __global__ void cell_mask_kernel(const int32_t *__restrict__ llens, const int32_
     }
 }
 
-template <int TERMS>
+// GT: dtype of the logits gradient (float, or __bf16 in the AMP step: a dY patch is then 4 x 2 bytes per cell)
+template <int TERMS, typename GT = float>
 __global__ __launch_bounds__(512) void joint_bwd_dw_split_kernel(
-    const float *__restrict__ gout /* [M, V] */, const float *__restrict__ h /* [M, J] */,
+    const GT *__restrict__ gout /* [M, V] */, const float *__restrict__ h /* [M, J] */,
     const unsigned char *__restrict__ mask /* [M] or null */, long M, int V, int J, int n_vs, int n_js, long rows_per_part,
     float *__restrict__ part_dw /* [parts][V][J] */, float *__restrict__ part_db /* [parts][V] */)
 {
@@ -952,18 +978,34 @@ __global__ __launch_bounds__(512) void joint_bwd_dw_split_kernel(
     const int steps = me > mb ? (int)((me - mb + 15) / 16) : 0;
 
     // staging map: thread -> operand (waves 0-1: dY, 2-3: H), cell group mg (8 cells), float4 column c4
-    const int c4 = tid & 63, mg = (tid >> 6) & 1, op = (tid >> 7) & 1;
+    // (mg and op are the same for a whole wave: scalar, so that the two operands' load paths are real branches -- as
+    // per-lane selects the 8-byte and the 16-byte load of a row shared their destination registers and waited on each other)
+    const int c4 = tid & 63, mg = __builtin_amdgcn_readfirstlane((tid >> 6) & 1), op = __builtin_amdgcn_readfirstlane((tid >> 7) & 1);
     const bool col_in = op == 0 ? (v0 + 4 * c4 < V) : (j0 + 4 * c4 < J);   // V, J multiples of 4: wholly in or out
     const int ld = op == 0 ? V : J;
-    const float *__restrict__ gsrc = (op == 0 ? gout + v0 : h + j0) + (col_in ? 4 * c4 : 0);
-    struct Regs { f32x4 x[8]; };
+    constexpr bool G16 = !std::is_same<GT, float>::value;
+    const float *__restrict__ gsrc = (op == 0 ? (G16 ? h : reinterpret_cast<const float *>(gout) + v0) : h + j0) + (col_in ? 4 * c4 : 0);
+    const GT *__restrict__ gsrc16 = gout + v0 + (col_in ? 4 * c4 : 0);          // G16: the dY patches
+    struct Regs { f32x4 x[8]; };                            // G16 dY patches: four bf16 as loaded in x[e][0..1] (widening them
+                                                            // at the load would wait for it two steps early)
     auto gload = [&](int s, Regs &z) {
         if (!stager) return;
+        if (G16 && op == 0) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            long m = mb + 16L * s + 8 * mg + e;
-            m = m < me ? m : me - 1;
-            z.x[e] = *reinterpret_cast<const f32x4 *>(gsrc + (size_t)m * ld);
+            for (int e = 0; e < 8; ++e) {
+                long m = mb + 16L * s + 8 * mg + e;
+                m = m < me ? m : me - 1;
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 r = *reinterpret_cast<const u32x2 *>(gsrc16 + (size_t)m * ld);
+                z.x[e] = __builtin_bit_cast(f32x4, __builtin_shufflevector(r, r, 0, 1, -1, -1));
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                long m = mb + 16L * s + 8 * mg + e;
+                m = m < me ? m : me - 1;
+                z.x[e] = *reinterpret_cast<const f32x4 *>(gsrc + (size_t)m * ld);
+            }
         }
     };
     f32x4 dbacc = (f32x4){0, 0, 0, 0};
@@ -972,6 +1014,12 @@ __global__ __launch_bounds__(512) void joint_bwd_dw_split_kernel(
         const f32x4 zero = (f32x4){0, 0, 0, 0};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
+            if (G16 && op == 0) {                                    // four bf16 -> four floats (exact: a shift)
+                const u32x4 raw = __builtin_bit_cast(u32x4, z.x[e]);
+                const unsigned rx = raw[0], ry = raw[1];
+                z.x[e] = (f32x4){__builtin_bit_cast(float, rx << 16), __builtin_bit_cast(float, rx & 0xffff0000u),
+                                 __builtin_bit_cast(float, ry << 16), __builtin_bit_cast(float, ry & 0xffff0000u)};
+            }
             const long m = mb + 16L * s + 8 * mg + e;
             bool on = m < me && col_in;
             if (on && mask != nullptr) on = mask[m] != 0;
@@ -1846,14 +1894,16 @@ extern "C" size_t wr_joint_dz_split_workspace_bytes(int J, int V)
     return 2 * align_up(n_jt * D * 2 * 64 * 8 * sizeof(unsigned short), 256);
 }
 
-extern "C" int wr_joint_bwd_dz_split(const float *gout_d, const float *ep_d, const float *pp_d, const float *w_out_d,
-                                     const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B, int T, int U1,
-                                     int J, int V, int activation, int terms, float *dz_d, float *h_d, void *workspace_d,
-                                     size_t workspace_bytes, void *stream)
+namespace {
+int joint_bwd_dz_split_launch(const void *gout_d, bool g16, const float *ep_d, const float *pp_d, const float *w_out_d,
+                              const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B, int T, int U1,
+                              int J, int V, int activation, int terms, float *dz_d, float *h_d, void *workspace_d,
+                              size_t workspace_bytes, void *stream)
 {
     if (int rc = split_check(B, T, U1, J, V, terms, 0, activation)) return rc;
-    WR_REQUIRE(V % 4 == 0 && V >= 32, WR_EUNSUPPORTED,
-               "joint_bwd_dz_split: V=%d not supported (16-byte aligned gradient rows: V a multiple of 4, at least 32)", V);
+    WR_REQUIRE(V % (g16 ? 8 : 4) == 0 && V >= 32, WR_EUNSUPPORTED,
+               "joint_bwd_dz_split: V=%d not supported (16-byte aligned gradient rows: V a multiple of %d, at least 32)", V,
+               g16 ? 8 : 4);
     WR_REQUIRE(gout_d && ep_d && pp_d && w_out_d && dz_d && workspace_d, WR_EINVAL, "joint_bwd_dz_split: null pointer argument");
     WR_REQUIRE((logit_lengths_d == nullptr) == (target_lengths_d == nullptr), WR_EINVAL,
                "joint_bwd_dz_split: pass both length arrays or neither");
@@ -1870,20 +1920,42 @@ extern "C" int wr_joint_bwd_dz_split(const float *gout_d, const float *ep_d, con
     {                                                       // 128-cell tiling, W fragments staged in LDS
         const size_t lds = (size_t)kZStages * 2 * 16 * 64 * 16 + (size_t)kZM2 * (2 * sizeof(long) + sizeof(int));
         const dim3 grid2((unsigned)((M + kZM2 - 1) / kZM2));
-#define WR_LAUNCH_DZ2(TERMS, FULL_)                                                                                    \
+#define WR_LAUNCH_DZ2(TERMS, FULL_, GT)                                                                                \
         do {                                                                                                          \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_bwd_dz_split128_kernel<TERMS, FULL_>),       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_bwd_dz_split128_kernel<TERMS, FULL_, GT>),   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
-            hipLaunchKernelGGL((joint_bwd_dz_split128_kernel<TERMS, FULL_>), grid2, dim3(256), lds, st, gout_d, ep_d, pp_d, \
+            hipLaunchKernelGGL((joint_bwd_dz_split128_kernel<TERMS, FULL_, GT>), grid2, dim3(256), lds, st,             \
+                               static_cast<const GT *>(gout_d), ep_d, pp_d,                                            \
                                reinterpret_cast<const u32x4 *>(wh), reinterpret_cast<const u32x4 *>(wl),               \
                                logit_lengths_d, target_lengths_d, B, T, U1, J, V, D, n_jt, activation, dz_d, h_d);     \
         } while (0)
-        if (n_jt == 16) { if (terms == 3) WR_LAUNCH_DZ2(3, true); else WR_LAUNCH_DZ2(1, true); }
-        else { if (terms == 3) WR_LAUNCH_DZ2(3, false); else WR_LAUNCH_DZ2(1, false); }
+#define WR_LAUNCH_DZ2_T(TERMS, FULL_) do { if (g16) WR_LAUNCH_DZ2(TERMS, FULL_, __bf16); else WR_LAUNCH_DZ2(TERMS, FULL_, float); } while (0)
+        if (n_jt == 16) { if (terms == 3) WR_LAUNCH_DZ2_T(3, true); else WR_LAUNCH_DZ2_T(1, true); }
+        else { if (terms == 3) WR_LAUNCH_DZ2_T(3, false); else WR_LAUNCH_DZ2_T(1, false); }
+#undef WR_LAUNCH_DZ2_T
 #undef WR_LAUNCH_DZ2
         WR_CHECK_LAUNCH("joint_bwd_dz_split128_kernel");
     }
     return WR_OK;
+}
+}  // namespace
+
+extern "C" int wr_joint_bwd_dz_split(const float *gout_d, const float *ep_d, const float *pp_d, const float *w_out_d,
+                                     const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B, int T, int U1,
+                                     int J, int V, int activation, int terms, float *dz_d, float *h_d, void *workspace_d,
+                                     size_t workspace_bytes, void *stream)
+{
+    return joint_bwd_dz_split_launch(gout_d, false, ep_d, pp_d, w_out_d, logit_lengths_d, target_lengths_d, B, T, U1, J, V,
+                                     activation, terms, dz_d, h_d, workspace_d, workspace_bytes, stream);
+}
+
+extern "C" int wr_joint_bwd_dz_split_bf16(const void *gout_bf16_d, const float *ep_d, const float *pp_d, const float *w_out_d,
+                                          const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B, int T,
+                                          int U1, int J, int V, int activation, int terms, float *dz_d, float *h_d,
+                                          void *workspace_d, size_t workspace_bytes, void *stream)
+{
+    return joint_bwd_dz_split_launch(gout_bf16_d, true, ep_d, pp_d, w_out_d, logit_lengths_d, target_lengths_d, B, T, U1, J,
+                                     V, activation, terms, dz_d, h_d, workspace_d, workspace_bytes, stream);
 }
 
 extern "C" size_t wr_joint_dw_split_workspace_bytes(int B, int T, int U1, int J, int V)
@@ -1893,9 +1965,10 @@ extern "C" size_t wr_joint_dw_split_workspace_bytes(int B, int T, int U1, int J,
     return align_up((size_t)split_dw_parts(V, J) * ((size_t)V * J + V) * sizeof(float), 256) + align_up(M, 256);
 }
 
-extern "C" int wr_joint_bwd_dw_split(const float *gout_d, const float *h_d, const int32_t *logit_lengths_d,
-                                     const int32_t *target_lengths_d, int B, int T, int U1, int J, int V, int terms,
-                                     float *dw_d, float *db_d, void *workspace_d, size_t workspace_bytes, void *stream)
+namespace {
+int joint_bwd_dw_split_launch(const void *gout_d, bool g16, const float *h_d, const int32_t *logit_lengths_d,
+                              const int32_t *target_lengths_d, int B, int T, int U1, int J, int V, int terms,
+                              float *dw_d, float *db_d, void *workspace_d, size_t workspace_bytes, void *stream)
 {
     if (int rc = split_check(B, T, U1, J, V, terms, 0)) return rc;
     WR_REQUIRE(V % 4 == 0 && J % 4 == 0, WR_EUNSUPPORTED,
@@ -1921,18 +1994,36 @@ extern "C" int wr_joint_bwd_dw_split(const float *gout_d, const float *h_d, cons
     long rows_per_part = (M + parts - 1) / parts;
     rows_per_part = (rows_per_part + 15) / 16 * 16;
     const size_t lds = (size_t)kWStages * 2 * 2 * 2 * 4 * 64 * 16;   // three stages of ready-made fragments
-#define WR_LAUNCH_DW(TERMS)                                                                                            \
+#define WR_LAUNCH_DW(TERMS, GT)                                                                                        \
     do {                                                                                                              \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_bwd_dw_split_kernel<TERMS>),                     \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(joint_bwd_dw_split_kernel<TERMS, GT>),                 \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
-        hipLaunchKernelGGL(joint_bwd_dw_split_kernel<TERMS>, dim3(n_vs * n_js * parts), dim3(512), lds, st, gout_d, h_d, \
-                           mask, M, V, J, n_vs, n_js, rows_per_part, part_dw, part_db);                                \
+        hipLaunchKernelGGL((joint_bwd_dw_split_kernel<TERMS, GT>), dim3(n_vs * n_js * parts), dim3(512), lds, st,       \
+                           static_cast<const GT *>(gout_d), h_d, mask, M, V, J, n_vs, n_js, rows_per_part, part_dw, part_db); \
     } while (0)
-    if (terms == 3) WR_LAUNCH_DW(3); else WR_LAUNCH_DW(1);
+    if (g16) { if (terms == 3) WR_LAUNCH_DW(3, __bf16); else WR_LAUNCH_DW(1, __bf16); }
+    else { if (terms == 3) WR_LAUNCH_DW(3, float); else WR_LAUNCH_DW(1, float); }
 #undef WR_LAUNCH_DW
     WR_CHECK_LAUNCH("joint_bwd_dw_split_kernel");
     hipLaunchKernelGGL(split_dw_reduce_kernel, dim3(1024), dim3(256), 0, st, part_dw, part_db, parts, (long)V * J, V, dw_d,
                        db_d);
     WR_CHECK_LAUNCH("split_dw_reduce_kernel");
     return WR_OK;
+}
+}  // namespace
+
+extern "C" int wr_joint_bwd_dw_split(const float *gout_d, const float *h_d, const int32_t *logit_lengths_d,
+                                     const int32_t *target_lengths_d, int B, int T, int U1, int J, int V, int terms,
+                                     float *dw_d, float *db_d, void *workspace_d, size_t workspace_bytes, void *stream)
+{
+    return joint_bwd_dw_split_launch(gout_d, false, h_d, logit_lengths_d, target_lengths_d, B, T, U1, J, V, terms, dw_d, db_d,
+                                     workspace_d, workspace_bytes, stream);
+}
+
+extern "C" int wr_joint_bwd_dw_split_bf16(const void *gout_bf16_d, const float *h_d, const int32_t *logit_lengths_d,
+                                          const int32_t *target_lengths_d, int B, int T, int U1, int J, int V, int terms,
+                                          float *dw_d, float *db_d, void *workspace_d, size_t workspace_bytes, void *stream)
+{
+    return joint_bwd_dw_split_launch(gout_bf16_d, true, h_d, logit_lengths_d, target_lengths_d, B, T, U1, J, V, terms, dw_d,
+                                     db_d, workspace_d, workspace_bytes, stream);
 }

@@ -117,16 +117,20 @@ def joint_backward(gout, ep, pp, w, llens, tlens, terms: int, need_w: bool, need
     U1 = pp.shape[1]
     V = w.shape[0]
     dev = ep.device
-    gout = gout.float().contiguous()
+    # AMP step: the loss hands back a bf16 gradient for bf16 logits; the split kernels take it as it is (bf16 values are
+    # their own hi parts) -- no widening pass over the logits-sized tensor, half the gradient bytes in dZ and dW
+    g16 = gout.dtype == torch.bfloat16 and terms != 0 and V % 8 == 0 and V >= 32 and J % 4 == 0
+    gout = gout.contiguous() if g16 else gout.float().contiguous()
     dz = torch.empty(B, T, U1, J, dtype=torch.float32, device=dev)
     h = torch.empty_like(dz) if need_w else None
     if terms != 0 and V % 4 == 0 and V >= 32:       # same split as the forward (gradient rows 16-byte aligned)
         wsb = lib.wr_joint_dz_split_workspace_bytes(J, V)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        fn = lib.wr_joint_bwd_dz_split_bf16 if g16 else lib.wr_joint_bwd_dz_split
         with torch.cuda.device(dev):
-            rc = lib.wr_joint_bwd_dz_split(_lib.ptr(gout), _lib.ptr(ep), _lib.ptr(pp), _lib.ptr(w), _lib.ptr(llens),
-                                           _lib.ptr(tlens), B, T, U1, J, V, act, terms, _lib.ptr(dz), _lib.ptr(h),
-                                           _lib.ptr(ws), wsb, _lib.current_stream(dev))
+            rc = fn(_lib.ptr(gout), _lib.ptr(ep), _lib.ptr(pp), _lib.ptr(w), _lib.ptr(llens),
+                    _lib.ptr(tlens), B, T, U1, J, V, act, terms, _lib.ptr(dz), _lib.ptr(h),
+                    _lib.ptr(ws), wsb, _lib.current_stream(dev))
         _lib.check(rc, "wr_joint_bwd_dz_split")
     else:
         with torch.cuda.device(dev):
@@ -145,10 +149,11 @@ def joint_backward(gout, ep, pp, w, llens, tlens, terms: int, need_w: bool, need
         if terms != 0 and V % 4 == 0 and J % 4 == 0:
             wsb = lib.wr_joint_dw_split_workspace_bytes(B, T, U1, J, V)
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            fn = lib.wr_joint_bwd_dw_split_bf16 if g16 else lib.wr_joint_bwd_dw_split
             with torch.cuda.device(dev):
-                rc = lib.wr_joint_bwd_dw_split(_lib.ptr(gout), _lib.ptr(h), _lib.ptr(llens), _lib.ptr(tlens), B, T, U1,
-                                               J, V, terms, _lib.ptr(d_w), _lib.ptr(d_b), _lib.ptr(ws), wsb,
-                                               _lib.current_stream(dev))
+                rc = fn(_lib.ptr(gout), _lib.ptr(h), _lib.ptr(llens), _lib.ptr(tlens), B, T, U1,
+                        J, V, terms, _lib.ptr(d_w), _lib.ptr(d_b), _lib.ptr(ws), wsb,
+                        _lib.current_stream(dev))
             _lib.check(rc, "wr_joint_bwd_dw_split")
         else:
             wsb = lib.wr_joint_dw_workspace_bytes(J, V)
@@ -158,7 +163,7 @@ def joint_backward(gout, ep, pp, w, llens, tlens, terms: int, need_w: bool, need
                                          _lib.ptr(d_w), _lib.ptr(d_b), _lib.ptr(ws), wsb, _lib.current_stream(dev))
             _lib.check(rc, "wr_joint_bwd_dw")
     elif need_b:
-        g2 = gout.view(-1, V)
+        g2 = gout.float().view(-1, V)
         if llens is not None:
             tt = torch.arange(T, device=dev)[None, :, None] < llens[:, None, None]
             uu = torch.arange(U1, device=dev)[None, None, :] <= tlens[:, None, None]
