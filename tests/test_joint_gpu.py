@@ -358,7 +358,7 @@ def test_split_backward_takes_a_bf16_gradient_as_it_is(terms, B, T, U1, J, V):
                                           P(wz), wsz, st) != 0      # V not a multiple of 8
 
 
-def test_amp_step_backward_uses_the_bf16_gradient():
+def test_amp_step_backward_uses_the_bf16_gradient(monkeypatch):
     """Under autocast(bfloat16) with precision="bf16" the loss returns a bf16 gradient; the joiner's backward feeds it
     to the split kernels unwidened.  Gradients equal those of the same backward run on the widened gradient."""
     import wenet_celoss_amd as w
@@ -377,12 +377,44 @@ def test_amp_step_backward_uses_the_bf16_gradient():
     assert gl.dtype == torch.bfloat16
     loss.backward()
     ep = m.enc_ffn(enc.detach()).float(); pp = m.pred_ffn(pred.detach()).float()
+    monkeypatch.setenv("WR_AMP_BACKWARD", "kernels")        # the kernels' path: bit-identical on the widened gradient
     want = joint_backward(gl.float(), ep, pp, m.ffn_out.weight.detach(), None, None, 1, True, True)
     got = joint_backward(gl, ep, pp, m.ffn_out.weight.detach(), None, None, 1, True, True)
     for a, b in zip(got, want):
         assert torch.equal(a, b)
     assert m.ffn_out.weight.grad is not None and torch.isfinite(m.ffn_out.weight.grad).all()
     assert enc.grad is not None and torch.isfinite(enc.grad).all() and torch.isfinite(pred.grad).all()
+
+
+@pytest.mark.parametrize("act", ["tanh", "relu"])
+@pytest.mark.parametrize("B,T,U1,J,V", [(2, 9, 5, 128, 304), (1, 70, 3, 256, 1000), (3, 50, 7, 260, 520)])
+def test_amp_backward_library_gemms_match_the_single_term_kernels(monkeypatch, act, B, T, U1, J, V):
+    """The AMP backward's default (dH and [dW | db] as vendor-library bf16 GEMMs around wr_joint_dz_act) against this
+    package's single-term kernels (WR_AMP_BACKWARD=kernels) on the same bf16 gradient: same products, another order
+    of the fp32 sums -- 2e-3 of each result's r.m.s.; padded cells contribute nothing, their dZ rows are exactly zero."""
+    from wenet_celoss_amd.joint import joint_backward, activation_code
+    g = torch.Generator().manual_seed(T + J + V)
+    ep = torch.randn(B, T, J, generator=g).to(DEV); pp = torch.randn(B, U1, J, generator=g).to(DEV)
+    w = (torch.randn(V, J, generator=g) * 0.1).to(DEV)
+    gout = torch.randn(B, T, U1, V, generator=g).to(DEV).to(torch.bfloat16)
+    ll = torch.randint(1, T + 1, (B,), generator=g).to(torch.int32); ll[0] = T
+    tl = torch.randint(0, U1, (B,), generator=g).to(torch.int32); tl[0] = U1 - 1
+    ll, tl = ll.to(DEV), tl.to(DEV)
+    code = activation_code(act)
+    for lens in ((None, None), (ll, tl)):
+        monkeypatch.setenv("WR_AMP_BACKWARD", "kernels")
+        want = joint_backward(gout, ep, pp, w, lens[0], lens[1], 1, True, True, act=code)
+        monkeypatch.setenv("WR_AMP_BACKWARD", "library")
+        got = joint_backward(gout, ep, pp, w, lens[0], lens[1], 1, True, True, act=code)
+        for a, b_ in zip(got, want):
+            assert a.shape == b_.shape and a.dtype == b_.dtype == torch.float32
+            assert float((a - b_).abs().max()) <= 2e-3 * float(b_.pow(2).mean().sqrt()) + 1e-6
+        if lens[0] is not None:
+            tt = torch.arange(T, device=DEV)[None, :, None] < ll[:, None, None]
+            uu = torch.arange(U1, device=DEV)[None, None, :] <= tl[:, None, None]
+            pad = ~(tt & uu)
+            # d_ep sums dZ over u: a frame past the utterance's length has only padded cells
+            assert float(got[0][pad.all(dim=2)].abs().max() if pad.all(dim=2).any() else 0.0) == 0.0
 
 
 def test_split_training_step_with_lengths_matches_exact(monkeypatch):

@@ -126,6 +126,33 @@ def leg_loss_block(dev, steps=2):
             "utt_per_s": round(B / ms * 1e3, 2)}
 
 
+def leg_amp_block(dev, steps=2):
+    """The loss block as the reference runs it under --use_amp (executor.py:91 autocast): 16-bit logits from the single-term
+    joiner forward, rnnt_loss on them, backward with the bf16 gradient (library GEMMs around wr_joint_dz_act / _db_bf16)."""
+    import wenet_celoss_amd as w
+    torch.manual_seed(3)
+    B, T, U, V, E, Pd, J = 16, 1000, 150, 5000, 256, 256, 512
+    enc = torch.randn(B, T, E, device=dev, requires_grad=True)
+    pred = torch.randn(B, U + 1, Pd, device=dev, requires_grad=True)
+    y = torch.randint(1, V, (B, U), dtype=torch.int32, device=dev)
+    ll = torch.full((B,), T, dtype=torch.int32, device=dev); tl = torch.full((B,), U, dtype=torch.int32, device=dev)
+    joint = w.TransducerJoint(V, E, Pd, J, precision="bf16").to(dev)
+    with torch.no_grad():
+        for prm in joint.parameters():
+            prm.copy_(torch.randn_like(prm) * 0.05)
+
+    def step():
+        joint.zero_grad(set_to_none=True); enc.grad = None; pred.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = w.rnnt_loss(joint(enc, pred), y, ll, tl, blank=0, reduction="mean")
+        loss.backward()
+        return loss
+    ms = _median_ms(step, steps)
+    return {"what": "AMP loss block: pre-join projections -> single-term bf16 joiner (bf16 logits) -> RNN-T loss -> backward",
+            "B": B, "T": T, "U": U, "V": V, "J": J, "ms_per_step": round(ms, 2), "utt_per_s": round(B / ms * 1e3, 2),
+            "max_memory_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1)}
+
+
 def leg_ctc(dev, steps=20):
     from wenet_celoss_amd import _lib
     lib = _lib.load()
@@ -248,8 +275,8 @@ def leg_hotword(dev, steps=3):
     return res
 
 
-LEGS = (("joiner", leg_joiner), ("loss_block", leg_loss_block), ("ctc", leg_ctc), ("greedy", leg_greedy),
-        ("beam", leg_beam), ("hotword", leg_hotword))
+LEGS = (("joiner", leg_joiner), ("loss_block", leg_loss_block), ("amp_block", leg_amp_block), ("ctc", leg_ctc),
+        ("greedy", leg_greedy), ("beam", leg_beam), ("hotword", leg_hotword))
 
 
 def collect(dev, budget_s: float = 90.0, only=None):

@@ -752,12 +752,14 @@ __global__ __launch_bounds__(256) void joint_bwd_dz_split128_kernel(
     const int steps = 2 * D;                                // 16-deep steps, two per double step
 
     // W staging: chunk c = tid + 256 q (q < 8) is lane (c & 63) of fragment (c >> 6): fragments 0..15 hi, 16..31 lo
+    // (single-term mode stages the hi image only: chunks 0-3)
+    constexpr int NQ = TERMS == 3 ? 8 : 4;
     struct WRegs { u32x4 v[8]; };
     auto wload = [&](int s, WRegs &z) {
         const int ss = s < steps ? s : steps - 1;
         const int d = ss >> 1, t = ss & 1;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int c = tid + 256 * q, fr = c >> 6, ln = c & 63;
             int jt = fr & 15;
             jt = jt < n_jt ? jt : n_jt - 1;
@@ -768,7 +770,7 @@ __global__ __launch_bounds__(256) void joint_bwd_dz_split128_kernel(
     auto wwrite = [&](int s, const WRegs &z) {
         u32x4 *st = stage + (size_t)(s % kZStages) * 2 * 16 * 64;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) st[tid + 256 * q] = z.v[q];
+        for (int q = 0; q < NQ; ++q) st[tid + 256 * q] = z.v[q];
     };
     // the same, one fragment chunk at a time and without clamps (every step < steps: the fragment index is linear in the
     // step, ((jt * D + d) * 2 + t) = jt * 2D + s), for the main loop, which spreads a step's 8 LDS writes and 8 global loads
@@ -845,8 +847,8 @@ __global__ __launch_bounds__(256) void joint_bwd_dz_split128_kernel(
                 if (TERMS == 3) rl[(c + 2) % 3] = st[(16 + c + 2) * 64];
             }
             if (fast) {                                      // staging of step s + 2 (tiles 0-7), loads of step s + 4 (tiles 8-15)
-                if (c < 8) wwrite_fast(s + 2, zw, c);
-                else wload_fast(s + 4, zw, c - 8);
+                if (c < NQ) wwrite_fast(s + 2, zw, c);
+                else if (c >= 8 && c < 8 + NQ) wload_fast(s + 4, zw, c - 8);
             }
             if (FULL || c < n_jt) {
                 const bf16x8 bhv = __builtin_bit_cast(bf16x8, rh[c % 3]);
@@ -1611,9 +1613,13 @@ int split_check(int B, int T, int U1, int J, int V, int terms, int out_dtype, in
 
 // dz[m, j] *= act'(ep[bt, j] + pp[bu, j]),  h[m, j] = act(...)   (zero in padded cells: dz already is): the second pass
 // of the generic-activation path of joint_bwd_dz_block_kernel<true>
+// HT: dtype of the activation copy (float, or __bf16 with row stride h_ld >= J for the AMP step, whose weight gradient is
+// a library GEMM over bf16 operands: column J of a row is then 1 in valid cells -- the bias gradient falls out of the
+// same GEMM as one more column -- and columns J+1 .. h_ld-1 are zero)
+template <typename HT>
 __global__ void joint_dz_act_kernel(const float *__restrict__ ep, const float *__restrict__ pp, const int32_t *__restrict__ llens,
                                     const int32_t *__restrict__ tlens, int T, int U1, int J, long M, int act,
-                                    float *__restrict__ dz, float *__restrict__ hout)
+                                    float *__restrict__ dz, HT *__restrict__ hout, int h_ld)
 {
     const long n4 = M * (J / 4);                                      // J % 4 == 0
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -1635,7 +1641,18 @@ __global__ void joint_dz_act_kernel(const float *__restrict__ ep, const float *_
             h4[q] = ok ? hh : 0.f;
         }
         *reinterpret_cast<f32x4 *>(dz + m * J + j) = g4;
-        if (hout) *reinterpret_cast<f32x4 *>(hout + m * J + j) = h4;
+        if (hout) {
+            if constexpr (std::is_same<HT, float>::value) {
+                *reinterpret_cast<f32x4 *>(hout + m * h_ld + j) = h4;
+            } else {
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                const bf16x2 p0 = __builtin_convertvector((f32x2){h4[0], h4[1]}, bf16x2);
+                const bf16x2 p1 = __builtin_convertvector((f32x2){h4[2], h4[3]}, bf16x2);
+                *reinterpret_cast<u32x2 *>(hout + m * h_ld + j) = (u32x2){__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
+            }
+            if (j == 0)
+                for (int c = J; c < h_ld; ++c) hout[m * h_ld + c] = (HT)((c == J && ok) ? 1.f : 0.f);
+        }
     }
 }
 
@@ -1658,8 +1675,8 @@ int joint_bwd_dz_block(const float *gout_d, const float *ep_d, const float *pp_d
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(joint_bwd_dz_block_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, st, gout_d, ep_d, pp_d, w_d,
                            llens_d, tlens_d, B, T, U1, J, V, n_js, act, dz_d, h_d);
-        hipLaunchKernelGGL(joint_dz_act_kernel, dim3(256 * 16), dim3(256), 0, st, ep_d, pp_d, llens_d, tlens_d, T, U1, J, M, act,
-                           dz_d, h_d);
+        hipLaunchKernelGGL(joint_dz_act_kernel<float>, dim3(256 * 16), dim3(256), 0, st, ep_d, pp_d, llens_d, tlens_d, T, U1, J, M, act,
+                           dz_d, h_d, J);
     }
     WR_CHECK_LAUNCH("joint_bwd_dz_block_kernel");
     return WR_OK;
@@ -1956,6 +1973,103 @@ extern "C" int wr_joint_bwd_dz_split_bf16(const void *gout_bf16_d, const float *
 {
     return joint_bwd_dz_split_launch(gout_bf16_d, true, ep_d, pp_d, w_out_d, logit_lengths_d, target_lengths_d, B, T, U1, J,
                                      V, activation, terms, dz_d, h_d, workspace_d, workspace_bytes, stream);
+}
+
+// ---- bias gradient from a bf16 logits gradient: db[v] = sum over valid cells of gout[cell, v] ----
+// (the AMP step's weight gradient is a library GEMM; the column sums are this memory-bound pass: a thread owns 8 columns,
+// a workgroup 2 048 columns of one of `parts` row ranges; partial sums, then an ordered reduction: deterministic)
+namespace wr {
+namespace {
+constexpr int kDbParts = 512;
+__global__ __launch_bounds__(256) void joint_db_bf16_kernel(const __bf16 *__restrict__ gout, const unsigned char *__restrict__ mask,
+                                                            long M, int V, long rows_per_part, float *__restrict__ part)
+{
+    const int v = (blockIdx.x * 256 + threadIdx.x) * 8;
+    const long r0 = (long)blockIdx.y * rows_per_part;
+    const long r1 = r0 + rows_per_part < M ? r0 + rows_per_part : M;
+    if (v >= V) return;                                     // V % 8 == 0: a thread's columns are wholly in or out
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const __bf16 *__restrict__ p = gout + v;
+#pragma unroll 4
+    for (long m = r0; m < r1; ++m) {
+        if (mask != nullptr && mask[m] == 0) continue;      // uniform over the workgroup
+        const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p + (size_t)m * V));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[2 * i] += __builtin_bit_cast(float, x[i] << 16);
+            acc[2 * i + 1] += __builtin_bit_cast(float, x[i] & 0xffff0000u);
+        }
+    }
+    float *__restrict__ o = part + (size_t)blockIdx.y * V + v;
+    *reinterpret_cast<f32x4 *>(o) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+    *reinterpret_cast<f32x4 *>(o + 4) = (f32x4){acc[4], acc[5], acc[6], acc[7]};
+}
+__global__ void joint_db_reduce_kernel(const float *__restrict__ part, int parts, int V, float *__restrict__ db)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    float s = 0.f;
+    for (int p = 0; p < parts; ++p) s += part[(size_t)p * V + v];
+    db[v] = s;
+}
+}  // namespace
+}  // namespace wr
+
+extern "C" size_t wr_joint_db_workspace_bytes(int B, int T, int U1, int V)
+{
+    if (B <= 0 || T <= 0 || U1 <= 0 || V <= 0) return 0;
+    return wr::align_up((size_t)wr::kDbParts * V * sizeof(float), 256) + wr::align_up((size_t)B * T * U1, 256);
+}
+
+extern "C" int wr_joint_db_bf16(const void *gout_bf16_d, const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B,
+                                int T, int U1, int V, float *db_d, void *workspace_d, size_t workspace_bytes, void *stream)
+{
+    using namespace wr;
+    WR_REQUIRE(B > 0 && T > 0 && U1 > 0 && V > 0 && V % 8 == 0, WR_EINVAL, "joint_db_bf16: sizes must be positive, V a multiple of 8");
+    WR_REQUIRE(gout_bf16_d && db_d && workspace_d, WR_EINVAL, "joint_db_bf16: null pointer argument");
+    WR_REQUIRE((logit_lengths_d == nullptr) == (target_lengths_d == nullptr), WR_EINVAL,
+               "joint_db_bf16: pass both length arrays or neither");
+    WR_REQUIRE(workspace_bytes >= wr_joint_db_workspace_bytes(B, T, U1, V), WR_EWORKSPACE, "joint_db_bf16: workspace too small");
+    const long M = (long)B * T * U1;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *part = static_cast<float *>(workspace_d);
+    unsigned char *mask = nullptr;
+    if (logit_lengths_d != nullptr) {
+        mask = reinterpret_cast<unsigned char *>(static_cast<char *>(workspace_d) + align_up((size_t)kDbParts * V * sizeof(float), 256));
+        hipLaunchKernelGGL(cell_mask_kernel, dim3(1024), dim3(256), 0, st, logit_lengths_d, target_lengths_d, T, U1, M, mask);
+        WR_CHECK_LAUNCH("cell_mask_kernel");
+    }
+    const int parts = M < kDbParts ? (int)M : kDbParts;
+    const long rows_per_part = (M + parts - 1) / parts;
+    hipLaunchKernelGGL(joint_db_bf16_kernel, dim3((V / 8 + 255) / 256, parts), dim3(256), 0, st,
+                       static_cast<const __bf16 *>(gout_bf16_d), mask, M, V, rows_per_part, part);
+    WR_CHECK_LAUNCH("joint_db_bf16_kernel");
+    hipLaunchKernelGGL(joint_db_reduce_kernel, dim3((V + 255) / 256), dim3(256), 0, st, part, parts, V, db_d);
+    WR_CHECK_LAUNCH("joint_db_reduce_kernel");
+    return WR_OK;
+}
+
+extern "C" int wr_joint_dz_act(float *dz_d, const float *ep_d, const float *pp_d, const int32_t *logit_lengths_d,
+                               const int32_t *target_lengths_d, int B, int T, int U1, int J, int activation, void *h_d,
+                               int h_dtype, int h_ld, void *stream)
+{
+    WR_REQUIRE(B > 0 && T > 0 && U1 > 0 && J > 0 && J % 4 == 0, WR_EINVAL, "joint_dz_act: sizes must be positive, J a multiple of 4");
+    WR_REQUIRE(activation >= WR_ACT_TANH && activation <= WR_ACT_GELU, WR_EINVAL, "joint_dz_act: unknown activation %d", activation);
+    WR_REQUIRE(dz_d && ep_d && pp_d, WR_EINVAL, "joint_dz_act: null pointer argument");
+    WR_REQUIRE((logit_lengths_d == nullptr) == (target_lengths_d == nullptr), WR_EINVAL,
+               "joint_dz_act: pass both length arrays or neither");
+    WR_REQUIRE(h_d == nullptr || ((h_dtype == WR_F32 || h_dtype == WR_BF16) && h_ld >= J && h_ld % 4 == 0), WR_EINVAL,
+               "joint_dz_act: h must be fp32 or bf16 with a row stride >= J that is a multiple of 4");
+    const long M = (long)B * T * U1;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (h_d != nullptr && h_dtype == WR_BF16)
+        hipLaunchKernelGGL(joint_dz_act_kernel<__bf16>, dim3(256 * 16), dim3(256), 0, st, ep_d, pp_d, logit_lengths_d,
+                           target_lengths_d, T, U1, J, M, activation, dz_d, static_cast<__bf16 *>(h_d), h_ld);
+    else
+        hipLaunchKernelGGL(joint_dz_act_kernel<float>, dim3(256 * 16), dim3(256), 0, st, ep_d, pp_d, logit_lengths_d,
+                           target_lengths_d, T, U1, J, M, activation, dz_d, static_cast<float *>(h_d), h_d ? h_ld : J);
+    WR_CHECK_LAUNCH("joint_dz_act_kernel");
+    return WR_OK;
 }
 
 extern "C" size_t wr_joint_dw_split_workspace_bytes(int B, int T, int U1, int J, int V)
