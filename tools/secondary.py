@@ -131,6 +131,7 @@ def leg_amp_block(dev, steps=2):
     joiner forward, rnnt_loss on them, backward with the bf16 gradient (library GEMMs around wr_joint_dz_act / _db_bf16)."""
     import wenet_celoss_amd as w
     torch.manual_seed(3)
+    torch.cuda.reset_peak_memory_stats()
     B, T, U, V, E, Pd, J = 16, 1000, 150, 5000, 256, 256, 512
     enc = torch.randn(B, T, E, device=dev, requires_grad=True)
     pred = torch.randn(B, U + 1, Pd, device=dev, requires_grad=True)

@@ -1990,15 +1990,23 @@ __global__ __launch_bounds__(256) void joint_db_bf16_kernel(const __bf16 *__rest
     if (v >= V) return;                                     // V % 8 == 0: a thread's columns are wholly in or out
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const __bf16 *__restrict__ p = gout + v;
-#pragma unroll 4
-    for (long m = r0; m < r1; ++m) {
-        if (mask != nullptr && mask[m] == 0) continue;      // uniform over the workgroup
-        const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p + (size_t)m * V));
+    constexpr int R = 8;                                    // rows in flight per thread (rows past the range repeat the last
+    for (long m = r0; m < r1; m += R) {                     // one with weight 0)
+        u32x4 x[R];
+        bool on[R];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc[2 * i] += __builtin_bit_cast(float, x[i] << 16);
-            acc[2 * i + 1] += __builtin_bit_cast(float, x[i] & 0xffff0000u);
+        for (int q = 0; q < R; ++q) {
+            const long mm = m + q < r1 ? m + q : r1 - 1;
+            x[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p + (size_t)mm * V));
+            on[q] = m + q < r1 && (mask == nullptr || mask[mm] != 0);
         }
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[2 * i] += on[q] ? __builtin_bit_cast(float, x[q][i] << 16) : 0.f;       // a select: padded cells may hold anything
+                acc[2 * i + 1] += on[q] ? __builtin_bit_cast(float, x[q][i] & 0xffff0000u) : 0.f;
+            }
     }
     float *__restrict__ o = part + (size_t)blockIdx.y * V + v;
     *reinterpret_cast<f32x4 *>(o) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
