@@ -11,6 +11,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $CMD > 
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $CMD > $O/bench_fetch.log 2>&1 &&
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $CMD > $O/bench_write.log 2>&1 &&
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dec -- python3 tools/secondary.py greedy beam hotword > $O/secondary_dec.log 2>&1 &&
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/jc -- python3 tools/secondary.py joiner loss_block ctc > $O/secondary_jc.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/jc -- python3 tools/secondary.py joiner loss_block amp_block ctc > $O/secondary_jc.log 2>&1
 echo "exit $?"
 tail -2 $O/bench_kt.log | cut -c1-300

@@ -84,7 +84,8 @@ def main():
                                         "hbm_bytes": fetch[k] * 1024 * 2 + write[k] * 1024,
                                         "source": f"profiles/{a.tag}_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                                                   "passes; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md)"}
-    json.dump({"tag": a.tag, "kernels": traffic}, open(os.path.join(out_dir, "traffic.json"), "w"), indent=1)
+    if traffic:                                      # only a run with both PMC passes may replace the committed constants
+        json.dump({"tag": a.tag, "kernels": traffic}, open(os.path.join(out_dir, "traffic.json"), "w"), indent=1)
     print("\n".join(lines))
 
 
