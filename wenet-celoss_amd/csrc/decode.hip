@@ -80,7 +80,10 @@ enum PredictorType { kPredLstm = 0, kPredEmbedding = 1, kPredConv = 2 };
 constexpr int kMaxLanes = 1024;      // streams (greedy) or utterances x beam decoded together
 constexpr int kMaxBeam = 16;
 constexpr int kMaxLook = 4;          // greedy look-ahead: encoder frames evaluated per micro-step against one predictor state
-constexpr int kStepsPerGraph = 16;
+#ifndef WR_STEPS_PER_GRAPH
+#define WR_STEPS_PER_GRAPH 16
+#endif
+constexpr int kStepsPerGraph = WR_STEPS_PER_GRAPH;
 constexpr int kStageSlots = 4;
 
 struct Dims {
