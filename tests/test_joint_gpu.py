@@ -417,6 +417,54 @@ def test_amp_backward_library_gemms_match_the_single_term_kernels(monkeypatch, a
             assert float(got[0][pad.all(dim=2)].abs().max() if pad.all(dim=2).any() else 0.0) == 0.0
 
 
+@pytest.mark.parametrize("h_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", ["tanh", "swish"])
+def test_dz_act_and_db_entry_points(h_dtype, act):
+    """wr_joint_dz_act (activation gradient in place + the activation copy, fp32 or bf16, with the ones column when the row
+    stride exceeds J) and wr_joint_db_bf16 (column sums of a bf16 gradient over the valid cells) against PyTorch."""
+    from wenet_celoss_amd import _lib
+    from wenet_celoss_amd.joint import activation_code, _TORCH_ACTIVATIONS
+    lib = _lib.load()
+    B, T, U1, J, V = 2, 11, 4, 36, 72
+    g = torch.Generator().manual_seed(17)
+    ep = torch.randn(B, T, J, generator=g).to(DEV); pp = torch.randn(B, U1, J, generator=g).to(DEV)
+    dh = torch.randn(B, T, U1, J, generator=g).to(DEV)
+    ll = torch.tensor([11, 6], dtype=torch.int32, device=DEV); tl = torch.tensor([3, 1], dtype=torch.int32, device=DEV)
+    tt = torch.arange(T, device=DEV)[None, :, None] < ll[:, None, None]
+    uu = torch.arange(U1, device=DEV)[None, None, :] <= tl[:, None, None]
+    valid = (tt & uu)
+    st, P = _lib.current_stream(torch.device(DEV)), _lib.ptr
+    z = (ep[:, :, None, :] + pp[:, None, :, :]).double().requires_grad_(True)
+    hh = _TORCH_ACTIVATIONS[act]()(z)
+    (dact,) = torch.autograd.grad(hh.sum(), z)
+    for lens, ok in (((None, None), torch.ones_like(valid)), ((ll, tl), valid)):
+        for ld in (J, J + 8):
+            dz = dh.clone()
+            h = torch.full((B, T, U1, ld), float("nan"), dtype=h_dtype, device=DEV)
+            _lib.check(lib.wr_joint_dz_act(P(dz), P(ep), P(pp), P(lens[0]), P(lens[1]), B, T, U1, J, activation_code(act), P(h),
+                                           _lib.dtype_code(h_dtype), ld, st))
+            want_dz = (dh.double() * dact) * ok[..., None]
+            torch.testing.assert_close(dz.double(), want_dz, rtol=2e-5, atol=2e-6)
+            want_h = (hh.detach() * ok[..., None])
+            tol = dict(rtol=1e-5, atol=1e-6) if h_dtype == torch.float32 else dict(rtol=8e-3, atol=1e-6)
+            torch.testing.assert_close(h[..., :J].double(), want_h, **tol)
+            if ld > J:
+                assert torch.equal(h[..., J].float(), ok.float())
+                assert float(h[..., J + 1:].float().abs().max()) == 0.0
+    # bias gradient
+    gout = torch.randn(B, T, U1, V, generator=g).to(DEV).to(torch.bfloat16)
+    gout[1, 8:] = float("nan")                                       # padded frames may hold anything
+    wsb = lib.wr_joint_db_workspace_bytes(B, T, U1, V); ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    db = torch.full((V,), float("nan"), device=DEV)
+    _lib.check(lib.wr_joint_db_bf16(P(gout), P(ll), P(tl), B, T, U1, V, P(db), P(ws), wsb, st))
+    want = torch.where(valid[..., None], gout.float(), torch.zeros((), device=DEV)).double().sum(dim=(0, 1, 2))
+    torch.testing.assert_close(db.double(), want, rtol=1e-5, atol=1e-5)
+    gout = torch.nan_to_num(gout.float()).to(torch.bfloat16)
+    _lib.check(lib.wr_joint_db_bf16(P(gout), None, None, B, T, U1, V, P(db), P(ws), wsb, st))
+    torch.testing.assert_close(db.double(), gout.double().sum(dim=(0, 1, 2)), rtol=1e-5, atol=1e-5)
+    assert lib.wr_joint_db_bf16(P(gout), None, None, B, T, U1, 36, P(db), P(ws), wsb, st) != 0      # V % 8
+
+
 def test_split_training_step_with_lengths_matches_exact(monkeypatch):
     """Joiner + RNN-T loss, forward and backward, ragged lengths: every gradient of the bf16x3 mode against the exact
     mode's (tolerances at the assertion); the environment switch selects the same path as the argument."""
