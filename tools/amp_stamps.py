@@ -21,7 +21,7 @@ wss = lib.wr_joint_split_workspace_bytes(J, V); ws = torch.empty(wss, dtype=torc
 out = torch.empty(B, T, U1, V, dtype=torch.bfloat16, device=dev)
 cells = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 form = int(sys.argv[2]) if len(sys.argv) > 2 else 0           # knob 12 for 64 cells: 0 two per CU, 1 one per CU
-lib.wr_tune_set(12, 2 if cells == 128 else form)
+lib.wr_tune_set(12, (3 if form == 3 else 2) if cells == 128 else form)
 f = lambda: _lib.check(lib.wr_joint_fwd_split(P(ep), P(pp), P(w), P(b), None, None, B, T, U1, J, V, 0, 1, P(out), 2, P(ws), wss, st))
 t0 = time.time()
 while time.time() - t0 < 2.0:
@@ -30,7 +30,8 @@ while time.time() - t0 < 2.0:
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); f(); e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
-WGS, WAVES, PTS = 2048, 4, 12
+WAVES = 8 if (cells == 128 and form == 3) else 4
+WGS, PTS = 2048 * 4 // WAVES, 12
 buf = np.zeros(WGS * WAVES * PTS, dtype=np.uint64)
 lib.wr_debug_read_js_stamps.restype = ctypes.c_int
 lib.wr_debug_read_js_stamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
@@ -53,7 +54,7 @@ res = {
         "mfma_first_set_of_round": med(r[..., 9] / np.maximum(rounds, 1)),
         "mfma_other_sets_each": med((r[..., 6] - r[..., 9]) / np.maximum(r[..., 10] - rounds, 1)),
     },
-    "ideal_mfma_cycles_per_set": (4 if cells == 64 else 2) * (cells // 32) * 2 * 32,
+    "ideal_mfma_cycles_per_set": (4 if cells == 64 else 2) * (cells // 32) * 2 * 32, "waves_per_workgroup": WAVES,
 }
 res["us_per_workgroup"] = round(res["cycles_per_workgroup"]["whole"] / res["clock_MHz_median"], 2)
 print(json.dumps(res, indent=1))

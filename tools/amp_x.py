@@ -24,7 +24,7 @@ for knob, store in ((0, 0), (0, 1), (1, 0), (2, 0)):
     same = None
     if ref is None: ref = out[:1].clone()
     else: same = bool(torch.equal(ref, out[:1]))
-    print(json.dumps({"flags": os.environ.get("WR_EXTRA_HIPCC_FLAGS", ""), "parts": PARTS, "form": {0: "64 cells x 2 per CU", 1: "64 cells", 2: "128 cells"}[knob],
+    print(json.dumps({"flags": os.environ.get("WR_EXTRA_HIPCC_FLAGS", ""), "parts": PARTS, "form": {0: "64 cells x 2 per CU", 1: "64 cells", 2: "128 cells", 3: "128 cells x 8 waves"}[knob],
                       "stores": "transposed" if store else "staged",
                       "ms": round(ms, 3), "TFLOPs": round(flops / ms / 1e9, 1), "identical_to_first": same}), flush=True)
 lib.wr_tune_set(12, 0); lib.wr_tune_set(13, 0)

@@ -136,8 +136,12 @@ template <> __device__ __forceinline__ __bf16 to_out<__bf16>(float x) { return (
 // (both have the same register layout), so a tile comes out transposed -- a lane holds ONE lattice cell and 4 x 4
 // consecutive vocabulary entries of it, which it adds the bias to, packs and stores itself (8 or 16 bytes per lane and
 // store): no LDS stage, no wave barriers, a quarter of the store instructions of the cell-major layout.
-template <int TERMS, typename OutT, bool LSE = false, int RT = 2, int OCC = 1, bool TRN = false>
-__global__ __launch_bounds__(64 * kSWaves, OCC) void joint_fwd_split_kernel(
+// NW = waves per workgroup: 4 in every shipped form.  8 with RT = 4, OCC = 2 is the 128-cell form as ONE workgroup of eight
+// waves per CU (two per SIMD, 256 registers each; a 4 x 2 register tile needs half the W bytes per MFMA): measured 9.1-10.2 ms
+// against 7.8 for two 64-cell workgroups -- eight accumulator tiles in 256 registers spill in the staged epilogue
+// (26 k cycles per round), the transposed epilogue does not but stores 16-byte pieces -- so it is not instantiated.
+template <int TERMS, typename OutT, bool LSE = false, int RT = 2, int OCC = 1, bool TRN = false, int NW = kSWaves>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : OCC) void joint_fwd_split_kernel(
     const float *__restrict__ ep, const float *__restrict__ pp, const u32x4 *__restrict__ wh, const u32x4 *__restrict__ wl,
     const float *__restrict__ bias, const int32_t *__restrict__ llens, const int32_t *__restrict__ tlens, int B, int T,
     int U1, int J, int Jp, int V, int Vp, int npart, int act, OutT *__restrict__ out, JointLse lse = JointLse{},
@@ -147,7 +151,9 @@ __global__ __launch_bounds__(64 * kSWaves, OCC) void joint_fwd_split_kernel(
     constexpr int SM = 32 * RT;                            // lattice cells of this workgroup
     constexpr int PF = RT == 4 ? 2 : kSPF;                 // k-steps per register set (eight accumulator tiles leave room for less)
     static_assert(RT == 2 || (RT == 4 && TERMS == 1 && !LSE), "128-cell tiles: single-term mode without row statistics");
-    static_assert(OCC == 1 || (OCC == 2 && RT == 2 && TERMS == 1 && !LSE), "two workgroups per CU: single-term mode, 64 cells");
+    static_assert(OCC == 1 || (OCC == 2 && TERMS == 1 && !LSE && ((RT == 2 && NW == 4) || (RT == 4 && NW == 8))),
+                  "two waves per SIMD: single-term mode; 64 cells x two workgroups or 128 cells x eight waves");
+    static_assert(NW == 4 || NW == 8, "waves per workgroup");
     static_assert(!TRN || (TERMS == 1 && !LSE), "transposed tiles: single-term mode without row statistics");
     const int JS = Jp + 8;                                 // padded row stride (bf16 elements): 16-byte pad
     unsigned short *Ahi = lds_s;                            // [SM][JS]
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(64 * kSWaves, OCC) void joint_fwd_split_kernel(
     const int pair0 = part * ppp;
     const int npairs = pairs - pair0 < ppp ? pairs - pair0 : ppp;
     if (npairs <= 0) return;
-    const int rounds = (npairs + kSWaves - 1) / kSWaves;
+    const int rounds = (npairs + NW - 1) / NW;
     const int total = rounds * cpr;
 
     // fragment pointers of this lane
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(64 * kSWaves, OCC) void joint_fwd_split_kernel(
     // W fragments of set li (PF k-steps x kSCT column tiles of this wave's pair) -> registers; k-step i alone when i >= 0
     // (the main loop issues a set's loads between the MFMAs of the set two ahead of it, one k-step's loads per k-step)
     auto set_base = [&](int lr, int lc0) -> size_t {
-        const int pr = lr * kSWaves + wave;
+        const int pr = lr * NW + wave;
         const int ct0 = (pair0 + (pr < npairs ? pr : npairs - 1)) * kSCT;   // waves past the last pair reload it (results dropped)
         return ((size_t)ct0 * S + (size_t)lc0 * PF) * 64;
     };
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(64 * kSWaves, OCC) void joint_fwd_split_kernel(
 
     // bias of this part's columns -> LDS (read back per round without touching the vector-memory counter)
     if (OCC == 1) {
-        for (int i = tid; i < npairs * 32 * kSCT; i += 64 * kSWaves) {
+        for (int i = tid; i < npairs * 32 * kSCT; i += 64 * NW) {
             const int col = pair0 * 32 * kSCT + i;
             bias_s[i] = col < V ? bias[col] : 0.f;
         }
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(64 * kSWaves, OCC) void joint_fwd_split_kernel(
     const bool bias_vec = (reinterpret_cast<size_t>(bias) & 15) == 0;
     auto next_bias = [&](int r) {
         if (OCC == 1) return;
-        const int pr = r * kSWaves + wave;
+        const int pr = r * NW + wave;
         if constexpr (TRN) {
 #pragma unroll
             for (int c = 0; c < kSCT; ++c)
@@ -277,22 +283,22 @@ __global__ __launch_bounds__(64 * kSWaves, OCC) void joint_fwd_split_kernel(
         constexpr int RB = 2;                               // rows per batch (8 or 16 loads per lane in flight; larger batches
                                                             // measured no faster -- at 8 rows of 16-byte loads 12 % slower)
         typedef float fvec __attribute__((ext_vector_type(VW)));
-        static_assert(SM / kSWaves % RB == 0, "rows per wave");
+        static_assert(SM / NW % RB == 0, "rows per wave");
         fvec ec[KI];                                        // the ep row of the cell being evaluated
         long ec_bt = -1;
-        for (int rb = 0; rb < SM / kSWaves; rb += RB) {
+        for (int rb = 0; rb < SM / NW; rb += RB) {
             fvec ev[RB][KI], pv[RB][KI];
             bool fresh[RB];
             long bt_last = ec_bt;
 #pragma unroll
             for (int q = 0; q < RB; ++q) {
-                const int row = wave + kSWaves * (rb + q);
+                const int row = wave + NW * (rb + q);
                 const float *__restrict__ e = ep + (size_t)w_bt * J;
                 const float *__restrict__ p = pp + ((size_t)w_b * U1 + w_u) * J;
                 fresh[q] = w_bt != bt_last;
                 bt_last = w_bt;
-                if (m0 + row + kSWaves < M) {               // the wave's next cell (cells past M keep the last valid address)
-                    w_u += kSWaves;
+                if (m0 + row + NW < M) {               // the wave's next cell (cells past M keep the last valid address)
+                    w_u += NW;
                     while (w_u >= U1) {
                         w_u -= U1;
                         ++w_bt;
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(64 * kSWaves, OCC) void joint_fwd_split_kernel(
             ec_bt = bt_last;
 #pragma unroll
             for (int q = 0; q < RB; ++q) {
-                const int row = wave + kSWaves * (rb + q);
+                const int row = wave + NW * (rb + q);
                 const bool in = m0 + row < M;
 #pragma unroll
                 for (int i = 0; i < KI; ++i) {
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(64 * kSWaves, OCC) void joint_fwd_split_kernel(
         const bool last = cc0 + 1 == cpr;
         advance(cr, cc0);
         if (!last) return;
-        const int pr = r * kSWaves + wave;
+        const int pr = r * NW + wave;
         const int ct0 = (pair0 + pr) * kSCT;
         // interior tiles (all 64 cells and all 64 columns valid: everything but the matrix edges) store without
         // per-element guards, so the stores issue back to back
@@ -625,15 +631,15 @@ __global__ __launch_bounds__(64 * kSWaves, OCC) void joint_fwd_split_kernel(
 #ifdef WR_JS_STAMPS
     WR_JS_NOW(js_t2);
     WR_JS_NOW_RT(js_r2);
-    if (lane == 0 && blockIdx.x % 16 == 0 && blockIdx.x / 16 < kJsWgs) {
-        unsigned long long *o = g_js + ((size_t)(blockIdx.x / 16) * kSWaves + wave) * kJsPts;
+    if (lane == 0 && blockIdx.x % 16 == 0 && blockIdx.x / 16 < kJsWgs * kSWaves / NW) {
+        unsigned long long *o = g_js + ((size_t)(blockIdx.x / 16) * NW + wave) * kJsPts;
         o[0] = js_t0; o[1] = js_t1; o[2] = js_t2; o[3] = js_r0; o[4] = js_r2; o[5] = js_ld; o[6] = js_mm; o[7] = js_ep;
         o[8] = js_ep_n; o[9] = js_mm_first; o[10] = (unsigned long long)total; o[11] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
     }
 #endif
     if (LSE) {
         __syncthreads();                                    // every wave is done with the activation images: reuse them
-        joint_lse_finish<kSWaves>(lse, reinterpret_cast<float *>(lds_s), rm, rs, llens, tlens,
+        joint_lse_finish<NW>(lse, reinterpret_cast<float *>(lds_s), rm, rs, llens, tlens,
                                   reinterpret_cast<const float *>(out), m0, M, T, U1, V);
     }
 }
