@@ -329,13 +329,13 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(
 #pragma unroll
             for (int q = 0; q < UN; ++q) dov(i + q * kWave, x[q]);
         }
-        for (; i < nv; i += (UN / 2) * kWave) {          // remainder: half-size batches, still issued together
-            vec_t x[UN / 2];
+        if (i < nv) {                                    // remainder (fewer than UN vectors per lane): one guarded batch
+            vec_t x[UN];
 #pragma unroll
-            for (int q = 0; q < UN / 2; ++q)
+            for (int q = 0; q < UN; ++q)
                 if (i + q * kWave < nv) x[q] = ldv<NT>(body + i + q * kWave);
 #pragma unroll
-            for (int q = 0; q < UN / 2; ++q)
+            for (int q = 0; q < UN; ++q)
                 if (i + q * kWave < nv) dov(i + q * kWave, x[q]);
         }
     }

@@ -89,13 +89,13 @@ __device__ __forceinline__ float wave_row_lse(const T *__restrict__ row, int V, 
 #pragma unroll
         for (int q = 0; q < UN; ++q) stat_addv<T>(st, x[q]);
     }
-    for (; i < sp.nv; i += (UN / 2) * kWave) {
-        vec_t x[UN / 2];
-#pragma unroll
-        for (int q = 0; q < UN / 2; ++q)
+    if (i < sp.nv) {                                        // remainder (fewer than UN vectors per lane): ONE guarded batch, so a
+        vec_t x[UN];                                        // short row (16-bit logits: 625 vectors at V = 5000) has all its
+#pragma unroll                                              // loads in flight at once instead of 8 + a straggler
+        for (int q = 0; q < UN; ++q)
             if (i + q * kWave < sp.nv) x[q] = ldv<NT>(body + i + q * kWave);
 #pragma unroll
-        for (int q = 0; q < UN / 2; ++q)
+        for (int q = 0; q < UN; ++q)
             if (i + q * kWave < sp.nv) stat_addv<T>(st, x[q]);
     }
     const float M = wave_max(st.m);
