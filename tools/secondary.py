@@ -79,6 +79,17 @@ def leg_joiner(dev, steps=3):
                                                               P(out16), _lib.WR_BF16, P(ws_s), wss, st)), steps)
     res["fwd_bf16_single_term"] = {"ms": round(ms, 3), "TFLOPs": round(flops / ms / 1e9, 1),
                                    "frac": round(flops / ms / 1e9 / BF16_DENSE_PEAK_TF, 4), "logits": "bf16"}
+    # reference point: the vendor GEMM library on the BARE contraction of the same shape (H given in bf16, no tanh, no bias)
+    try:
+        hb = torch.tanh(torch.randn(B * T * U1, J, device=dev, generator=g)).to(torch.bfloat16)
+        wb = w.to(torch.bfloat16)
+        o2 = out16.view(B * T * U1, V)
+        ms = _median_ms(lambda: torch.mm(hb, wb.t(), out=o2), steps)
+        res["vendor_gemm_bf16_bare_contraction"] = {"ms": round(ms, 3), "TFLOPs": round(flops / ms / 1e9, 1),
+                                                    "frac": round(flops / ms / 1e9 / BF16_DENSE_PEAK_TF, 4)}
+        del hb, wb, o2
+    except Exception as e:
+        res["vendor_gemm_bf16_bare_contraction"] = {"error": str(e)[:120]}
     del out16
     out3 = torch.empty(B, T, U1, V, device=dev)
     ms = _median_ms(lambda: _lib.check(lib.wr_joint_fwd_split(P(ep), P(pp), P(w), P(b), None, None, B, T, U1, J, V, 0, 3,
