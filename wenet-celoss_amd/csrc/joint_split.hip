@@ -1983,14 +1983,16 @@ extern "C" int wr_joint_bwd_dz_split_bf16(const void *gout_bf16_d, const float *
 
 // ---- bias gradient from a bf16 logits gradient: db[v] = sum over valid cells of gout[cell, v] ----
 // (the AMP step's weight gradient is a library GEMM; the column sums are this memory-bound pass: a thread owns 8 columns,
-// a workgroup 2 048 columns of one of `parts` row ranges; partial sums, then an ordered reduction: deterministic)
+// a workgroup of 640 threads whole rows of up to 5 120 columns -- sequential 10 KB reads at V = 5000 -- of one of `parts`
+// row ranges; partial sums, then an ordered reduction: deterministic)
 namespace wr {
 namespace {
-constexpr int kDbParts = 512;
-__global__ __launch_bounds__(256) void joint_db_bf16_kernel(const __bf16 *__restrict__ gout, const unsigned char *__restrict__ mask,
-                                                            long M, int V, long rows_per_part, float *__restrict__ part)
+constexpr int kDbParts = 1024;
+constexpr int kDbThreads = 640;
+__global__ __launch_bounds__(kDbThreads) void joint_db_bf16_kernel(const __bf16 *__restrict__ gout, const unsigned char *__restrict__ mask,
+                                                                   long M, int V, long rows_per_part, float *__restrict__ part)
 {
-    const int v = (blockIdx.x * 256 + threadIdx.x) * 8;
+    const int v = (blockIdx.x * kDbThreads + threadIdx.x) * 8;
     const long r0 = (long)blockIdx.y * rows_per_part;
     const long r1 = r0 + rows_per_part < M ? r0 + rows_per_part : M;
     if (v >= V) return;                                     // V % 8 == 0: a thread's columns are wholly in or out
@@ -2055,7 +2057,7 @@ extern "C" int wr_joint_db_bf16(const void *gout_bf16_d, const int32_t *logit_le
     }
     const int parts = M < kDbParts ? (int)M : kDbParts;
     const long rows_per_part = (M + parts - 1) / parts;
-    hipLaunchKernelGGL(joint_db_bf16_kernel, dim3((V / 8 + 255) / 256, parts), dim3(256), 0, st,
+    hipLaunchKernelGGL(joint_db_bf16_kernel, dim3((V / 8 + kDbThreads - 1) / kDbThreads, parts), dim3(kDbThreads), 0, st,
                        static_cast<const __bf16 *>(gout_bf16_d), mask, M, V, rows_per_part, part);
     WR_CHECK_LAUNCH("joint_db_bf16_kernel");
     hipLaunchKernelGGL(joint_db_reduce_kernel, dim3((V + 255) / 256), dim3(256), 0, st, part, parts, V, db_d);
