@@ -105,6 +105,22 @@ class _JointFn(torch.autograd.Function):
         return d_ep, d_pp, d_w, d_b, None, None, None, None, None
 
 
+_MM_OUT_DTYPE = None
+
+
+def _mm_takes_out_dtype() -> bool:
+    """torch.mm(bf16, bf16, out_dtype=float32) -- fp32 results of a bf16 GEMM without a rounding to bf16 in between -- is what
+    the library form of the AMP backward needs; a PyTorch without it keeps the backward on this package's kernels."""
+    global _MM_OUT_DTYPE
+    if _MM_OUT_DTYPE is None:
+        try:
+            a = torch.zeros(8, 8, dtype=torch.bfloat16, device="cuda")
+            _MM_OUT_DTYPE = torch.mm(a, a, out_dtype=torch.float32).dtype == torch.float32
+        except (TypeError, RuntimeError):
+            _MM_OUT_DTYPE = False
+    return _MM_OUT_DTYPE
+
+
 def _amp_backward_library(lib, gout, ep, pp, w, llens, tlens, need_w, need_b, gout_zero_in_padding, act):
     """Single-term (AMP) backward with a bf16 logits gradient: the two contractions dH = dY W and [dW | db] = dY^T [H | 1]
     are plain bf16 GEMMs with fp32 accumulation and fp32 results -- they go to the vendor GEMM library (measured at the
@@ -158,7 +174,7 @@ def joint_backward(gout, ep, pp, w, llens, tlens, terms: int, need_w: bool, need
     # their own hi parts) -- no widening pass over the logits-sized tensor, half the gradient bytes in dZ and dW
     g16 = gout.dtype == torch.bfloat16 and terms != 0 and V % 8 == 0 and V >= 32 and J % 4 == 0
     gout = gout.contiguous() if g16 else gout.float().contiguous()
-    if g16 and terms == 1 and os.environ.get("WR_AMP_BACKWARD", "library") != "kernels":
+    if g16 and terms == 1 and os.environ.get("WR_AMP_BACKWARD", "library") != "kernels" and _mm_takes_out_dtype():
         return _amp_backward_library(lib, gout, ep, pp, w, llens, tlens, need_w, need_b, gout_zero_in_padding, act)
     dz = torch.empty(B, T, U1, J, dtype=torch.float32, device=dev)
     h = torch.empty_like(dz) if need_w else None
