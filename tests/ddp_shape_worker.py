@@ -34,6 +34,12 @@ V, D, J, H = 5000, 256, 512, 256
 ACCUM = 4
 
 
+def amp_on() -> bool:
+    """WR_SHAPE_AMP=1: the reference's --use_amp step (executor.py:91 autocast, here bfloat16) with the joiner's 16-bit
+    single-term mode: bf16 logits, the loss's bf16 gradient, the library-GEMM backward."""
+    return os.environ.get("WR_SHAPE_AMP", "0") == "1"
+
+
 class FFBlock(torch.nn.Module):
     def __init__(self, d, hidden, pairs):
         super().__init__()
@@ -70,7 +76,8 @@ class BudgetEncoder(torch.nn.Module):
 def build_model(dev):
     import wenet_celoss_amd as w
     torch.manual_seed(7)
-    m = w.Transducer(V, 0, BudgetEncoder(), w.RNNPredictor(V, D, D, 0.0, H, 2, dropout=0.0), w.TransducerJoint(V, D, D, J),
+    m = w.Transducer(V, 0, BudgetEncoder(), w.RNNPredictor(V, D, D, 0.0, H, 2, dropout=0.0),
+                     w.TransducerJoint(V, D, D, J, precision="bf16" if amp_on() else None),
                      ctc=w.CTC(V, D), ctc_weight=0.25, transducer_weight=0.75, hw_weight=0.0)
     return m.to(dev)
 
@@ -99,7 +106,8 @@ def accumulate(model_call, params, rank, dev, sync_ctx=None, timings=None):
         with ctx:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            loss = model_call(*micro_batch(rank, i, dev))["loss"] / ACCUM         # executor.py:101 loss / accum_grad
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp_on()):  # executor.py:91
+                loss = model_call(*micro_batch(rank, i, dev))["loss"] / ACCUM     # executor.py:101 loss / accum_grad
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             loss.backward()
@@ -138,13 +146,14 @@ def main():
     pred = m.predictor(add_blank(text, 0, -1)).detach().requires_grad_(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    _, lr = m.compute_loss(enc, mask.squeeze(1).sum(1), pred, text, tlen)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp_on()):
+        _, lr = m.compute_loss(enc, mask.squeeze(1).sum(1), pred, text, tlen)
     lr.backward()
     torch.cuda.synchronize()
     loss_block_ms = (time.perf_counter() - t0) * 1e3
     m.zero_grad()
     no_sync_bwd = sorted(t["backward_ms"] for t in timings[:-1])[len(timings[:-1]) // 2]
-    info = {"rank": rank, "backend": backend, "parameters": nparam, "gradient_MB": round(nparam * 4 / 1e6, 1),
+    info = {"rank": rank, "backend": backend, "amp": amp_on(), "parameters": nparam, "gradient_MB": round(nparam * 4 / 1e6, 1),
             "steps": timings, "loss_block_fwd_bwd_ms": round(loss_block_ms, 2),
             "all_reduce_ms(sync backward - median no_sync backward)": round(timings[-1]["backward_ms"] - no_sync_bwd, 2)}
     torch.save({"grads": grads, "info": json.dumps(info)}, f"{out_path}.rank{rank}")
