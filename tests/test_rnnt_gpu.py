@@ -238,6 +238,38 @@ def test_half_precision_logits(dtype, tol, V):
         assert not x.grad[b, llens[b]:].any() and not x.grad[b, :, tlens[b] + 1:].any()
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_full_length_utterance_16bit_logits_vs_f64(dt):
+    """The AMP step's loss at the BASELINE lattice scale: one whole utterance (T=1000, U=150, V=5000) of 16-bit logits.
+    The kernels read the 16-bit values, compute in fp32 / fp64 as for fp32 logits and round the gradient to the input
+    dtype; the float64 oracle gets the same values widened.  Cost within one rounding of the 16-bit format it is returned in;
+    gradient within one rounding of the 16-bit format (2^-8 relative for bfloat16, 2^-11 for float16) plus the fp32 path's own 1e-4 / 1e-5."""
+    import wenet_celoss_amd as w
+    T, U, V = 1000, 150, 5000
+    gen = torch.Generator(device=DEV).manual_seed(99)
+    x = torch.randn(1, T, U + 1, V, device=DEV, generator=gen).to(dt)
+    y = torch.randint(1, V, (1, U), dtype=torch.int32, device=DEV, generator=gen)
+    ll = torch.tensor([T], dtype=torch.int32, device=DEV); tl = torch.tensor([U], dtype=torch.int32, device=DEV)
+    lg = x.detach().requires_grad_(True)
+    cost = w.rnnt_loss(lg, y, ll, tl, blank=0, reduction="sum")
+    cost.backward()
+    assert lg.grad.dtype == dt
+    c64, g64 = oracle.rnnt_loss_f64(x.float().cpu().numpy(), y.cpu().numpy(), np.array([T], np.int32), np.array([U], np.int32))
+    ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    assert cost.dtype == dt                                     # the cost comes back in the logits' dtype, as torchaudio's does
+    assert abs(c64[0] - float(cost)) <= ulp * abs(c64[0]), (c64[0], float(cost))
+    got = lg.grad.float().cpu().numpy()
+    err = np.abs(got - g64)
+    bound = 1e-5 + (1e-4 + ulp) * np.abs(g64)
+    if dt == torch.float16:
+        bound = bound + 6e-8                                  # float16 subnormal spacing: tiny gradient entries flush in steps
+    worst = float((err / bound).max())
+    at = np.unravel_index(int((err / bound).argmax()), err.shape)
+    print(f"{dt}: full-length utterance gradient vs f64 oracle, worst |err| / bound = {worst:.3f} at {at}: "
+          f"got {got[at]!r}, f64 {g64[at]!r}")
+    assert worst <= 1.0
+
+
 def test_full_baseline_shape_properties():
     """BASELINE.json configs[1] at full size (B=32, T=1000, U=150, V=5000, fp32; 96.6 GB of logits, gradient
     written in place).  north_star's bar -- loss and gradient within 1e-4 relative -- is checked AT THIS LATTICE
