@@ -1777,7 +1777,11 @@ int joint_fwd_split_launch(const float *ep_d, const float *pp_d, const float *w_
     // two per CU: W in two column slabs (a workgroup covers one; consecutive workgroups land on consecutive XCDs, so an
     // XCD keeps re-reading ONE slab) once the bf16 image exceeds an XCD's 4 MB L2 -- 8.20 -> 7.81 ms at V = 5000, J = 512
     // although every activation tile is then built twice; four slabs: 8.8 ms
-    if (two && tune_get(kTuneSplitParts) == 0 && img > (size_t)4 << 20) npart = 2;
+    // (larger vocabularies: as many slabs as keep one at <= 3 MB -- the measured case's 2.6 MB -- up to eight)
+    if (two && tune_get(kTuneSplitParts) == 0 && img > (size_t)4 << 20) {
+        npart = 2;
+        while (npart < 8 && img / npart > (size_t)3 << 20) npart *= 2;
+    }
     size_t tile_lds = (size_t)(terms == 3 ? 2 : 1) * cells * (Jp + 8) * sizeof(unsigned short);
     if (lse && tile_lds < joint_lse_exchange_bytes(kSWaves)) tile_lds = joint_lse_exchange_bytes(kSWaves);
     const size_t extra = 0;
