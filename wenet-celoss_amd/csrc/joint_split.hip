@@ -356,12 +356,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : OCC) void joint_fwd_split_ke
         for (int i = 0; i < PF; ++i) load_step(b1, i, qbh, qbl);
     }
     __syncthreads();
-#ifdef WR_X_STAGGER
-    if (OCC == 2 && (__builtin_amdgcn_s_getreg(4 | (3 << 11)) & 1)) {       // experiment: odd wave slots start their k-loop later
-#pragma unroll
-        for (int i = 0; i < WR_X_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);  // 1024 cycles each
-    }
-#endif
     WR_JS_NOW(js_t1);
 
     const unsigned short *a_hi = Ahi + (size_t)l31 * JS + 8 * half;
