@@ -257,13 +257,13 @@ int wr_joint_bwd_dz_split_bf16(const void *gout_bf16_d /* [B,T,U1,V] bf16 */, co
 
 /* Second half of the activation gradient for callers that form dH = gout . W themselves (the AMP step hands that plain
  * bf16 contraction to the vendor GEMM library): dz[cell, j] = dH[cell, j] * act'(ep + pp) in place (zero in padded cells
- * when lengths are given) and, unless h_d is NULL, h[cell, 0..J) = act(ep + pp) (zero in padded cells) as fp32 or bf16
+ * when lengths are given) and, unless h_d is NULL, h[cell, 0..J) = act(ep + pp) (zero in padded cells) as fp32, fp16 or bf16
  * with row stride h_ld >= J (a multiple of 4).  When h_ld > J, column J of a row is 1 in valid cells and 0 in padded
  * ones and columns J+1 .. h_ld-1 are 0: gout^T h then carries the bias gradient in column J.  J a multiple of 4. */
 int wr_joint_dz_act(float *dz_d /* [B,T,U1,J] in: dH, out: dZ */, const float *ep_d, const float *pp_d,
                     const int32_t *logit_lengths_d /* nullable */, const int32_t *target_lengths_d /* nullable */,
                     int B, int T, int U1, int J, int activation,
-                    void *h_d /* [B,T,U1,h_ld] or NULL */, int h_dtype /* WR_F32 | WR_BF16 */, int h_ld, void *stream);
+                    void *h_d /* [B,T,U1,h_ld] or NULL */, int h_dtype /* WR_F32 | WR_F16 | WR_BF16 */, int h_ld, void *stream);
 
 /* Bias gradient from a bf16 logits gradient: db[v] = sum over lattice cells of gout[cell, v], padded cells excluded when
  * lengths are given (the AMP step, whose weight gradient is a vendor-library GEMM).  V a multiple of 8.  Deterministic. */
@@ -273,6 +273,12 @@ int wr_joint_db_bf16(const void *gout_bf16_d /* [B,T,U1,V] bf16 */,
                      const int32_t *logit_lengths_d /* nullable */, const int32_t *target_lengths_d /* nullable */,
                      int B, int T, int U1, int V, float *db_d /* [V] */,
                      void *workspace_d, size_t workspace_bytes, void *stream);
+
+/* The same for a float16 gradient (torch.cuda.amp.autocast's default dtype, the reference's --use_amp). */
+int wr_joint_db_f16(const void *gout_f16_d /* [B,T,U1,V] fp16 */,
+                    const int32_t *logit_lengths_d /* nullable */, const int32_t *target_lengths_d /* nullable */,
+                    int B, int T, int U1, int V, float *db_d /* [V] */,
+                    void *workspace_d, size_t workspace_bytes, void *stream);
 
 /* Weight gradient of ffn_out:  dw[v, :] = sum over lattice cells of gout[cell, v] * h[cell, :],
  * db[v] = sum of gout[cell, v]  (h = tanh(ep+pp) as written by wr_joint_bwd_dz).  With lengths, cells in the

@@ -417,7 +417,32 @@ def test_amp_backward_library_gemms_match_the_single_term_kernels(monkeypatch, a
             assert float(got[0][pad.all(dim=2)].abs().max() if pad.all(dim=2).any() else 0.0) == 0.0
 
 
-@pytest.mark.parametrize("h_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_amp_backward_library_gemms_match_float64(dt):
+    """The library form of the AMP backward for both autocast dtypes (float16 is torch.cuda.amp.autocast's default, the
+    reference's --use_amp) against a float64 evaluation with the operands rounded as the step rounds them (W and H to the
+    gradient's dtype): 1e-3 of each result's r.m.s.; lengths given, padded cells excluded."""
+    from wenet_celoss_amd.joint import joint_backward
+    B, T, U1, J, V = 2, 21, 5, 96, 520
+    g = torch.Generator().manual_seed(5)
+    ep = torch.randn(B, T, J, generator=g).to(DEV); pp = torch.randn(B, U1, J, generator=g).to(DEV)
+    w = (torch.randn(V, J, generator=g) * 0.1).to(DEV)
+    gout = (torch.randn(B, T, U1, V, generator=g) * 0.3).to(DEV).to(dt)
+    ll = torch.tensor([21, 9], dtype=torch.int32, device=DEV); tl = torch.tensor([4, 2], dtype=torch.int32, device=DEV)
+    tt = torch.arange(T, device=DEV)[None, :, None] < ll[:, None, None]
+    uu = torch.arange(U1, device=DEV)[None, None, :] <= tl[:, None, None]
+    ok = (tt & uu)[..., None].double()
+    d_ep, d_pp, d_w, d_b = joint_backward(gout, ep, pp, w, ll, tl, 1, True, True)
+    g64 = gout.double() * ok
+    h = torch.tanh(ep[:, :, None, :] + pp[:, None, :, :]).double()
+    dz = (g64 @ w.to(dt).double()) * (1 - h * h) * ok
+    want = (dz.sum(2), dz.sum(1), g64.reshape(-1, V).T @ (h.to(dt).double() * ok).reshape(-1, J), g64.sum((0, 1, 2)))
+    for a_, b_ in zip((d_ep, d_pp, d_w, d_b), want):
+        assert a_.dtype == torch.float32
+        assert float((a_.double() - b_).abs().max()) <= 1e-3 * float(b_.pow(2).mean().sqrt()) + 1e-6
+
+
+@pytest.mark.parametrize("h_dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("act", ["tanh", "swish"])
 def test_dz_act_and_db_entry_points(h_dtype, act):
     """wr_joint_dz_act (activation gradient in place + the activation copy, fp32 or bf16, with the ones column when the row
@@ -446,7 +471,8 @@ def test_dz_act_and_db_entry_points(h_dtype, act):
             want_dz = (dh.double() * dact) * ok[..., None]
             torch.testing.assert_close(dz.double(), want_dz, rtol=2e-5, atol=2e-6)
             want_h = (hh.detach() * ok[..., None])
-            tol = dict(rtol=1e-5, atol=1e-6) if h_dtype == torch.float32 else dict(rtol=8e-3, atol=1e-6)
+            tol = dict(rtol=1e-5, atol=1e-6) if h_dtype == torch.float32 else dict(rtol=8e-3, atol=1e-6) \
+                if h_dtype == torch.bfloat16 else dict(rtol=1e-3, atol=1e-6)
             torch.testing.assert_close(h[..., :J].double(), want_h, **tol)
             if ld > J:
                 assert torch.equal(h[..., J].float(), ok.float())
@@ -463,6 +489,10 @@ def test_dz_act_and_db_entry_points(h_dtype, act):
     _lib.check(lib.wr_joint_db_bf16(P(gout), None, None, B, T, U1, V, P(db), P(ws), wsb, st))
     torch.testing.assert_close(db.double(), gout.double().sum(dim=(0, 1, 2)), rtol=1e-5, atol=1e-5)
     assert lib.wr_joint_db_bf16(P(gout), None, None, B, T, U1, 36, P(db), P(ws), wsb, st) != 0      # V % 8
+    g16 = gout.to(torch.float16)
+    _lib.check(lib.wr_joint_db_f16(P(g16), P(ll), P(tl), B, T, U1, V, P(db), P(ws), wsb, st))
+    want = torch.where(valid[..., None], g16.float(), torch.zeros((), device=DEV)).double().sum(dim=(0, 1, 2))
+    torch.testing.assert_close(db.double(), want, rtol=1e-5, atol=1e-5)
 
 
 def test_split_training_step_with_lengths_matches_exact(monkeypatch):

@@ -121,6 +121,7 @@ SIGNATURES = {
     "wr_joint_bwd_dz_split_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "wr_joint_db_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "wr_joint_db_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "wr_joint_db_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "wr_joint_dz_act": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "wr_joint_dw_split_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "wr_joint_bwd_dw_split_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),

@@ -1646,8 +1646,9 @@ __global__ void joint_dz_act_kernel(const float *__restrict__ ep, const float *_
                 *reinterpret_cast<f32x4 *>(hout + m * h_ld + j) = h4;
             } else {
                 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-                const bf16x2 p0 = __builtin_convertvector((f32x2){h4[0], h4[1]}, bf16x2);
-                const bf16x2 p1 = __builtin_convertvector((f32x2){h4[2], h4[3]}, bf16x2);
+                typedef HT h2 __attribute__((ext_vector_type(2)));
+                const h2 p0 = __builtin_convertvector((f32x2){h4[0], h4[1]}, h2);
+                const h2 p1 = __builtin_convertvector((f32x2){h4[2], h4[3]}, h2);
                 *reinterpret_cast<u32x2 *>(hout + m * h_ld + j) = (u32x2){__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
             }
             if (j == 0)
@@ -1987,7 +1988,8 @@ namespace wr {
 namespace {
 constexpr int kDbParts = 1024;
 constexpr int kDbThreads = 640;
-__global__ __launch_bounds__(kDbThreads) void joint_db_bf16_kernel(const __bf16 *__restrict__ gout, const unsigned char *__restrict__ mask,
+template <typename GT>
+__global__ __launch_bounds__(kDbThreads) void joint_db_bf16_kernel(const GT *__restrict__ gout, const unsigned char *__restrict__ mask,
                                                                    long M, int V, long rows_per_part, float *__restrict__ part)
 {
     const int v = (blockIdx.x * kDbThreads + threadIdx.x) * 8;
@@ -1995,7 +1997,7 @@ __global__ __launch_bounds__(kDbThreads) void joint_db_bf16_kernel(const __bf16 
     const long r1 = r0 + rows_per_part < M ? r0 + rows_per_part : M;
     if (v >= V) return;                                     // V % 8 == 0: a thread's columns are wholly in or out
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const __bf16 *__restrict__ p = gout + v;
+    const GT *__restrict__ p = gout + v;
     constexpr int R = 8;                                    // rows in flight per thread (rows past the range repeat the last
     for (long m = r0; m < r1; m += R) {                     // one with weight 0)
         u32x4 x[R];
@@ -2010,8 +2012,18 @@ __global__ __launch_bounds__(kDbThreads) void joint_db_bf16_kernel(const __bf16 
         for (int q = 0; q < R; ++q)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                acc[2 * i] += on[q] ? __builtin_bit_cast(float, x[q][i] << 16) : 0.f;       // a select: padded cells may hold anything
-                acc[2 * i + 1] += on[q] ? __builtin_bit_cast(float, x[q][i] & 0xffff0000u) : 0.f;
+                float lo, hi;
+                if constexpr (std::is_same<GT, __bf16>::value) {
+                    lo = __builtin_bit_cast(float, x[q][i] << 16);
+                    hi = __builtin_bit_cast(float, x[q][i] & 0xffff0000u);
+                } else {
+                    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+                    const f16x8 hv = __builtin_bit_cast(f16x8, x[q]);
+                    lo = (float)hv[2 * i];
+                    hi = (float)hv[2 * i + 1];
+                }
+                acc[2 * i] += on[q] ? lo : 0.f;             // a select: padded cells may hold anything
+                acc[2 * i + 1] += on[q] ? hi : 0.f;
             }
     }
     float *__restrict__ o = part + (size_t)blockIdx.y * V + v;
@@ -2035,8 +2047,9 @@ extern "C" size_t wr_joint_db_workspace_bytes(int B, int T, int U1, int V)
     return wr::align_up((size_t)wr::kDbParts * V * sizeof(float), 256) + wr::align_up((size_t)B * T * U1, 256);
 }
 
-extern "C" int wr_joint_db_bf16(const void *gout_bf16_d, const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B,
-                                int T, int U1, int V, float *db_d, void *workspace_d, size_t workspace_bytes, void *stream)
+namespace {
+int joint_db_16_launch(const void *gout_bf16_d, bool f16, const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B,
+                       int T, int U1, int V, float *db_d, void *workspace_d, size_t workspace_bytes, void *stream)
 {
     using namespace wr;
     WR_REQUIRE(B > 0 && T > 0 && U1 > 0 && V > 0 && V % 8 == 0, WR_EINVAL, "joint_db_bf16: sizes must be positive, V a multiple of 8");
@@ -2055,12 +2068,31 @@ extern "C" int wr_joint_db_bf16(const void *gout_bf16_d, const int32_t *logit_le
     }
     const int parts = M < kDbParts ? (int)M : kDbParts;
     const long rows_per_part = (M + parts - 1) / parts;
-    hipLaunchKernelGGL(joint_db_bf16_kernel, dim3((V / 8 + kDbThreads - 1) / kDbThreads, parts), dim3(kDbThreads), 0, st,
-                       static_cast<const __bf16 *>(gout_bf16_d), mask, M, V, rows_per_part, part);
+    if (f16)
+        hipLaunchKernelGGL(joint_db_bf16_kernel<_Float16>, dim3((V / 8 + kDbThreads - 1) / kDbThreads, parts), dim3(kDbThreads), 0, st,
+                           static_cast<const _Float16 *>(gout_bf16_d), mask, M, V, rows_per_part, part);
+    else
+        hipLaunchKernelGGL(joint_db_bf16_kernel<__bf16>, dim3((V / 8 + kDbThreads - 1) / kDbThreads, parts), dim3(kDbThreads), 0, st,
+                           static_cast<const __bf16 *>(gout_bf16_d), mask, M, V, rows_per_part, part);
     WR_CHECK_LAUNCH("joint_db_bf16_kernel");
     hipLaunchKernelGGL(joint_db_reduce_kernel, dim3((V + 255) / 256), dim3(256), 0, st, part, parts, V, db_d);
     WR_CHECK_LAUNCH("joint_db_reduce_kernel");
     return WR_OK;
+}
+}  // namespace
+
+extern "C" int wr_joint_db_bf16(const void *gout_bf16_d, const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B,
+                                int T, int U1, int V, float *db_d, void *workspace_d, size_t workspace_bytes, void *stream)
+{
+    return joint_db_16_launch(gout_bf16_d, false, logit_lengths_d, target_lengths_d, B, T, U1, V, db_d, workspace_d, workspace_bytes,
+                              stream);
+}
+
+extern "C" int wr_joint_db_f16(const void *gout_f16_d, const int32_t *logit_lengths_d, const int32_t *target_lengths_d, int B,
+                               int T, int U1, int V, float *db_d, void *workspace_d, size_t workspace_bytes, void *stream)
+{
+    return joint_db_16_launch(gout_f16_d, true, logit_lengths_d, target_lengths_d, B, T, U1, V, db_d, workspace_d, workspace_bytes,
+                              stream);
 }
 
 extern "C" int wr_joint_dz_act(float *dz_d, const float *ep_d, const float *pp_d, const int32_t *logit_lengths_d,
@@ -2072,13 +2104,16 @@ extern "C" int wr_joint_dz_act(float *dz_d, const float *ep_d, const float *pp_d
     WR_REQUIRE(dz_d && ep_d && pp_d, WR_EINVAL, "joint_dz_act: null pointer argument");
     WR_REQUIRE((logit_lengths_d == nullptr) == (target_lengths_d == nullptr), WR_EINVAL,
                "joint_dz_act: pass both length arrays or neither");
-    WR_REQUIRE(h_d == nullptr || ((h_dtype == WR_F32 || h_dtype == WR_BF16) && h_ld >= J && h_ld % 4 == 0), WR_EINVAL,
-               "joint_dz_act: h must be fp32 or bf16 with a row stride >= J that is a multiple of 4");
+    WR_REQUIRE(h_d == nullptr || ((h_dtype == WR_F32 || h_dtype == WR_BF16 || h_dtype == WR_F16) && h_ld >= J && h_ld % 4 == 0),
+               WR_EINVAL, "joint_dz_act: h must be fp32, fp16 or bf16 with a row stride >= J that is a multiple of 4");
     const long M = (long)B * T * U1;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (h_d != nullptr && h_dtype == WR_BF16)
         hipLaunchKernelGGL(joint_dz_act_kernel<__bf16>, dim3(256 * 16), dim3(256), 0, st, ep_d, pp_d, logit_lengths_d,
                            target_lengths_d, T, U1, J, M, activation, dz_d, static_cast<__bf16 *>(h_d), h_ld);
+    else if (h_d != nullptr && h_dtype == WR_F16)
+        hipLaunchKernelGGL(joint_dz_act_kernel<_Float16>, dim3(256 * 16), dim3(256), 0, st, ep_d, pp_d, logit_lengths_d,
+                           target_lengths_d, T, U1, J, M, activation, dz_d, static_cast<_Float16 *>(h_d), h_ld);
     else
         hipLaunchKernelGGL(joint_dz_act_kernel<float>, dim3(256 * 16), dim3(256), 0, st, ep_d, pp_d, logit_lengths_d,
                            target_lengths_d, T, U1, J, M, activation, dz_d, static_cast<float *>(h_d), h_d ? h_ld : J);

@@ -122,8 +122,8 @@ def _mm_takes_out_dtype() -> bool:
 
 
 def _amp_backward_library(lib, gout, ep, pp, w, llens, tlens, need_w, need_b, gout_zero_in_padding, act):
-    """Single-term (AMP) backward with a bf16 logits gradient: the two contractions dH = dY W and [dW | db] = dY^T [H | 1]
-    are plain bf16 GEMMs with fp32 accumulation and fp32 results -- they go to the vendor GEMM library (measured at the
+    """Single-term (AMP) backward with a 16-bit (bfloat16 or float16) logits gradient: the two contractions dH = dY W and [dW | db] = dY^T [H | 1]
+    are plain 16-bit GEMMs with fp32 accumulation and fp32 results -- they go to the vendor GEMM library (measured at the
     B = 16 BASELINE slice: 11.9 + 15.8 ms against 23.0 + 34.5 ms for this package's single-term kernels, which stay
     reachable with WR_AMP_BACKWARD=kernels); what is fused around them stays here: ``wr_joint_dz_act`` applies the
     activation's derivative to dH in place and writes H in bf16 (zero in padded cells), ``wr_joint_db_bf16`` sums the
@@ -134,11 +134,12 @@ def _amp_backward_library(lib, gout, ep, pp, w, llens, tlens, need_w, need_b, go
     dev = ep.device
     M = B * T * U1
     g2 = gout.view(M, V)
-    dz = torch.mm(g2, w.to(torch.bfloat16), out_dtype=torch.float32).view(B, T, U1, J)
-    hb = torch.empty(M, J, dtype=torch.bfloat16, device=dev) if need_w else None
+    dt = gout.dtype                                 # bfloat16, or float16 (autocast's default dtype: the reference's --use_amp)
+    dz = torch.mm(g2, w.to(dt), out_dtype=torch.float32).view(B, T, U1, J)
+    hb = torch.empty(M, J, dtype=dt, device=dev) if need_w else None
     with torch.cuda.device(dev):
         rc = lib.wr_joint_dz_act(_lib.ptr(dz), _lib.ptr(ep), _lib.ptr(pp), _lib.ptr(llens), _lib.ptr(tlens), B, T, U1, J, act,
-                                 _lib.ptr(hb), _lib.dtype_code(torch.bfloat16), J, _lib.current_stream(dev))
+                                 _lib.ptr(hb), _lib.dtype_code(dt), J, _lib.current_stream(dev))
     _lib.check(rc, "wr_joint_dz_act")
     d_ep = dz.sum(dim=2)
     d_pp = dz.sum(dim=1)
@@ -152,8 +153,9 @@ def _amp_backward_library(lib, gout, ep, pp, w, llens, tlens, need_w, need_b, go
         if gout_zero_in_padding:
             llens = tlens = None
         with torch.cuda.device(dev):
-            rc = lib.wr_joint_db_bf16(_lib.ptr(g2), _lib.ptr(llens), _lib.ptr(tlens), B, T, U1, V, _lib.ptr(d_b), _lib.ptr(ws),
-                                      wsb, _lib.current_stream(dev))
+            fn = lib.wr_joint_db_bf16 if dt == torch.bfloat16 else lib.wr_joint_db_f16
+            rc = fn(_lib.ptr(g2), _lib.ptr(llens), _lib.ptr(tlens), B, T, U1, V, _lib.ptr(d_b), _lib.ptr(ws),
+                    wsb, _lib.current_stream(dev))
         _lib.check(rc, "wr_joint_db_bf16")
     return d_ep, d_pp, d_w, d_b
 
@@ -172,10 +174,12 @@ def joint_backward(gout, ep, pp, w, llens, tlens, terms: int, need_w: bool, need
     dev = ep.device
     # AMP step: the loss hands back a bf16 gradient for bf16 logits; the split kernels take it as it is (bf16 values are
     # their own hi parts) -- no widening pass over the logits-sized tensor, half the gradient bytes in dZ and dW
-    g16 = gout.dtype == torch.bfloat16 and terms != 0 and V % 8 == 0 and V >= 32 and J % 4 == 0
+    ok16 = terms != 0 and V % 8 == 0 and V >= 32 and J % 4 == 0
+    if (ok16 and terms == 1 and gout.dtype in (torch.bfloat16, torch.float16)
+            and os.environ.get("WR_AMP_BACKWARD", "library") != "kernels" and _mm_takes_out_dtype()):
+        return _amp_backward_library(lib, gout.contiguous(), ep, pp, w, llens, tlens, need_w, need_b, gout_zero_in_padding, act)
+    g16 = gout.dtype == torch.bfloat16 and ok16
     gout = gout.contiguous() if g16 else gout.float().contiguous()
-    if g16 and terms == 1 and os.environ.get("WR_AMP_BACKWARD", "library") != "kernels" and _mm_takes_out_dtype():
-        return _amp_backward_library(lib, gout, ep, pp, w, llens, tlens, need_w, need_b, gout_zero_in_padding, act)
     dz = torch.empty(B, T, U1, J, dtype=torch.float32, device=dev)
     h = torch.empty_like(dz) if need_w else None
     if terms != 0 and V % 4 == 0 and V >= 32:       # same split as the forward (gradient rows 16-byte aligned)
